@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — tracked features/s of the pyramidal KLT hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): BasicKlt inverse,
+2000 features, 640x480 synthetic pair, 4-level pyramid, 21x21 patch — per GPU (weak scaling).
+A step = ONE TrackFeatures pass over the batch: one kernel launch on device-resident inputs
+(pyramids, ref_uv, predicted cur_uv, status already in HBM) writing (u, v) + status, and for
+N > 1 the RCCL all-gather of every rank's packed result shard.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
+  roofline     : algorithmic bytes of the tracker kernel / its average launch duration (HIP events
+                 on the launch stream) against the 8 TB/s HBM peak; traffic = PMC-derived bytes per
+                 launch when profiles/ holds a counter summary, else null.
+  cpu_baseline : the oracle (CPU restatement, single thread) timed on a bounded sample of the same
+                 workload on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(iters: np.ndarray, levels: int, half: int, method: str) -> int:
+    """B(f) = sum_l [R + it(f,l) * C] + 26 with R, C the image footprints of the
+    gradient-side and residual-side samples; it(f, .) is counted by the kernel."""
+    if method == "direct":
+        r, c = (2 * half + 2) ** 2, (2 * half + 4) ** 2
+    else:
+        r, c = (2 * half + 4) ** 2, (2 * half + 2) ** 2
+    return int(iters.size * (levels * r + 26) + int(iters.astype(np.int64).sum()) * c)
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("klt_config2_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(cfg, ref_levels, cur_levels, uv, budget_s=12.0):
+    """Times the oracle on this host: single thread (the reference has no threads), whole 2000-feature
+    calls repeated until ~budget_s of CPU work, median per-call time."""
+    from tests import oracle_lib
+
+    oracle_lib.lib()
+    times = []
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        oracle_lib.klt_track_pyramid(cfg["model"], ref_levels, cur_levels, uv, method=cfg["method"], half=cfg["half"], max_points=cfg["n"])
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s or len(times) >= 200:
+            break
+    med = float(np.median(times))
+    return {
+        "value": cfg["n"] / med, "unit": "tracked features/s", "cores": 1, "kind": "port",
+        "sample": f"{len(times)} full calls of the workload ({cfg['n']} features each), median {med * 1e3:.2f} ms/call, "
+                  f"oracle/liboracle.so (gcc -O3, no -march, -ffp-contract=off), host cpus={os.cpu_count()}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config2", help="feature_tracker_amd.synth.CONFIGS key")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import dist as FD
+    from feature_tracker_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synth.CONFIGS[args.workload]
+    n, w, h, levels, half = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
+    if cfg["model"] == "basic":
+        ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))
+    else:
+        ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1), rotation_deg=1.5, scale=1.02)
+    ref_levels = synth.build_pyramid(ref_img, levels)
+    cur_levels = synth.build_pyramid(cur_img, levels)
+    # weak scaling: every rank tracks its own n features (different seeds), pyramids replicated
+    uv = synth.make_features(n, w, h, seed=12345 + rank, half=half)
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, local_rank)
+        ref_pyr = D.upload_pyramid(ref_levels, ctx, dev)
+        cur_pyr = D.upload_pyramid(cur_levels, ctx, dev)
+        opt = F.OpticalFlowOptions()
+        opt.kMethod = cfg["method"]
+        opt.kPatchRowHalfSize = opt.kPatchColHalfSize = half
+        opt.kMaxTrackPointsNumber = n
+        klt = D.DeviceKlt(cfg["model"], opt, ref_pyr, cur_pyr, ctx)
+
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_cur_in = d_ref.clone()  # no prediction: cur = ref (optical_flow.cpp:12-14)
+        d_st_in = torch.zeros(n, dtype=torch.uint8, device=dev)
+        packed = torch.zeros(FD.packed_bytes(n), dtype=torch.uint8, device=dev)
+        d_cur_out, d_st_out = FD.pack_views(packed, n)
+        d_iters = torch.zeros(n, dtype=torch.int32, device=dev)
+
+        def step(with_iters=False):
+            klt.track(d_ref, d_cur_in, d_st_in, d_cur_out, d_st_out, d_iters if with_iters else None)
+            if world > 1:
+                return FD.all_gather_results(packed, world)
+            return packed
+
+        step(with_iters=True)
+        stream.synchronize()
+        iters = d_iters.cpu().numpy().astype(np.uint32)
+        status = d_st_out.cpu().numpy()
+        for _ in range(args.warmup):
+            step()
+        stream.synchronize()
+
+        # kernel-only duration: HIP events on the launch stream around the tracker launches of the timed region
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev0[k].record(stream)
+            klt.track(d_ref, d_cur_in, d_st_in, d_cur_out, d_st_out, None)
+            ev1[k].record(stream)
+            if world > 1:
+                FD.all_gather_results(packed, world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    if rank == 0:
+        total_features = n * world * args.steps
+        value = total_features / elapsed
+        algo = algorithmic_bytes(iters, levels, half, cfg["method"])
+        achieved = algo / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": value, "unit": "tracked features/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['model']} KLT {cfg['method']}, {n} features/GPU, {w}x{h}, {levels}-level pyramid, "
+                                   f"{2 * half + 1}x{2 * half + 1} patch", "parallelism": f"features sharded x{world}, pyramids replicated, "
+                       "one all-gather of packed (uv,status) per step" if world > 1 else "single GPU",
+                       "tracked_fraction": float((status == 1).mean()), "mean_iterations_per_feature": float(iters.mean())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(), "kernel": "klt_track_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

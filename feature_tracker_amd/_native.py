@@ -1,0 +1,121 @@
+"""ctypes binding of libftk_hip.so (C ABI in include/ftk.h).
+
+The library is built in-tree by ``feature_tracker_amd/csrc/Makefile`` (hipcc, gfx950).  Loading
+fails loudly when it is missing: there is no Python / CPU fallback for any compute entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libftk_hip.so")
+
+FTK_OK = 0
+FTK_MAX_LEVELS = 12
+ERROR_NAMES = {0: "FTK_OK", -1: "FTK_E_INVALID_ARGUMENT", -2: "FTK_E_NO_DEVICE", -3: "FTK_E_HIP", -4: "FTK_E_UNSUPPORTED",
+               -5: "FTK_E_OUT_OF_MEMORY"}
+
+MODELS = {"basic": 0, "affine": 1, "lssd": 2}
+METHODS = {"inverse": 0, "direct": 1, "fast": 2, "sse": 3, "neon": 4}
+
+# every symbol include/ftk.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "ftk_abi_version", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
+    "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
+    "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
+    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_fill_matched_pixels",
+]
+
+
+class FtkError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class KltOptions(C.Structure):
+    """OpticalFlowOptions (optical_flow.h:20-28)."""
+    _fields_ = [
+        ("max_track_points", C.c_uint32), ("max_iteration", C.c_uint32), ("max_tolerance_large_step", C.c_uint32),
+        ("half_rows", C.c_int32), ("half_cols", C.c_int32), ("max_converge_step", C.c_float), ("method", C.c_int32),
+    ]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libftk_hip.so for gfx950 with the committed Makefile (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".cpp", ".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "ftk.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        cmd = ["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else []) + ["libftk_hip.so"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("building libftk_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+        if verbose:
+            print(res.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch wheels bundle their own HIP / HSA runtime.  Two runtimes in one process do not share
+    # the device, so when torch is installed it must be loaded FIRST: libftk_hip.so then binds to
+    # the same libamdhip64.so.7 (same SONAME) and device pointers / streams are interchangeable.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension must be built first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C feature_tracker_amd/csrc). "
+            "feature_tracker_amd has no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    vp, i32, u32p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)
+    l.ftk_abi_version.restype = C.c_int
+    l.ftk_device_count.restype = C.c_int
+    l.ftk_context_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    l.ftk_context_destroy.argtypes = [vp]
+    l.ftk_context_destroy.restype = None
+    l.ftk_last_error.argtypes = [vp]
+    l.ftk_last_error.restype = C.c_char_p
+    l.ftk_synchronize.argtypes = [vp]
+    l.ftk_default_klt_options.argtypes = [C.POINTER(KltOptions)]
+    l.ftk_default_klt_options.restype = None
+    l.ftk_pyramid_upload.argtypes = [vp, C.POINTER(Image), i32, C.POINTER(vp)]
+    l.ftk_pyramid_wrap_device.argtypes = [vp, C.POINTER(Image), i32, C.POINTER(vp)]
+    l.ftk_pyramid_build.argtypes = [vp, vp, i32, i32, i32, C.c_int, C.POINTER(vp)]
+    l.ftk_pyramid_levels.argtypes = [vp]
+    l.ftk_pyramid_level.argtypes = [vp, i32, C.POINTER(Image)]
+    l.ftk_pyramid_download_level.argtypes = [vp, vp, i32, vp]
+    l.ftk_pyramid_destroy.argtypes = [vp]
+    l.ftk_pyramid_destroy.restype = None
+    l.ftk_klt_track.argtypes = [vp, C.c_int, C.POINTER(KltOptions), vp, vp, vp, vp, vp, i32, vp, C.c_int, C.c_int, vp]
+    l.ftk_klt_track_device.argtypes = [vp, C.c_int, C.POINTER(KltOptions), vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_int, C.c_int, vp]
+    l.ftk_extract_extend_patch.argtypes = [vp, vp, i32, C.c_float, C.c_float, i32, i32, vp, vp, u32p]
+    l.ftk_hamming_match.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
+    l.ftk_hamming_match_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, vp]
+    l.ftk_fill_matched_pixels.argtypes = [vp, i32, vp, i32, vp, vp]
+    _lib = l
+    return l
+
+
+def check(rc: int, ctx_handle=None) -> None:
+    if rc != FTK_OK:
+        msg = lib().ftk_last_error(ctx_handle)
+        raise FtkError(rc, msg.decode() if msg else "")

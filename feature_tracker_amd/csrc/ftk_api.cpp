@@ -1,0 +1,715 @@
+// ftk_api.cpp — the C ABI of libftk_hip.so (declared in include/ftk.h).
+//
+// Host-side plumbing only: argument validation, device buffers, stream ordering, launches.
+// All numerics live in the kernels.  There is deliberately no CPU fallback: if HIP is not
+// usable every compute entry point fails with FTK_E_NO_DEVICE / FTK_E_HIP.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ftk_device.h"
+
+using ftk::DevImage;
+
+struct ftk_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string error;
+    // cached device scratch for the host-buffer entry points
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    unsigned long long *match_keys = nullptr;
+    size_t match_keys_count = 0;
+};
+
+struct ftk_pyramid {
+    int device = 0;
+    int32_t n_levels = 0;
+    DevImage levels[FTK_MAX_LEVELS];
+    uint8_t *owned = nullptr;  // single allocation holding every owned level
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(ftk_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) {
+        ctx->error = buf;
+    } else {
+        g_create_error = buf;
+    }
+    return code;
+}
+
+#define FTK_HIP(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? FTK_E_OUT_OF_MEMORY : FTK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                                    \
+    } while (0)
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int ensure_scratch(ftk_context *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) {
+        return FTK_OK;
+    }
+    if (ctx->scratch) {
+        FTK_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 2, 4096);
+    FTK_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return FTK_OK;
+}
+
+int ensure_match_keys(ftk_context *ctx, size_t count) {
+    if (count <= ctx->match_keys_count) {
+        return FTK_OK;
+    }
+    if (ctx->match_keys) {
+        FTK_HIP(ctx, hipFree(ctx->match_keys));
+        ctx->match_keys = nullptr;
+        ctx->match_keys_count = 0;
+    }
+    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->match_keys), sizeof(unsigned long long) * count));
+    ctx->match_keys_count = count;
+    return FTK_OK;
+}
+
+uint32_t div_magic(int32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+
+int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, int32_t n,
+                    const float *prior, int consider_luminance, int single_level, ftk::KltParams *out) {
+    if (!opt || !ref || !cur) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: null options or pyramid");
+    }
+    if (model < FTK_MODEL_BASIC || model > FTK_MODEL_LSSD) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: unknown model %d", model);
+    }
+    if (opt->method < FTK_METHOD_INVERSE || opt->method > FTK_METHOD_NEON) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: unknown method %d", opt->method);
+    }
+    if (ref->n_levels != cur->n_levels) {
+        // OpticalFlow::TrackFeatures returns false here (optical_flow.cpp:9); callers above the ABI handle it
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: pyramid level mismatch (%d vs %d)", ref->n_levels, cur->n_levels);
+    }
+    if (ref->n_levels < 1) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: empty pyramid");
+    }
+    if (ref->device != ctx->device || cur->device != ctx->device) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: pyramid lives on another device");
+    }
+    if (opt->half_rows < 0 || opt->half_cols < 0 || opt->half_rows > 63 || opt->half_cols > 63) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "klt: half patch size (%d, %d) outside [0, 63]", opt->half_rows, opt->half_cols);
+    }
+    ftk::KltParams &p = *out;
+    memset(&p, 0, sizeof(p));
+    p.n_levels = single_level ? 1 : ref->n_levels;
+    p.single_level = single_level ? 1 : 0;
+    for (int i = 0; i < p.n_levels; ++i) {
+        p.ref[i] = ref->levels[i];
+        p.cur[i] = cur->levels[i];
+        if (p.ref[i].rows < 2 || p.ref[i].cols < 2 || p.cur[i].rows < 2 || p.cur[i].cols < 2) {
+            return fail(ctx, FTK_E_UNSUPPORTED, "klt: pyramid level %d smaller than 2x2", i);
+        }
+    }
+    p.n = n;
+    p.n_track = ((uint32_t)n < opt->max_track_points) ? (uint32_t)n : opt->max_track_points;
+    p.max_iteration = opt->max_iteration;
+    p.max_large_step = opt->max_tolerance_large_step;
+    p.half_rows = opt->half_rows;
+    p.half_cols = opt->half_cols;
+    p.converge = opt->max_converge_step;
+    static const float identity[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+    const float *pr = prior ? prior : identity;
+    for (int i = 0; i < 4; ++i) {
+        p.prior[i] = pr[i];
+    }
+    p.consider_luminance = consider_luminance ? 1 : 0;
+    p.patch_rows = 2 * opt->half_rows + 1;
+    p.patch_cols = 2 * opt->half_cols + 1;
+    p.P = p.patch_rows * p.patch_cols;
+    p.Ppad = (p.P + 3) & ~3;
+    p.ex_rows = p.patch_rows + 2;
+    p.ex_cols = p.patch_cols + 2;
+    p.E = p.ex_rows * p.ex_cols;
+    p.magic_pc = div_magic(p.patch_cols);
+    p.magic_exc = div_magic(p.ex_cols);
+    const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
+    if (lds == 0 || lds > 160 * 1024) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu B of LDS (limit 163840)", p.patch_rows, p.patch_cols, lds);
+    }
+    return FTK_OK;
+}
+
+int make_pyramid(ftk_context *ctx, ftk_pyramid **out) {
+    if (!ctx || !out) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: null context or output");
+    }
+    ftk_pyramid *pyr = new (std::nothrow) ftk_pyramid();
+    if (!pyr) {
+        return fail(ctx, FTK_E_OUT_OF_MEMORY, "pyramid: host allocation failed");
+    }
+    pyr->device = ctx->device;
+    *out = pyr;
+    return FTK_OK;
+}
+
+int check_levels(ftk_context *ctx, const ftk_image *levels, int32_t n_levels) {
+    if (!levels || n_levels < 1 || n_levels > FTK_MAX_LEVELS) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: n_levels %d outside [1, %d]", n_levels, FTK_MAX_LEVELS);
+    }
+    for (int i = 0; i < n_levels; ++i) {
+        if (!levels[i].data || levels[i].rows <= 0 || levels[i].cols <= 0) {
+            return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: level %d is empty", i);
+        }
+    }
+    return FTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ftk_abi_version(void) { return FTK_ABI_VERSION; }
+
+int ftk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+void ftk_default_klt_options(ftk_klt_options *opt) {
+    if (!opt) {
+        return;
+    }
+    opt->max_track_points = 500;
+    opt->max_iteration = 15;
+    opt->max_tolerance_large_step = 3;
+    opt->half_rows = 6;
+    opt->half_cols = 6;
+    opt->max_converge_step = 4e-2f;
+    opt->method = FTK_METHOD_FAST;
+}
+
+int ftk_context_create(int device, void *stream, ftk_context **out) {
+    if (!out) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "context: null output pointer");
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        return fail(nullptr, FTK_E_NO_DEVICE, "context: no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device < 0) {
+        FTK_HIP(nullptr, hipGetDevice(&device));
+    }
+    if (device >= count) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "context: device %d out of range (have %d)", device, count);
+    }
+    FTK_HIP(nullptr, hipSetDevice(device));
+    ftk_context *ctx = new (std::nothrow) ftk_context();
+    if (!ctx) {
+        return fail(nullptr, FTK_E_OUT_OF_MEMORY, "context: host allocation failed");
+    }
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+        ctx->owns_stream = false;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete ctx;
+            return fail(nullptr, FTK_E_HIP, "context: hipStreamCreate failed: %s", hipGetErrorString(se));
+        }
+        ctx->owns_stream = true;
+    }
+    *out = ctx;
+    return FTK_OK;
+}
+
+void ftk_context_destroy(ftk_context *ctx) {
+    if (!ctx) {
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) {
+        (void)hipFree(ctx->scratch);
+    }
+    if (ctx->match_keys) {
+        (void)hipFree(ctx->match_keys);
+    }
+    if (ctx->owns_stream) {
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char *ftk_last_error(const ftk_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int ftk_synchronize(ftk_context *ctx) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "synchronize: null context");
+    }
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- pyramids ------------------------------------------------------------------------------ */
+
+int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n_levels, ftk_pyramid **out) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_upload: null context");
+    }
+    int rc = check_levels(ctx, host_levels, n_levels);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t offsets[FTK_MAX_LEVELS];
+    size_t total = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        offsets[i] = total;
+        total += align_up((size_t)host_levels[i].rows * host_levels[i].cols, 256);
+    }
+    ftk_pyramid *pyr = nullptr;
+    rc = make_pyramid(ctx, &pyr);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&pyr->owned), total);
+    if (e != hipSuccess) {
+        delete pyr;
+        return fail(ctx, FTK_E_OUT_OF_MEMORY, "pyramid_upload: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    }
+    pyr->n_levels = n_levels;
+    for (int i = 0; i < n_levels; ++i) {
+        const size_t bytes = (size_t)host_levels[i].rows * host_levels[i].cols;
+        e = hipMemcpyAsync(pyr->owned + offsets[i], host_levels[i].data, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            ftk_pyramid_destroy(pyr);
+            return fail(ctx, FTK_E_HIP, "pyramid_upload: copy of level %d failed: %s", i, hipGetErrorString(e));
+        }
+        pyr->levels[i].data = pyr->owned + offsets[i];
+        pyr->levels[i].rows = host_levels[i].rows;
+        pyr->levels[i].cols = host_levels[i].cols;
+    }
+    e = hipStreamSynchronize(ctx->stream);  // the host buffers may be released by the caller right after return
+    if (e != hipSuccess) {
+        ftk_pyramid_destroy(pyr);
+        return fail(ctx, FTK_E_HIP, "pyramid_upload: synchronize failed: %s", hipGetErrorString(e));
+    }
+    *out = pyr;
+    return FTK_OK;
+}
+
+int ftk_pyramid_wrap_device(ftk_context *ctx, const ftk_image *device_levels, int32_t n_levels, ftk_pyramid **out) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_wrap_device: null context");
+    }
+    int rc = check_levels(ctx, device_levels, n_levels);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    ftk_pyramid *pyr = nullptr;
+    rc = make_pyramid(ctx, &pyr);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    pyr->n_levels = n_levels;
+    for (int i = 0; i < n_levels; ++i) {
+        pyr->levels[i].data = device_levels[i].data;
+        pyr->levels[i].rows = device_levels[i].rows;
+        pyr->levels[i].cols = device_levels[i].cols;
+    }
+    *out = pyr;
+    return FTK_OK;
+}
+
+int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int32_t cols, int32_t n_levels, int image_on_device,
+                      ftk_pyramid **out) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_build: null context");
+    }
+    if (!image || rows <= 0 || cols <= 0 || n_levels < 1 || n_levels > FTK_MAX_LEVELS || !out) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_build: bad image or level count");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t lrows[FTK_MAX_LEVELS], lcols[FTK_MAX_LEVELS];
+    size_t offsets[FTK_MAX_LEVELS];
+    size_t total = 0;
+    lrows[0] = rows;
+    lcols[0] = cols;
+    for (int i = 0; i < n_levels; ++i) {
+        if (i > 0) {
+            lrows[i] = lrows[i - 1] / 2;
+            lcols[i] = lcols[i - 1] / 2;
+            if (lrows[i] <= 0 || lcols[i] <= 0) {
+                return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_build: level %d would be empty", i);
+            }
+        }
+        offsets[i] = total;
+        if (i > 0 || !image_on_device) {
+            total += align_up((size_t)lrows[i] * lcols[i], 256);
+        }
+    }
+    ftk_pyramid *pyr = nullptr;
+    int rc = make_pyramid(ctx, &pyr);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    if (total > 0) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&pyr->owned), total);
+        if (e != hipSuccess) {
+            delete pyr;
+            return fail(ctx, FTK_E_OUT_OF_MEMORY, "pyramid_build: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        }
+    }
+    pyr->n_levels = n_levels;
+    hipError_t e = hipSuccess;
+    if (image_on_device) {
+        pyr->levels[0].data = image;
+    } else {
+        e = hipMemcpyAsync(pyr->owned, image, (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream);
+        pyr->levels[0].data = pyr->owned;
+    }
+    pyr->levels[0].rows = rows;
+    pyr->levels[0].cols = cols;
+    for (int i = 1; i < n_levels && e == hipSuccess; ++i) {
+        uint8_t *dst = pyr->owned + offsets[i];
+        e = ftk::pyramid_downsample_launch(pyr->levels[i - 1].data, lrows[i - 1], lcols[i - 1], dst, ctx->stream);
+        pyr->levels[i].data = dst;
+        pyr->levels[i].rows = lrows[i];
+        pyr->levels[i].cols = lcols[i];
+    }
+    if (e == hipSuccess && !image_on_device) {
+        e = hipStreamSynchronize(ctx->stream);  // host image may be released by the caller
+    }
+    if (e != hipSuccess) {
+        ftk_pyramid_destroy(pyr);
+        return fail(ctx, FTK_E_HIP, "pyramid_build: %s", hipGetErrorString(e));
+    }
+    *out = pyr;
+    return FTK_OK;
+}
+
+int ftk_pyramid_levels(const ftk_pyramid *pyr) { return pyr ? pyr->n_levels : 0; }
+
+int ftk_pyramid_level(const ftk_pyramid *pyr, int32_t level, ftk_image *out) {
+    if (!pyr || !out || level < 0 || level >= pyr->n_levels) {
+        return FTK_E_INVALID_ARGUMENT;
+    }
+    out->data = pyr->levels[level].data;
+    out->rows = pyr->levels[level].rows;
+    out->cols = pyr->levels[level].cols;
+    return FTK_OK;
+}
+
+int ftk_pyramid_download_level(ftk_context *ctx, const ftk_pyramid *pyr, int32_t level, uint8_t *host_out) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_download_level: null context");
+    }
+    if (!pyr || !host_out || level < 0 || level >= pyr->n_levels) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_download_level: bad arguments");
+    }
+    const size_t bytes = (size_t)pyr->levels[level].rows * pyr->levels[level].cols;
+    FTK_HIP(ctx, hipMemcpyAsync(host_out, pyr->levels[level].data, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+void ftk_pyramid_destroy(ftk_pyramid *pyr) {
+    if (!pyr) {
+        return;
+    }
+    if (pyr->owned) {
+        (void)hipSetDevice(pyr->device);
+        (void)hipFree(pyr->owned);
+    }
+    delete pyr;
+}
+
+/* ---- KLT ----------------------------------------------------------------------------------- */
+
+int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur,
+                         const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out, const uint8_t *d_status_in,
+                         uint8_t *d_status_out, int32_t n, const float *prior, int consider_luminance, int single_level, uint32_t *d_iters) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "klt_track_device: null context");
+    }
+    if (n < 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track_device: negative feature count");
+    }
+    if (n == 0) {
+        return FTK_OK;
+    }
+    if (!d_ref_uv || !d_cur_uv_in || !d_cur_uv_out || !d_status_in || !d_status_out) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track_device: null buffer");
+    }
+    ftk::KltParams p;
+    const int rc = fill_klt_params(ctx, model, opt, ref, cur, n, prior, consider_luminance, single_level, &p);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    p.ref_uv = d_ref_uv;
+    p.cur_uv_in = d_cur_uv_in;
+    p.cur_uv_out = d_cur_uv_out;
+    p.status_in = d_status_in;
+    p.status_out = d_status_out;
+    p.iters = d_iters;
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    FTK_HIP(ctx, ftk::klt_launch(model, opt->method, p, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *ref_uv,
+                  float *cur_uv, uint8_t *status, int32_t n, const float *prior, int consider_luminance, int single_level, uint32_t *iters) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "klt_track: null context");
+    }
+    if (n < 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track: negative feature count");
+    }
+    if (n == 0) {
+        return FTK_OK;
+    }
+    if (!ref_uv || !cur_uv || !status) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    // scratch layout: ref_uv | cur_uv | iters | status
+    const size_t uv_bytes = align_up(sizeof(float) * 2 * (size_t)n, 256);
+    const size_t it_bytes = align_up(sizeof(uint32_t) * (size_t)n, 256);
+    const size_t st_bytes = align_up((size_t)n, 256);
+    int rc = ensure_scratch(ctx, 2 * uv_bytes + it_bytes + st_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_ref = reinterpret_cast<float *>(base);
+    float *d_cur = reinterpret_cast<float *>(base + uv_bytes);
+    uint32_t *d_it = reinterpret_cast<uint32_t *>(base + 2 * uv_bytes);
+    uint8_t *d_st = base + 2 * uv_bytes + it_bytes;
+    FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_st, status, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = ftk_klt_track_device(ctx, model, opt, ref, cur, d_ref, d_cur, d_cur, d_st, d_st, n, prior, consider_luminance, single_level,
+                              iters ? d_it : nullptr);
+    if (rc != FTK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(cur_uv, d_cur, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (iters) {
+        FTK_HIP(ctx, hipMemcpyAsync(iters, d_it, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t level, float u, float v, int32_t ex_rows, int32_t ex_cols,
+                             float *ex_patch, uint8_t *valid, uint32_t *valid_count) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "extract_extend_patch: null context");
+    }
+    if (!ref || level < 0 || level >= ref->n_levels || ex_rows <= 0 || ex_cols <= 0 || !ex_patch || !valid || !valid_count) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "extract_extend_patch: bad arguments");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ex_rows * ex_cols;
+    const size_t patch_bytes = align_up(sizeof(float) * n, 256);
+    const size_t valid_bytes = align_up(n, 256);
+    int rc = ensure_scratch(ctx, patch_bytes + valid_bytes + 256);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_patch = reinterpret_cast<float *>(base);
+    uint8_t *d_valid = base + patch_bytes;
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(base + patch_bytes + valid_bytes);
+    FTK_HIP(ctx, ftk::extract_patch_launch(ref->levels[level], u, v, ex_rows, ex_cols, d_patch, d_valid, d_count, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(ex_patch, d_patch, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(valid_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- matcher ------------------------------------------------------------------------------- */
+
+static bool supported_words(int32_t n_words) { return n_words == 1 || n_words == 2 || n_words == 4 || n_words == 8 || n_words == 16; }
+
+int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int32_t n_ref, const uint32_t *d_cur_words, int32_t n_cur,
+                             int32_t n_words, int32_t n_bits, float max_distance, const float *d_pred_uv, const float *d_cur_uv,
+                             int32_t max_col_distance, int32_t max_row_distance, int32_t *d_index_pairs, uint64_t *d_workspace) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "hamming_match_device: null context");
+    }
+    if (n_ref < 0 || n_cur < 0 || n_bits < 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: negative size");
+    }
+    if (n_ref == 0 || n_cur == 0) {
+        return FTK_OK;
+    }
+    if (!supported_words(n_words)) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "hamming_match_device: n_words must be 1, 2, 4, 8 or 16 (got %d); zero-pad the descriptors", n_words);
+    }
+    if (n_bits > 32 * n_words) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: n_bits %d exceeds %d words", n_bits, n_words);
+    }
+    if (!d_ref_words || !d_cur_words || !d_index_pairs || (d_pred_uv && !d_cur_uv)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(d_workspace);
+    if (!keys) {
+        const int rc = ensure_match_keys(ctx, (size_t)n_ref);
+        if (rc != FTK_OK) {
+            return rc;
+        }
+        keys = ctx->match_keys;
+    }
+    ftk::MatchParams p;
+    p.ref_words = d_ref_words;
+    p.cur_words = d_cur_words;
+    p.pred_uv = d_pred_uv;
+    p.cur_uv = d_cur_uv;
+    p.index_pairs = d_index_pairs;
+    p.keys = keys;
+    p.n_ref = n_ref;
+    p.n_cur = n_cur;
+    p.n_words = n_words;
+    p.n_bits = n_bits;
+    p.max_distance = max_distance;
+    p.max_col = (float)max_col_distance;
+    p.max_row = (float)max_row_distance;
+    // split the candidate range so that the grid has >= ~2048 workgroups' worth of waves
+    const int row_blocks = (n_ref + 255) / 256;
+    int splits = (2048 + row_blocks - 1) / row_blocks;
+    const int max_splits = (n_cur + 255) / 256;
+    if (splits > max_splits) {
+        splits = max_splits;
+    }
+    if (splits < 1) {
+        splits = 1;
+    }
+    int per = (n_cur + splits - 1) / splits;
+    per = (per + 255) / 256 * 256;
+    p.cur_per_block = per;
+    FTK_HIP(ctx, ftk::match_launch(p, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref, const uint32_t *cur_words, int32_t n_cur, int32_t n_words,
+                      int32_t n_bits, float max_distance, const float *pred_uv, const float *cur_uv, int32_t max_col_distance,
+                      int32_t max_row_distance, int32_t *index_pairs, int *matched_ok) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "hamming_match: null context");
+    }
+    if (matched_ok) {
+        *matched_ok = 0;
+    }
+    if (n_ref < 0 || n_cur < 0 || n_words < 1 || n_words > 16 || n_bits < 0 || n_bits > 32 * n_words) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match: bad sizes (n_ref %d, n_cur %d, n_words %d, n_bits %d)", n_ref, n_cur, n_words, n_bits);
+    }
+    if (n_cur == 0) {
+        return FTK_OK;  // descriptor_matcher.h:58 — `return false`
+    }
+    if (matched_ok) {
+        *matched_ok = 1;
+    }
+    if (n_ref == 0) {
+        return FTK_OK;
+    }
+    if (!ref_words || !cur_words || !index_pairs || (pred_uv && !cur_uv)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    int dev_words = 1;
+    while (dev_words < n_words) {
+        dev_words *= 2;
+    }
+    const size_t ref_bytes = align_up(sizeof(uint32_t) * (size_t)n_ref * dev_words, 256);
+    const size_t cur_bytes = align_up(sizeof(uint32_t) * (size_t)n_cur * dev_words, 256);
+    const size_t pred_bytes = pred_uv ? align_up(sizeof(float) * 2 * (size_t)n_ref, 256) : 0;
+    const size_t cuv_bytes = pred_uv ? align_up(sizeof(float) * 2 * (size_t)n_cur, 256) : 0;
+    const size_t idx_bytes = align_up(sizeof(int32_t) * (size_t)n_ref, 256);
+    int rc = ensure_scratch(ctx, ref_bytes + cur_bytes + pred_bytes + cuv_bytes + idx_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    uint32_t *d_ref = reinterpret_cast<uint32_t *>(base);
+    uint32_t *d_cur = reinterpret_cast<uint32_t *>(base + ref_bytes);
+    float *d_pred = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes) : nullptr;
+    float *d_cuv = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes + pred_bytes) : nullptr;
+    int32_t *d_idx = reinterpret_cast<int32_t *>(base + ref_bytes + cur_bytes + pred_bytes + cuv_bytes);
+    if (dev_words == n_words) {
+        FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_words, sizeof(uint32_t) * (size_t)n_ref * n_words, hipMemcpyHostToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_words, sizeof(uint32_t) * (size_t)n_cur * n_words, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        // zero-pad each descriptor to the next supported width (pad bits are equal in both sets -> distance unchanged)
+        FTK_HIP(ctx, hipMemsetAsync(d_ref, 0, ref_bytes + cur_bytes, ctx->stream));
+        FTK_HIP(ctx, hipMemcpy2DAsync(d_ref, sizeof(uint32_t) * dev_words, ref_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
+                                      (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpy2DAsync(d_cur, sizeof(uint32_t) * dev_words, cur_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
+                                      (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (pred_uv) {
+        FTK_HIP(ctx, hipMemcpyAsync(d_pred, pred_uv, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpyAsync(d_cuv, cur_uv, sizeof(float) * 2 * (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(d_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    rc = ftk_hamming_match_device(ctx, d_ref, n_ref, d_cur, n_cur, dev_words, n_bits, max_distance, d_pred, d_cuv, max_col_distance,
+                                  max_row_distance, d_idx, nullptr);
+    if (rc != FTK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(index_pairs, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const float *cur_uv, int32_t n_cur, float *matched_uv, uint8_t *status) {
+    if (n_ref < 0 || n_cur < 0 || (n_ref > 0 && (!index_pairs || !matched_uv || !status)) || (n_cur > 0 && !cur_uv)) {
+        return FTK_E_INVALID_ARGUMENT;
+    }
+    for (int32_t i = 0; i < n_ref; ++i) {
+        if (status[i] > FTK_TRACKED) {
+            continue;
+        }
+        const int32_t j = index_pairs[i];
+        if (j >= 0 && j < n_cur) {
+            matched_uv[2 * i] = cur_uv[2 * j];
+            matched_uv[2 * i + 1] = cur_uv[2 * j + 1];
+            status[i] = FTK_TRACKED;
+        } else {
+            status[i] = FTK_LARGE_RESIDUAL;
+        }
+    }
+    return FTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// ftk_device.h — structures shared between the host-side C ABI (ftk_api.cpp) and the gfx950
+// kernels (klt_kernels.hip, matcher_kernels.hip, pyramid_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ftk.h"
+
+namespace ftk {
+
+struct DevImage {
+    const uint8_t *data;
+    int32_t rows;
+    int32_t cols;
+};
+
+// Kernel argument block of one KLT launch (passed by value: ~450 B of SGPR-loadable constants).
+struct KltParams {
+    DevImage ref[FTK_MAX_LEVELS];
+    DevImage cur[FTK_MAX_LEVELS];
+    int32_t n_levels;      // levels actually walked (1 in single-level mode)
+    int32_t single_level;  // TrackSingleLevel semantics
+    const float *ref_uv;
+    const float *cur_uv_in;
+    float *cur_uv_out;
+    const uint8_t *status_in;
+    uint8_t *status_out;
+    uint32_t *iters;       // may be null
+    int32_t n;             // features in the buffers
+    uint32_t n_track;      // min(n, kMaxTrackPointsNumber)
+    uint32_t max_iteration;
+    uint32_t max_large_step;
+    int32_t half_rows, half_cols;
+    float converge;
+    float prior[4];
+    int32_t consider_luminance;
+    // derived patch geometry
+    int32_t patch_rows, patch_cols, P, Ppad;  // Ppad = P rounded up to a multiple of 4
+    int32_t ex_rows, ex_cols, E;
+    uint32_t magic_pc;   // ceil(2^32 / patch_cols): row = umulhi(p, magic_pc)
+    uint32_t magic_exc;  // ceil(2^32 / ex_cols)
+};
+
+// LDS bytes a (model, method) variant needs for the given geometry; 0 if the variant is unknown.
+size_t klt_lds_bytes(int model, int method, const KltParams &p);
+// Launches the tracker kernel for (model, method) on `stream`; one 64-lane workgroup per feature.
+hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
+
+struct MatchParams {
+    const uint32_t *ref_words;
+    const uint32_t *cur_words;
+    const float *pred_uv;  // null => ForceMatch
+    const float *cur_uv;
+    int32_t *index_pairs;
+    unsigned long long *keys;  // workspace: n_ref packed (distance << 32 | index)
+    int32_t n_ref, n_cur, n_words, n_bits;
+    float max_distance;
+    float max_col, max_row;
+    int32_t cur_per_block;  // candidates scanned by one workgroup
+};
+hipError_t match_launch(const MatchParams &p, hipStream_t stream);
+
+hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream);
+hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
+                                uint32_t *d_count, hipStream_t stream);
+
+}  // namespace ftk

@@ -1,0 +1,89 @@
+"""Device-resident entry points for callers that already hold their data in HBM (torch tensors).
+
+PyTorch is plumbing here: it owns the device memory and the HIP stream; the computation is the
+``ftk_*_device`` part of the C ABI (hand-written HIP kernels).  Used by bench.py, the smoke test
+and the multi-GPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .tracker import Context, ImagePyramid, OpticalFlowOptions
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("feature_tracker_amd.device needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch
+
+
+def context_on_stream(stream, device_index: Optional[int] = None) -> Context:
+    """A context that launches on the given ``torch.cuda.Stream`` (not the legacy null stream), so
+    torch events, collectives and allocations made under ``with torch.cuda.stream(stream)`` order
+    correctly with the kernels."""
+    torch = _torch()
+    if device_index is None:
+        device_index = stream.device.index if stream.device.index is not None else torch.cuda.current_device()
+    handle = stream.cuda_stream
+    if not handle:
+        raise ValueError("pass a non-default torch.cuda.Stream (the null stream has no handle to borrow)")
+    return Context(device_index, handle)
+
+
+def pyramid_from_tensors(levels: Sequence, ctx: Context) -> ImagePyramid:
+    """levels: uint8 CUDA tensors [rows, cols], contiguous.  Borrowed, not copied."""
+    desc = []
+    for t in levels:
+        if t.dtype.__str__() != "torch.uint8" or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError("pyramid levels must be contiguous 2-D uint8 CUDA tensors")
+        desc.append((t.data_ptr(), t.shape[0], t.shape[1]))
+    return ImagePyramid.from_device_levels(desc, ctx, keepalive=list(levels))
+
+
+def upload_pyramid(host_levels: Sequence[np.ndarray], ctx: Context, device) -> ImagePyramid:
+    torch = _torch()
+    tensors = [torch.from_numpy(np.ascontiguousarray(l)).to(device) for l in host_levels]
+    return pyramid_from_tensors(tensors, ctx)
+
+
+class DeviceKlt:
+    """Runs one tracker variant on device-resident feature buffers.
+
+    ``track(ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None)`` enqueues ONE kernel on
+    the context's stream and returns immediately; the out tensors may alias the in tensors.
+    """
+
+    def __init__(self, model: str, options: OpticalFlowOptions, ref_pyr: ImagePyramid, cur_pyr: ImagePyramid, ctx: Context,
+                 prior: Optional[np.ndarray] = None, consider_luminance: bool = False, single_level: bool = False):
+        self.model = N.MODELS[model]
+        self.opt = options.to_native()
+        self.ref_pyr, self.cur_pyr, self.ctx = ref_pyr, cur_pyr, ctx
+        self.prior = None if prior is None else np.ascontiguousarray(prior, dtype=np.float32).reshape(4)
+        self.lum = int(bool(consider_luminance))
+        self.single = int(bool(single_level))
+
+    def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None):
+        n = ref_uv.shape[0]
+        rc = N.lib().ftk_klt_track_device(
+            self.ctx.handle, self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, C.c_void_p(ref_uv.data_ptr()),
+            C.c_void_p(cur_uv_in.data_ptr()), C.c_void_p(cur_uv_out.data_ptr()), C.c_void_p(status_in.data_ptr()),
+            C.c_void_p(status_out.data_ptr()), n, None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single,
+            None if iters is None else C.c_void_p(iters.data_ptr()))
+        N.check(rc, self.ctx.handle)
+
+
+def hamming_match_device(ctx: Context, ref_words, cur_words, n_bits: int, max_distance: float, index_pairs, pred_uv=None, cur_uv=None,
+                         max_col: int = 40, max_row: int = 40, workspace=None):
+    """ForceMatch (pred_uv None) / NearbyMatch on packed descriptors held in CUDA tensors ([n, words] int32/uint32)."""
+    rc = N.lib().ftk_hamming_match_device(
+        ctx.handle, C.c_void_p(ref_words.data_ptr()), ref_words.shape[0], C.c_void_p(cur_words.data_ptr()), cur_words.shape[0],
+        ref_words.shape[1], int(n_bits), float(max_distance), None if pred_uv is None else C.c_void_p(pred_uv.data_ptr()),
+        None if cur_uv is None else C.c_void_p(cur_uv.data_ptr()), int(max_col), int(max_row), C.c_void_p(index_pairs.data_ptr()),
+        None if workspace is None else C.c_void_p(workspace.data_ptr()))
+    N.check(rc, ctx.handle)

@@ -1,0 +1,73 @@
+"""Feature sharding across the GPUs of one node.
+
+Features are independent units (basic_klt.cpp:13-54 keeps no cross-feature state), so the path
+shards by block-partitioning the feature list over ranks, replicating both pyramids, and joining
+the per-rank results with ONE all-gather of the packed result shard ([u, v] float32 pairs followed
+by status bytes).  ``torch.distributed`` carries the collective: backend "nccl" (= RCCL over xGMI)
+on GPUs, "gloo" in the CPU tests.  No other exchange step exists on this path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(n: int, world_size: int, rank: int):
+    """Contiguous block partition; the first (n % world_size) ranks get one extra feature."""
+    base, extra = divmod(n, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_capacity(n: int, world_size: int) -> int:
+    """Per-rank slot count of the gathered buffer (ranks with fewer features pad)."""
+    return (n + world_size - 1) // world_size
+
+
+def packed_bytes(capacity: int) -> int:
+    """Bytes of one rank's packed result shard: capacity * (8 B uv + 1 B status), rounded up to 16 B
+    so that every rank's slice of the gathered buffer keeps the uv pairs 4-byte aligned."""
+    return (capacity * 9 + 15) // 16 * 16
+
+
+def pack_views(buffer, capacity: int):
+    """Split one rank's packed byte buffer (torch uint8 tensor, packed_bytes(capacity) bytes) into
+    (uv float32 [capacity, 2], status uint8 [capacity]) views that alias it."""
+    import torch
+
+    uv = buffer[: capacity * 8].view(torch.float32).view(capacity, 2)
+    status = buffer[capacity * 8: capacity * 9]
+    return uv, status
+
+
+def unpack_gathered(gathered, n: int, world_size: int):
+    """gathered: uint8 tensor [world_size * capacity * 9] -> (uv [n, 2], status [n]) in global feature order."""
+    import torch
+
+    cap = shard_capacity(n, world_size)
+    per = packed_bytes(cap)
+    uvs, sts = [], []
+    for r in range(world_size):
+        b, e = shard_bounds(n, world_size, r)
+        chunk = gathered[r * per:(r + 1) * per]
+        uv, st = pack_views(chunk, cap)
+        uvs.append(uv[: e - b])
+        sts.append(st[: e - b])
+    return torch.cat(uvs, dim=0), torch.cat(sts, dim=0)
+
+
+def all_gather_results(local_packed, world_size: int, group=None):
+    """One collective per call: every rank contributes its packed shard and receives all of them."""
+    import torch
+    import torch.distributed as dist
+
+    out = torch.empty(local_packed.numel() * world_size, dtype=torch.uint8, device=local_packed.device)
+    if world_size == 1:
+        out.copy_(local_packed)
+        return out
+    dist.all_gather_into_tensor(out, local_packed, group=group)
+    return out
+
+
+def split_numpy(arr: np.ndarray, world_size: int, rank: int) -> np.ndarray:
+    b, e = shard_bounds(arr.shape[0], world_size, rank)
+    return arr[b:e]

@@ -1,0 +1,374 @@
+"""Host-side mirror of the reference's tracker / matcher interface on top of the C ABI.
+
+Class and method names follow the reference (namespace feature_tracker):
+``OpticalFlowBasicKlt`` / ``OpticalFlowAffineKlt`` / ``OpticalFlowLssdKlt`` with ``options()``,
+``TrackFeatures`` (pyramid and single-image overloads, optical_flow.h:38-42), ``predict_affine``,
+``predict_R_cr``, ``consider_patch_luminance``; ``BriefMatcher`` = ``DescriptorMatcher<BriefType>``
+with ``ForceMatch`` / ``NearbyMatch`` (descriptor_matcher.h:26-37).  Python cannot mutate its
+arguments the way the C++ reference does, so the in/out vectors are returned instead:
+``ok, cur_uv, status = klt.TrackFeatures(ref_pyr, cur_pyr, ref_uv, cur_uv, status)``.
+
+All compute goes through libftk_hip.so; nothing here falls back to numpy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+NOT_TRACKED, TRACKED, LARGE_RESIDUAL, OUTSIDE, NUMERIC_ERROR = range(5)  # feature_tracker.h:8-14
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream (ftk_context).  ``stream`` may be a raw hipStream_t handle, e.g.
+    ``torch.cuda.Stream().cuda_stream``; by default the context owns a private stream."""
+
+    def __init__(self, device: int = -1, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        rc = N.lib().ftk_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
+        N.check(rc, None)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        N.check(N.lib().ftk_synchronize(self._h), self._h)
+
+    def close(self):
+        if self._h:
+            N.lib().ftk_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def _image_array(levels: Sequence[np.ndarray]):
+    arr = (N.Image * len(levels))()
+    keep = []
+    for i, img in enumerate(levels):
+        a = np.ascontiguousarray(img, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("images must be 2-D uint8 arrays")
+        keep.append(a)
+        arr[i].data = a.ctypes.data
+        arr[i].rows, arr[i].cols = a.shape
+    return arr, keep
+
+
+class ImagePyramid:
+    """Device-resident image pyramid (level 0 = full resolution)."""
+
+    def __init__(self, handle, ctx: Context, keepalive=None):
+        self._h = handle
+        self._ctx = ctx
+        self._keep = keepalive
+
+    @classmethod
+    def from_host_levels(cls, levels: Sequence[np.ndarray], ctx: Optional[Context] = None) -> "ImagePyramid":
+        """Upload an already built pyramid (what ImagePyramid::GetImageConst(i) returns per level)."""
+        ctx = ctx or default_context()
+        arr, keep = _image_array(levels)
+        h = C.c_void_p()
+        N.check(N.lib().ftk_pyramid_upload(ctx.handle, arr, len(levels), C.byref(h)), ctx.handle)
+        return cls(h, ctx)
+
+    @classmethod
+    def from_device_levels(cls, ptrs_rows_cols: Sequence[tuple], ctx: Optional[Context] = None, keepalive=None) -> "ImagePyramid":
+        """Borrow levels already in device memory: sequence of (device_ptr, rows, cols)."""
+        ctx = ctx or default_context()
+        arr = (N.Image * len(ptrs_rows_cols))()
+        for i, (ptr, rows, cols) in enumerate(ptrs_rows_cols):
+            arr[i].data, arr[i].rows, arr[i].cols = int(ptr), int(rows), int(cols)
+        h = C.c_void_p()
+        N.check(N.lib().ftk_pyramid_wrap_device(ctx.handle, arr, len(ptrs_rows_cols), C.byref(h)), ctx.handle)
+        return cls(h, ctx, keepalive)
+
+    @classmethod
+    def build(cls, image: np.ndarray, levels: int, ctx: Optional[Context] = None) -> "ImagePyramid":
+        """SetRawImage + CreateImagePyramid(levels) on the device (test_optical_flow.cpp:49-53,70-71)."""
+        ctx = ctx or default_context()
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        h = C.c_void_p()
+        N.check(N.lib().ftk_pyramid_build(ctx.handle, _ptr(a), a.shape[0], a.shape[1], int(levels), 0, C.byref(h)), ctx.handle)
+        return cls(h, ctx)
+
+    @classmethod
+    def build_from_device(cls, device_ptr: int, rows: int, cols: int, levels: int, ctx: Optional[Context] = None, keepalive=None):
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        N.check(N.lib().ftk_pyramid_build(ctx.handle, C.c_void_p(int(device_ptr)), rows, cols, int(levels), 1, C.byref(h)), ctx.handle)
+        return cls(h, ctx, keepalive)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def level(self) -> int:
+        return N.lib().ftk_pyramid_levels(self._h)
+
+    def level_desc(self, i: int):
+        im = N.Image()
+        rc = N.lib().ftk_pyramid_level(self._h, i, C.byref(im))
+        if rc != 0:
+            raise IndexError(i)
+        return im.data, im.rows, im.cols
+
+    def download_level(self, i: int) -> np.ndarray:
+        _, rows, cols = self.level_desc(i)
+        out = np.empty((rows, cols), dtype=np.uint8)
+        N.check(N.lib().ftk_pyramid_download_level(self._ctx.handle, self._h, i, _ptr(out)), self._ctx.handle)
+        return out
+
+    def close(self):
+        if self._h:
+            N.lib().ftk_pyramid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OpticalFlowOptions:
+    """optical_flow.h:20-28 — same field names and defaults."""
+
+    def __init__(self):
+        self.kMaxTrackPointsNumber = 500
+        self.kMaxIteration = 15
+        self.kMaxToleranceLargeStep = 3
+        self.kPatchRowHalfSize = 6
+        self.kPatchColHalfSize = 6
+        self.kMaxConvergeStep = 4e-2
+        self.kMethod = "fast"  # OpticalFlowMethod::kFast
+
+    def to_native(self) -> N.KltOptions:
+        o = N.KltOptions()
+        o.max_track_points = int(self.kMaxTrackPointsNumber)
+        o.max_iteration = int(self.kMaxIteration)
+        o.max_tolerance_large_step = int(self.kMaxToleranceLargeStep)
+        o.half_rows = int(self.kPatchRowHalfSize)
+        o.half_cols = int(self.kPatchColHalfSize)
+        o.max_converge_step = float(self.kMaxConvergeStep)
+        o.method = N.METHODS[self.kMethod] if isinstance(self.kMethod, str) else int(self.kMethod)
+        return o
+
+
+class OpticalFlow:
+    """Abstract base (optical_flow.h:30-112): input normalisation + dispatch to the device tracker."""
+
+    _model = None
+    _name = "None"
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+        self._options = OpticalFlowOptions()
+        self.last_iterations: Optional[np.ndarray] = None  # it(f) of the last call (bytes-moved accounting)
+
+    def OpticalFlowMethodName(self) -> str:
+        return self._name
+
+    def options(self) -> OpticalFlowOptions:
+        return self._options
+
+    # hooks for the subclasses' prediction members
+    def _prior(self) -> Optional[np.ndarray]:
+        return None
+
+    def _luminance(self) -> bool:
+        return False
+
+    def TrackFeatures(self, ref, cur, ref_pixel_uv, cur_pixel_uv=None, status=None):
+        """Pyramid overload when ``ref``/``cur`` are ImagePyramid, single-image overload when they are
+        2-D uint8 arrays (optical_flow.cpp:6-26 / :28-47).  Returns (ok, cur_pixel_uv, status)."""
+        ref_uv = np.ascontiguousarray(ref_pixel_uv, dtype=np.float32).reshape(-1, 2)
+        n = ref_uv.shape[0]
+        cur_uv = None if cur_pixel_uv is None else np.asarray(cur_pixel_uv, dtype=np.float32).reshape(-1, 2)
+        st = None if status is None else np.asarray(status, dtype=np.uint8).reshape(-1)
+        single = not isinstance(ref, ImagePyramid)
+        # RETURN_FALSE_IF(ref_pixel_uv.empty()) / level mismatch — before any normalisation (optical_flow.cpp:8-9)
+        if n == 0 or (not single and cur.level() != ref.level()):
+            return False, (np.zeros((0, 2), np.float32) if cur_uv is None else cur_uv), (np.zeros(0, np.uint8) if st is None else st)
+        # size mismatch => "no prediction" / "not tracked yet" (optical_flow.cpp:12-19)
+        cur_uv = ref_uv.copy() if (cur_uv is None or cur_uv.shape[0] != n) else np.ascontiguousarray(cur_uv).copy()
+        st = np.zeros(n, dtype=np.uint8) if (st is None or st.shape[0] != n) else np.ascontiguousarray(st).copy()
+
+        ctx = self._ctx or default_context()
+        if single:
+            ref_pyr = ImagePyramid.from_host_levels([ref], ctx)
+            cur_pyr = ImagePyramid.from_host_levels([cur], ctx)
+        else:
+            ref_pyr, cur_pyr = ref, cur
+        opt = self._options.to_native()
+        prior = self._prior()
+        prior_arr = None if prior is None else np.ascontiguousarray(prior, dtype=np.float32).reshape(4)
+        iters = np.zeros(n, dtype=np.uint32)
+        rc = N.lib().ftk_klt_track(ctx.handle, self._model, C.byref(opt), ref_pyr.handle, cur_pyr.handle, _ptr(ref_uv), _ptr(cur_uv), _ptr(st), n,
+                                   _ptr(prior_arr), int(self._luminance()), int(single), _ptr(iters))
+        N.check(rc, ctx.handle)
+        self.last_iterations = iters
+        return True, cur_uv, st
+
+    def ExtractExtendPatchInReferenceImage(self, ref_image, ref_pixel_uv, ex_ref_patch_rows: int, ex_ref_patch_cols: int):
+        """optical_flow.cpp:49-102.  Returns (valid_count, ex_patch (rows x cols float32), valid (rows x cols bool))."""
+        ctx = self._ctx or default_context()
+        pyr = ref_image if isinstance(ref_image, ImagePyramid) else ImagePyramid.from_host_levels([ref_image], ctx)
+        patch = np.zeros(ex_ref_patch_rows * ex_ref_patch_cols, dtype=np.float32)
+        valid = np.zeros(ex_ref_patch_rows * ex_ref_patch_cols, dtype=np.uint8)
+        cnt = C.c_uint32(0)
+        N.check(N.lib().ftk_extract_extend_patch(ctx.handle, pyr.handle, 0, float(ref_pixel_uv[0]), float(ref_pixel_uv[1]), ex_ref_patch_rows,
+                                                 ex_ref_patch_cols, _ptr(patch), _ptr(valid), C.byref(cnt)), ctx.handle)
+        return cnt.value, patch.reshape(ex_ref_patch_rows, ex_ref_patch_cols), valid.reshape(ex_ref_patch_rows, ex_ref_patch_cols).astype(bool)
+
+
+class OpticalFlowBasicKlt(OpticalFlow):
+    _model = N.MODELS["basic"]
+    _name = "Basic-Klt"  # basic_klt.h:15
+
+
+class OpticalFlowAffineKlt(OpticalFlow):
+    _model = N.MODELS["affine"]
+    _name = "Affine-Klt"  # affine_klt.h:15
+
+    def __init__(self, ctx: Optional[Context] = None):
+        super().__init__(ctx)
+        self.predict_affine = np.eye(2, dtype=np.float32)  # affine_klt.h:50
+
+    def _prior(self):
+        return self.predict_affine
+
+
+class OpticalFlowLssdKlt(OpticalFlow):
+    _model = N.MODELS["lssd"]
+    _name = "Lssd-Klt"  # lssd_klt.h:15
+
+    def __init__(self, ctx: Optional[Context] = None):
+        super().__init__(ctx)
+        self.predict_R_cr = np.eye(2, dtype=np.float32)  # lssd_klt.h:53
+        self.consider_patch_luminance = False  # lssd_klt.h:54
+
+    def _prior(self):
+        return self.predict_R_cr
+
+    def _luminance(self):
+        return bool(self.consider_patch_luminance)
+
+
+def pack_brief(bits: np.ndarray) -> np.ndarray:
+    """Per-bit BriefType container (n, n_bits) of 0/1 -> (n, ceil(n_bits / 32)) uint32 words."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    if bits.ndim != 2:
+        bits = bits.reshape(bits.shape[0], -1) if bits.size else bits.reshape(0, 0)
+    n, n_bits = bits.shape
+    words = max(1, (n_bits + 31) // 32)
+    padded = np.zeros((n, words * 32), dtype=np.uint8)
+    padded[:, :n_bits] = bits != 0
+    packed = np.packbits(padded.reshape(n, words, 32), axis=-1, bitorder="little")
+    return np.ascontiguousarray(packed).view("<u4").reshape(n, words)
+
+
+class DescriptorMatcherOptions:
+    """descriptor_matcher.h:16-20."""
+
+    def __init__(self):
+        self.kMaxValidPredictRowDistance = 40
+        self.kMaxValidPredictColDistance = 40
+        self.kMaxValidDescriptorDistance = 0.0
+
+
+class BriefMatcher:
+    """DescriptorMatcher<BriefType> with the Hamming ComputeDistance of
+    test/test_descriptor_matcher_brief.cpp:27-46.  Descriptors are per-bit arrays (n, n_bits)."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+        self._options = DescriptorMatcherOptions()
+
+    def options(self) -> DescriptorMatcherOptions:
+        return self._options
+
+    def _match(self, descriptors_ref, descriptors_cur, pred_uv, cur_uv, index_pairs):
+        ref_bits = np.asarray(descriptors_ref, dtype=np.uint8)
+        cur_bits = np.asarray(descriptors_cur, dtype=np.uint8)
+        n_ref, n_cur = ref_bits.shape[0], cur_bits.shape[0]
+        n_bits = ref_bits.shape[1] if ref_bits.ndim == 2 else 0
+        if n_cur == 0:
+            return False, index_pairs  # descriptor_matcher.h:58
+        # index_pairs reset only on size mismatch (descriptor_matcher.h:60-62)
+        if index_pairs is None or np.asarray(index_pairs).size != n_ref:
+            idx = np.full(n_ref, -1, dtype=np.int32)
+        else:
+            idx = np.array(index_pairs, dtype=np.int32).copy()
+        ctx = self._ctx or default_context()
+        ref_words = pack_brief(ref_bits.reshape(n_ref, n_bits))
+        cur_words = pack_brief(cur_bits.reshape(n_cur, n_bits))
+        ok = C.c_int(0)
+        o = self._options
+        rc = N.lib().ftk_hamming_match(ctx.handle, _ptr(ref_words), n_ref, _ptr(cur_words), n_cur, ref_words.shape[1], n_bits,
+                                       float(o.kMaxValidDescriptorDistance), _ptr(pred_uv), _ptr(cur_uv), int(o.kMaxValidPredictColDistance),
+                                       int(o.kMaxValidPredictRowDistance), _ptr(idx), C.byref(ok))
+        N.check(rc, ctx.handle)
+        return bool(ok.value), idx
+
+    def ForceMatch(self, descriptors_ref, descriptors_cur, index_pairs_in_cur=None):
+        """descriptor_matcher.h:55-79.  Returns (ok, index_pairs_in_cur)."""
+        return self._match(descriptors_ref, descriptors_cur, None, None, index_pairs_in_cur)
+
+    def NearbyMatch(self, descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, index_pairs_in_cur=None):
+        """descriptor_matcher.h:90-124.  Returns (ok, index_pairs_in_cur)."""
+        pred = np.ascontiguousarray(pixel_uv_pred_in_cur, dtype=np.float32).reshape(-1, 2)
+        cur = np.ascontiguousarray(pixel_uv_cur, dtype=np.float32).reshape(-1, 2)
+        n_ref, n_cur = len(descriptors_ref), len(descriptors_cur)
+        if n_cur == 0 or n_ref != pred.shape[0] or n_cur != cur.shape[0]:
+            return False, index_pairs_in_cur  # descriptor_matcher.h:94-96
+        return self._match(descriptors_ref, descriptors_cur, pred, cur, index_pairs_in_cur)
+
+    def FillMatchedPixelByPairIndices(self, index_pairs_in_cur, pixel_uv_cur, status=None):
+        """descriptor_matcher.h:135-157.  Returns (matched_pixel_uv_cur, status)."""
+        idx = np.ascontiguousarray(index_pairs_in_cur, dtype=np.int32)
+        cur = np.ascontiguousarray(pixel_uv_cur, dtype=np.float32).reshape(-1, 2)
+        n_ref = idx.shape[0]
+        st = np.zeros(n_ref, dtype=np.uint8) if (status is None or np.asarray(status).size != n_ref) else np.array(status, dtype=np.uint8).copy()
+        matched = np.zeros((n_ref, 2), dtype=np.float32)
+        rc = N.lib().ftk_fill_matched_pixels(_ptr(idx), n_ref, _ptr(cur), cur.shape[0], _ptr(matched), _ptr(st))
+        N.check(rc, None)
+        return matched, st
+
+    def ForceMatchPixels(self, descriptors_ref, descriptors_cur, pixel_uv_cur, status=None):
+        """The pixel-returning ForceMatch overload (descriptor_matcher.h:81-88)."""
+        ok, idx = self.ForceMatch(descriptors_ref, descriptors_cur, None)
+        if not ok:
+            return False, None, status
+        matched, st = self.FillMatchedPixelByPairIndices(idx, pixel_uv_cur, status)
+        return True, matched, st
+
+    def NearbyMatchPixels(self, descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, status=None):
+        """The pixel-returning NearbyMatch overload (descriptor_matcher.h:126-133)."""
+        ok, idx = self.NearbyMatch(descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, None)
+        if not ok:
+            return False, None, status
+        matched, st = self.FillMatchedPixelByPairIndices(idx, pixel_uv_cur, status)
+        return True, matched, st

@@ -1,0 +1,181 @@
+/*
+ * ftk.h — C ABI of the MI355X-native sparse feature tracker (libftk_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Horizon1026/Feature_Tracker: the pyramidal
+ * Lucas-Kanade trackers and the BRIEF descriptor matcher.  Every entry point names the
+ * reference interface it replaces (file:line relative to the reference repo).  Signatures use
+ * plain pointers and sizes only; the host-side C++ classes with the reference's names
+ * (feature_tracker_amd/host/) and the Python binding (feature_tracker_amd/) sit on top.
+ *
+ * Conventions
+ *   - (u, v) pairs are contiguous {float u(=x, col), float v(=y, row)} — the memory layout of
+ *     std::vector<Vec2> (optical_flow.h:38-42).
+ *   - status is one uint8_t per feature with the TrackStatus codes (src/feature_tracker.h:8-14).
+ *   - images are 8-bit gray, row-major, pitch == cols (GrayImage).
+ *   - 2x2 matrices (prior) are row-major [m00, m01, m10, m11].
+ *   - every function returns FTK_OK (0) or a negative FTK_E_* code; ftk_last_error() gives text.
+ *     There is NO CPU fallback: without a usable HIP device every compute call fails.
+ *   - a context is bound to one device and one HIP stream; it is not thread-safe (neither is the
+ *     reference: optical_flow.h:91-111 keeps mutable scratch in the tracker object).
+ */
+#ifndef FTK_H_
+#define FTK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTK_ABI_VERSION 1
+#define FTK_MAX_LEVELS 12
+
+enum {
+    FTK_OK = 0,
+    FTK_E_INVALID_ARGUMENT = -1,
+    FTK_E_NO_DEVICE = -2,
+    FTK_E_HIP = -3,
+    FTK_E_UNSUPPORTED = -4,
+    FTK_E_OUT_OF_MEMORY = -5,
+};
+
+/* TrackStatus, src/feature_tracker.h:8-14 */
+enum {
+    FTK_NOT_TRACKED = 0,
+    FTK_TRACKED = 1,
+    FTK_LARGE_RESIDUAL = 2,
+    FTK_OUTSIDE = 3,
+    FTK_NUMERIC_ERROR = 4,
+};
+
+/* OpticalFlowMethod, src/optical_flow_tracker/optical_flow.h:12-18.  kSse / kNeon (3, 4) take
+ * the reference's `default:` branch, i.e. behave as kFast (basic_klt.cpp:31-34). */
+enum { FTK_METHOD_INVERSE = 0, FTK_METHOD_DIRECT = 1, FTK_METHOD_FAST = 2, FTK_METHOD_SSE = 3, FTK_METHOD_NEON = 4 };
+
+/* which tracker class: OpticalFlowBasicKlt / OpticalFlowAffineKlt / OpticalFlowLssdKlt */
+enum { FTK_MODEL_BASIC = 0, FTK_MODEL_AFFINE = 1, FTK_MODEL_LSSD = 2 };
+
+/* GrayImage view (Slam_Utility datatype_image.h; call sites basic_klt.cpp:22-23) */
+typedef struct ftk_image {
+    const uint8_t *data;
+    int32_t rows;
+    int32_t cols;
+} ftk_image;
+
+/* OpticalFlowOptions, src/optical_flow_tracker/optical_flow.h:20-28 (same defaults) */
+typedef struct ftk_klt_options {
+    uint32_t max_track_points;         /* kMaxTrackPointsNumber   = 500  */
+    uint32_t max_iteration;            /* kMaxIteration           = 15   */
+    uint32_t max_tolerance_large_step; /* kMaxToleranceLargeStep  = 3    */
+    int32_t half_rows;                 /* kPatchRowHalfSize       = 6    */
+    int32_t half_cols;                 /* kPatchColHalfSize       = 6    */
+    float max_converge_step;           /* kMaxConvergeStep        = 4e-2 */
+    int32_t method;                    /* kMethod                 = kFast */
+} ftk_klt_options;
+
+typedef struct ftk_context ftk_context;
+typedef struct ftk_pyramid ftk_pyramid;
+
+/* ---- runtime ----------------------------------------------------------------------------- */
+
+int ftk_abi_version(void);
+/* Number of visible HIP devices (0 when none / no driver). Does not create a HIP context. */
+int ftk_device_count(void);
+/* stream: a hipStream_t to launch on (borrowed, e.g. a torch stream), or NULL to let the context
+ * create and own one.  device < 0 keeps the calling thread's current device. */
+int ftk_context_create(int device, void *stream, ftk_context **out);
+void ftk_context_destroy(ftk_context *ctx);
+/* Text of the last failure on this context (or of the last failed ftk_context_create when ctx is NULL). */
+const char *ftk_last_error(const ftk_context *ctx);
+int ftk_synchronize(ftk_context *ctx);
+void ftk_default_klt_options(ftk_klt_options *opt);
+
+/* ---- image pyramids resident in HBM ------------------------------------------------------ */
+
+/* Copies the levels of a host ImagePyramid (ImagePyramid::GetImageConst(i), basic_klt.cpp:22-23)
+ * into ONE device allocation, level after level, each level 256-byte aligned. */
+int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n_levels, ftk_pyramid **out);
+/* Borrows levels that already live in device memory (e.g. torch tensors); nothing is copied. */
+int ftk_pyramid_wrap_device(ftk_context *ctx, const ftk_image *device_levels, int32_t n_levels, ftk_pyramid **out);
+/* Replaces ImagePyramid::CreateImagePyramid (call sites test/test_optical_flow.cpp:70-71):
+ * uploads (or borrows, image_on_device != 0) the raw image as level 0 and builds levels
+ * 1..n_levels-1 on the device with the truncating 2x2 box mean. */
+int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int32_t cols, int32_t n_levels, int image_on_device,
+                      ftk_pyramid **out);
+int ftk_pyramid_levels(const ftk_pyramid *pyr);
+/* Device-side descriptor of one level (data is a device pointer). */
+int ftk_pyramid_level(const ftk_pyramid *pyr, int32_t level, ftk_image *out);
+/* Copies one level back to host memory (rows*cols bytes); for tests and for callers that still
+ * need the pyramid on the host. */
+int ftk_pyramid_download_level(ftk_context *ctx, const ftk_pyramid *pyr, int32_t level, uint8_t *host_out);
+void ftk_pyramid_destroy(ftk_pyramid *pyr);
+
+/* ---- KLT trackers ------------------------------------------------------------------------ */
+
+/*
+ * Replaces OpticalFlow{Basic,Affine,Lssd}Klt::TrackMultipleLevel
+ * (basic_klt.cpp:7-57, affine_klt.cpp:6-59, lssd_klt.cpp:7-61) when single_level == 0 and
+ * ::TrackSingleLevel (basic_klt.cpp:59-86, affine_klt.cpp:61-91, lssd_klt.cpp:63-94) when
+ * single_level != 0 (only level 0 of the pyramids is used).
+ *
+ * Host buffers, synchronous.  cur_uv and status are in/out exactly as in the reference
+ * (prediction in, result out; features whose incoming status > kTracked are skipped;
+ * features beyond max_track_points are left untouched).  prior is predict_affine_
+ * (affine_klt.h:50; used by the single-level path only) or predict_R_cr_ (lssd_klt.h:53);
+ * NULL means identity.  consider_luminance is consider_patch_luminance_ (lssd_klt.h:54).
+ * iters (optional, n entries) receives per feature the number of Gauss-Newton iterations that
+ * sampled the images, summed over levels — the it(f,l) of the bytes-moved model.
+ * The input normalisation of OpticalFlow::TrackFeatures (optical_flow.cpp:6-26: empty input,
+ * level mismatch, vector resizing) lives in the host-side classes above this ABI.
+ */
+int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *ref_uv,
+                  float *cur_uv, uint8_t *status, int32_t n, const float *prior, int consider_luminance, int single_level, uint32_t *iters);
+
+/*
+ * Same computation on device-resident buffers, asynchronous on the context's stream.
+ * d_cur_uv_out / d_status_out may alias the *_in buffers (in-place, as the reference) or be
+ * separate (repeatable launches for benchmarking).  d_iters may be NULL.
+ */
+int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur,
+                         const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out, const uint8_t *d_status_in,
+                         uint8_t *d_status_out, int32_t n, const float *prior, int consider_luminance, int single_level, uint32_t *d_iters);
+
+/* Replaces OpticalFlow::ExtractExtendPatchInReferenceImage (optical_flow.cpp:49-102, a public
+ * helper of the reference API).  Host buffers: ex_patch has ex_rows*ex_cols floats, valid one
+ * byte per pixel; *valid_count receives the return value of the reference function. */
+int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t level, float u, float v, int32_t ex_rows, int32_t ex_cols,
+                             float *ex_patch, uint8_t *valid, uint32_t *valid_count);
+
+/* ---- descriptor matcher ------------------------------------------------------------------ */
+
+/*
+ * Replaces DescriptorMatcher<BriefType>::ForceMatch (descriptor_matcher.h:55-79) and
+ * ::NearbyMatch (:90-124) for the per-bit Hamming distance of
+ * test/test_descriptor_matcher_brief.cpp:33-45.  Descriptors are bit-packed: n_words uint32
+ * per descriptor, bit i of the descriptor in bit (i % 32) of word i / 32, unused high bits 0.
+ * n_bits == 0 reproduces ComputeDistance's "empty descriptor" answer (kMaxInt32).
+ * pred_uv == NULL selects ForceMatch; otherwise NearbyMatch with the window test
+ * |pred.u - cur.u| > max_col_distance || |pred.v - cur.v| > max_row_distance -> skip.
+ * index_pairs is in/out (n_ref entries): written only where a candidate beats the threshold,
+ * exactly like the reference, whose caller-visible reset to -1 happens only on a size mismatch
+ * (descriptor_matcher.h:60-62) and therefore lives in the host-side class.
+ * Returns FTK_OK with *matched_ok = 0 when n_cur == 0 (the reference's `return false`).
+ */
+int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref, const uint32_t *cur_words, int32_t n_cur, int32_t n_words,
+                      int32_t n_bits, float max_distance, const float *pred_uv, const float *cur_uv, int32_t max_col_distance,
+                      int32_t max_row_distance, int32_t *index_pairs, int *matched_ok);
+
+/* Device-resident, asynchronous variant.  d_workspace must hold n_ref uint64 (packed
+ * (distance, index) keys); pass NULL to let the context allocate and cache one. */
+int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int32_t n_ref, const uint32_t *d_cur_words, int32_t n_cur,
+                             int32_t n_words, int32_t n_bits, float max_distance, const float *d_pred_uv, const float *d_cur_uv,
+                             int32_t max_col_distance, int32_t max_row_distance, int32_t *d_index_pairs, uint64_t *d_workspace);
+
+/* Replaces DescriptorMatcher::FillMatchedPixelByPairIndices (descriptor_matcher.h:135-157).
+ * Pure index -> pixel gather on host buffers (O(n_ref), not worth a launch); status is in/out. */
+int ftk_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const float *cur_uv, int32_t n_cur, float *matched_uv, uint8_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTK_H_ */

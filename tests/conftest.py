@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def ftk():
+    """The product package with its native library loaded (fails loudly if it was not built)."""
+    import feature_tracker_amd as F
+    from feature_tracker_amd import _native
+    _native.lib()
+    return F
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(ftk):
+    return ftk.default_context()

@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/ftk.h declares; without a
+device every compute path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "ftk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ftk_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_exports_match_header(ftk):
+    from feature_tracker_amd import _native
+    lib = _native.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    assert sorted(_native.EXPORTS) == names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.ftk_abi_version() == 1
+
+
+def test_default_options(ftk):
+    from feature_tracker_amd import _native
+    o = _native.KltOptions()
+    _native.lib().ftk_default_klt_options(C.byref(o))
+    # optical_flow.h:20-28
+    assert (o.max_track_points, o.max_iteration, o.max_tolerance_large_step, o.half_rows, o.half_cols, o.method) == (500, 15, 3, 6, 6, 2)
+    assert abs(o.max_converge_step - 4e-2) < 1e-9
+    p = ftk.OpticalFlowOptions().to_native()
+    assert (p.max_track_points, p.max_iteration, p.max_tolerance_large_step, p.half_rows, p.half_cols, p.method) == (500, 15, 3, 6, 6, 2)
+
+
+def test_no_device_fails_loudly(ftk):
+    from feature_tracker_amd import _native
+    if _native.lib().ftk_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_native.FtkError) as e:
+        ftk.Context()
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    import numpy as np
+    with pytest.raises(_native.FtkError):
+        ftk.OpticalFlowBasicKlt().TrackFeatures(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8), np.float32([[4, 4]]))
+
+
+def test_host_side_fill_needs_no_device(ftk):
+    import numpy as np
+    m = ftk.BriefMatcher()
+    matched, st = m.FillMatchedPixelByPairIndices([1, -1, 5], np.float32([[1, 2], [3, 4]]), [0, 0, 0])
+    assert st.tolist() == [1, 2, 2] and matched[0].tolist() == [3, 4]
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under feature_tracker_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "feature_tracker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "liboracle" not in text and "ftk_oracle" not in text, os.path.join(dirpath, f)

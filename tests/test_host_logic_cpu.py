@@ -1,0 +1,120 @@
+"""Host-side logic that needs no GPU: input normalisation, bit packing, feature sharding and the
+world_size-2 result exchange over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from feature_tracker_amd import dist as FD
+from feature_tracker_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_early_returns_need_no_device(ftk):
+    klt = ftk.OpticalFlowAffineKlt()
+    ok, c, s = klt.TrackFeatures(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.uint8), np.zeros((0, 2), np.float32))
+    assert ok is False  # optical_flow.cpp:30
+    assert klt.OpticalFlowMethodName() == "Affine-Klt" and ftk.OpticalFlowLssdKlt().OpticalFlowMethodName() == "Lssd-Klt"
+    m = ftk.BriefMatcher()
+    assert m.options().kMaxValidDescriptorDistance == 0.0 and m.options().kMaxValidPredictRowDistance == 40
+    ok, _ = m.ForceMatch(np.zeros((3, 8), np.uint8), np.zeros((0, 8), np.uint8))
+    assert ok is False  # descriptor_matcher.h:58
+    ok, _ = m.NearbyMatch(np.zeros((3, 8), np.uint8), np.zeros((2, 8), np.uint8), np.zeros((2, 2)), np.zeros((2, 2)))
+    assert ok is False  # descriptor_matcher.h:95
+
+
+def test_pack_brief_layout(ftk):
+    rs = np.random.RandomState(1)
+    for n_bits in (1, 31, 32, 33, 200, 256):
+        bits = rs.randint(0, 2, size=(17, n_bits)).astype(np.uint8)
+        words = ftk.pack_brief(bits)
+        assert words.shape == (17, (n_bits + 31) // 32) and words.dtype == np.uint32
+        assert np.array_equal(words, synth.pack_bits(bits))
+        for i in (0, 16):
+            for b in range(n_bits):
+                assert (int(words[i, b // 32]) >> (b % 32)) & 1 == bits[i, b]
+        # Hamming distance survives the packing
+        d_bits = int((bits[0] != bits[1]).sum())
+        d_words = sum(bin(int(a) ^ int(b)).count("1") for a, b in zip(words[0], words[1]))
+        assert d_bits == d_words
+    assert ftk.pack_brief(np.zeros((5, 0), np.uint8)).shape == (5, 1)
+
+
+def test_shard_bounds_partition():
+    for n in (0, 1, 7, 2000, 200000, 200003):
+        for world in (1, 2, 3, 8):
+            spans = [FD.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) <= FD.shard_capacity(n, world) if n else True
+
+
+def test_pack_unpack_roundtrip():
+    import torch
+    n, world = 37, 4
+    cap = FD.shard_capacity(n, world)
+    uv = torch.arange(n * 2, dtype=torch.float32).view(n, 2)
+    st = (torch.arange(n) % 5).to(torch.uint8)
+    chunks = []
+    for r in range(world):
+        b, e = FD.shard_bounds(n, world, r)
+        buf = torch.zeros(FD.packed_bytes(cap), dtype=torch.uint8)
+        puv, pst = FD.pack_views(buf, cap)
+        puv[: e - b] = uv[b:e]
+        pst[: e - b] = st[b:e]
+        chunks.append(buf)
+    guv, gst = FD.unpack_gathered(torch.cat(chunks), n, world)
+    assert torch.equal(guv, uv) and torch.equal(gst, st)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FTK_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from feature_tracker_amd import dist as FD, synth
+from tests import oracle_lib, scenes
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ref_levels, cur_levels = scenes.scene(160, 120, 2)
+n = 101
+uv = scenes.features(n, 160, 120, half=4)
+b, e = FD.shard_bounds(n, world, rank)
+cap = FD.shard_capacity(n, world)
+# stand-in for the device kernel on this rank's shard: the oracle (this is a test of the exchange path)
+ok, c, st, it = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv[b:e], method="fast", half=4, max_points=n)
+buf = torch.zeros(FD.packed_bytes(cap), dtype=torch.uint8)
+puv, pst = FD.pack_views(buf, cap)
+puv[: e - b] = torch.from_numpy(c)
+pst[: e - b] = torch.from_numpy(st)
+gathered = FD.all_gather_results(buf, world)
+guv, gst = FD.unpack_gathered(gathered, n, world)
+ok, c_all, st_all, _ = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="fast", half=4, max_points=n)
+assert np.array_equal(guv.numpy().view(np.uint32), c_all.view(np.uint32)), "gathered uv differs from the unsharded run"
+assert np.array_equal(gst.numpy(), st_all)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_exchange(tmp_path):
+    """N > 1 path on CPU: features sharded over 2 ranks, one all-gather of the packed shards, result
+    identical to the unsharded run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FTK_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {rank} ok" in out

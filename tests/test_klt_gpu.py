@@ -1,0 +1,240 @@
+"""GPU parity tests: the HIP trackers (through the C ABI) against the CPU oracle.
+
+Contract (BASELINE.json north_star): tracked (u, v) within 1e-3 px of the CPU path, status codes
+equal.  The kernels are designed to reproduce the scalar fp32 arithmetic in the same order, so the
+tests assert the stronger property — bit-identical (u, v), status and iteration counts — and state
+the contractual tolerance next to it.
+"""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 1e-3  # north_star tolerance on tracked positions
+
+MODELS = ["basic", "affine", "lssd"]
+METHODS = ["inverse", "direct", "fast"]
+CLASSES = {"basic": "OpticalFlowBasicKlt", "affine": "OpticalFlowAffineKlt", "lssd": "OpticalFlowLssdKlt"}
+
+
+def make_tracker(ftk, model, method, half, half_cols=None, max_points=100000, **kw):
+    klt = getattr(ftk, CLASSES[model])()
+    o = klt.options()
+    o.kMethod = method
+    o.kPatchRowHalfSize = half
+    o.kPatchColHalfSize = half if half_cols is None else half_cols
+    o.kMaxTrackPointsNumber = max_points
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return klt
+
+
+def oracle_kwargs(method, half, half_cols=None, max_points=100000, **kw):
+    d = dict(method=method, half=half, half_cols=half_cols, max_points=max_points)
+    if "kMaxIteration" in kw:
+        d["max_iteration"] = kw["kMaxIteration"]
+    if "kMaxToleranceLargeStep" in kw:
+        d["max_large_step"] = kw["kMaxToleranceLargeStep"]
+    if "kMaxConvergeStep" in kw:
+        d["converge"] = kw["kMaxConvergeStep"]
+    return d
+
+
+def assert_parity(gpu, cpu, what=""):
+    ok_g, uv_g, st_g, it_g = gpu
+    ok_c, uv_c, st_c, it_c = cpu
+    assert ok_g == ok_c, what
+    assert np.array_equal(st_g, st_c), f"{what}: status differs at {np.nonzero(st_g != st_c)[0][:10]}"
+    finite = np.isfinite(uv_c).all(axis=1)
+    d = np.abs(uv_g[finite].astype(np.float64) - uv_c[finite].astype(np.float64))
+    assert d.size == 0 or d.max() <= TOL_PX, f"{what}: max |duv| = {d.max()} px > {TOL_PX}"
+    # design goal: bit-identical results
+    assert np.array_equal(uv_g.view(np.uint32), uv_c.view(np.uint32)), (
+        f"{what}: not bit-identical, {np.count_nonzero((uv_g.view(np.uint32) != uv_c.view(np.uint32)).any(axis=1))} of {len(uv_c)} differ, "
+        f"max {d.max() if d.size else 0}")
+    if it_g is not None:
+        assert np.array_equal(it_g, it_c), f"{what}: iteration counts differ"
+
+
+def run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half, cur_uv=None, status=None, prior=None, luminance=False, **kw):
+    klt = make_tracker(ftk, model, method, half, **kw)
+    if prior is not None:
+        if model == "affine":
+            klt.predict_affine = np.asarray(prior, np.float32)
+        elif model == "lssd":
+            klt.predict_R_cr = np.asarray(prior, np.float32)
+    if model == "lssd":
+        klt.consider_patch_luminance = luminance
+    ref_pyr = ftk.ImagePyramid.from_host_levels(ref_levels)
+    cur_pyr = ftk.ImagePyramid.from_host_levels(cur_levels)
+    ok, c, s = klt.TrackFeatures(ref_pyr, cur_pyr, uv, cur_uv, status)
+    gpu = (ok, c, s, klt.last_iterations)
+    cpu = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, cur_uv, status, prior=prior, consider_luminance=luminance,
+                                   **oracle_kwargs(method, half, **kw))
+    return gpu, cpu
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("model", MODELS)
+def test_all_variants_small(ftk, oracle, model, method):
+    kind = "translation" if model == "basic" else "similarity"
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", kind)
+    uv = scenes.features(400, 320, 240, half=5)
+    gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=5)
+    assert_parity(gpu, cpu, f"{model}/{method}")
+    assert (cpu[2] == 1).sum() > 300  # the scene is trackable
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("model", MODELS)
+def test_all_variants_hard_motion(ftk, oracle, model, method):
+    ref_levels, cur_levels = scenes.scene(320, 240, 4, "hard", "similarity")
+    uv = scenes.features(300, 320, 240, half=6, seed=99)
+    gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=6)
+    assert_parity(gpu, cpu, f"{model}/{method} hard")
+
+
+def test_config1_basic_inverse(ftk, oracle):
+    """BASELINE.json configs[0]: 200 features, 640x480, 3 levels, 11x11."""
+    ref_levels, cur_levels = scenes.scene(640, 480, 3)
+    uv = scenes.features(200, 640, 480, half=5, border_fraction=0.01)
+    gpu, cpu = run_pyramid(ftk, oracle, "basic", "inverse", ref_levels, cur_levels, uv, half=5)
+    assert_parity(gpu, cpu, "config1")
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_config2_basic(ftk, oracle, method):
+    """BASELINE.json configs[1]: 2000 features, 640x480, 4 levels, 21x21."""
+    ref_levels, cur_levels = scenes.scene(640, 480, 4)
+    uv = scenes.features(2000, 640, 480, half=10, border_fraction=0.01)
+    gpu, cpu = run_pyramid(ftk, oracle, "basic", method, ref_levels, cur_levels, uv, half=10)
+    assert_parity(gpu, cpu, f"config2/{method}")
+    assert (cpu[2] == 1).sum() >= 1950
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_textureless_patch(ftk, oracle, model):
+    """Zero Hessian: Eigen's LDLT returns 0 (not NaN) -> ||v||^2 = 0 < threshold -> kTracked at once."""
+    ref_levels, cur_levels = scenes.scene(160, 120, 2, kind="flat")
+    uv = scenes.features(64, 160, 120, half=4)
+    for method in METHODS:
+        gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=4)
+        assert_parity(gpu, cpu, f"flat {model}/{method}")
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_border_and_outside_features(ftk, oracle, model):
+    """Features on / beyond the border exercise every validity path (partial patches, kOutside, zero valid pixels)."""
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    rs = np.random.RandomState(5)
+    n = 256
+    uv = np.empty((n, 2), np.float32)
+    uv[:, 0] = rs.uniform(-12, 332, n)
+    uv[:, 1] = rs.uniform(-12, 252, n)
+    uv[:8] = [[0, 0], [319, 239], [0, 239], [319, 0], [0.5, 0.5], [318.5, 238.5], [-3, 100], [400, 400]]
+    for method in METHODS:
+        gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=5)
+        assert_parity(gpu, cpu, f"border {model}/{method}")
+
+
+def test_prediction_status_and_cap(ftk, oracle):
+    """cur_uv prediction in, incoming status > kTracked skipped, kMaxTrackPointsNumber caps the loop (basic_klt.cpp:9,15)."""
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(300, 320, 240, half=5)
+    pred = uv + np.float32([2.5, -1.5])
+    status = (np.arange(300) % 5).astype(np.uint8)
+    for model in MODELS:
+        for method in METHODS:
+            gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=5, cur_uv=pred, status=status, max_points=250)
+            assert_parity(gpu, cpu, f"pred {model}/{method}")
+            # skipped / capped entries are untouched
+            skip = (status > 1) | (np.arange(300) >= 250)
+            assert np.array_equal(gpu[1][skip], pred[skip])
+            assert np.array_equal(gpu[2][skip], status[skip])
+
+
+def test_default_cap_is_500(ftk, oracle):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(600, 320, 240, half=5)
+    gpu, cpu = run_pyramid(ftk, oracle, "basic", "fast", ref_levels, cur_levels, uv, half=5, max_points=500)
+    assert_parity(gpu, cpu, "cap500")
+    assert np.array_equal(gpu[1][500:], uv[500:]) and (gpu[2][500:] == 0).all()
+
+
+def test_rectangular_patch_and_options(ftk, oracle):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "hard")
+    uv = scenes.features(200, 320, 240, half=7)
+    for model in MODELS:
+        for method in METHODS:
+            gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=3, half_cols=7, kMaxIteration=6,
+                                   kMaxToleranceLargeStep=2, kMaxConvergeStep=1e-3)
+            assert_parity(gpu, cpu, f"rect {model}/{method}")
+
+
+def test_lssd_luminance_and_prior(ftk, oracle):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    uv = scenes.features(300, 320, 240, half=6)
+    th = np.deg2rad(1.0)
+    prior = np.float32([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    for method in METHODS:
+        for lum in (False, True):
+            gpu, cpu = run_pyramid(ftk, oracle, "lssd", method, ref_levels, cur_levels, uv, half=6, prior=prior, luminance=lum)
+            assert_parity(gpu, cpu, f"lssd prior {method} lum={lum}")
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_single_level_overload(ftk, oracle, model):
+    """TrackFeatures(GrayImage, GrayImage, ...): affine honours predict_affine_ only here; LSSD never writes cur back (sic)."""
+    ref_levels, cur_levels = scenes.scene(320, 240, 1, "easy", "similarity")
+    uv = scenes.features(200, 320, 240, half=6)
+    pred = uv + np.float32([3.0, -2.0])
+    prior = np.float32([[1.01, 0.02], [-0.02, 0.99]])
+    for method in METHODS:
+        klt = make_tracker(ftk, model, method, 6)
+        if model == "affine":
+            klt.predict_affine = prior
+        if model == "lssd":
+            klt.predict_R_cr = prior
+        ok, c, s = klt.TrackFeatures(ref_levels[0], cur_levels[0], uv, pred, None)
+        cpu = oracle.klt_track_single(model, ref_levels[0], cur_levels[0], uv, pred, None, prior=prior, **oracle_kwargs(method, 6))
+        assert_parity((ok, c, s, klt.last_iterations), cpu, f"single {model}/{method}")
+        if model == "lssd":
+            assert np.array_equal(c, pred)
+
+
+def test_api_error_behaviour(ftk):
+    """Empty input and level mismatch return false before anything is touched (optical_flow.cpp:8-9)."""
+    ref_levels, cur_levels = scenes.scene(160, 120, 2)
+    klt = ftk.OpticalFlowBasicKlt()
+    p2 = ftk.ImagePyramid.from_host_levels(ref_levels)
+    p1 = ftk.ImagePyramid.from_host_levels(cur_levels[:1])
+    ok, _, _ = klt.TrackFeatures(p2, p2, np.zeros((0, 2), np.float32))
+    assert ok is False
+    ok, _, _ = klt.TrackFeatures(p2, p1, np.float32([[50, 50]]))
+    assert ok is False
+    assert klt.OpticalFlowMethodName() == "Basic-Klt"
+
+
+def test_extract_extend_patch(ftk, oracle):
+    ref_levels, _ = scenes.scene(160, 120, 1)
+    klt = ftk.OpticalFlowBasicKlt()
+    for (u, v) in [(80.3, 60.7), (1.2, 1.9), (158.9, 118.2), (-5.0, 300.0)]:
+        cnt, patch, valid = klt.ExtractExtendPatchInReferenceImage(ref_levels[0], (u, v), 9, 11)
+        ocnt, opatch, ovalid = oracle.extract_extend_patch(ref_levels[0], u, v, 9, 11)
+        assert cnt == ocnt
+        assert np.array_equal(valid, ovalid.astype(bool))
+        assert np.array_equal(patch.view(np.uint32), opatch.view(np.uint32))
+
+
+def test_pyramid_build_matches_oracle(ftk, oracle):
+    """Device CreateImagePyramid == truncating 2x2 box mean, including odd sizes."""
+    from feature_tracker_amd import synth
+    for (w, h, levels) in [(640, 480, 4), (321, 243, 4), (37, 29, 3)]:
+        img, _ = synth.make_image_pair(w, h)
+        pyr = ftk.ImagePyramid.build(img, levels)
+        ref = oracle.create_pyramid(img, levels)
+        assert pyr.level() == levels
+        for i in range(levels):
+            assert np.array_equal(pyr.download_level(i), ref[i]), (w, h, i)

@@ -1,0 +1,107 @@
+"""GPU parity tests: Hamming ForceMatch / NearbyMatch against the CPU oracle (indices bit-exact)."""
+import numpy as np
+import pytest
+
+from feature_tracker_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def matcher(ftk, max_dist, col=40, row=40):
+    m = ftk.BriefMatcher()
+    m.options().kMaxValidDescriptorDistance = max_dist
+    m.options().kMaxValidPredictColDistance = col
+    m.options().kMaxValidPredictRowDistance = row
+    return m
+
+
+@pytest.mark.parametrize("n_ref,n_cur,n_bits", [(1000, 1000, 256), (777, 1300, 256), (300, 257, 128), (100, 5000, 64), (64, 64, 200), (50, 70, 512)])
+def test_force_match(ftk, oracle, n_ref, n_cur, n_bits):
+    ref, cur, perm = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=max(1, n_bits // 13))
+    ok_g, idx_g = matcher(ftk, 60.0).ForceMatch(ref, cur)
+    ok_c, idx_c = oracle.force_match(ref, cur, 60.0)
+    assert ok_g and ok_c
+    assert np.array_equal(idx_g, idx_c)
+    assert (idx_c >= 0).sum() > 0
+
+
+def test_force_match_ties_and_threshold(ftk, oracle):
+    """Duplicate candidates: the lowest j wins; distance == threshold never matches; default threshold 0 matches nothing."""
+    rs = np.random.RandomState(3)
+    ref = rs.randint(0, 2, size=(200, 256)).astype(np.uint8)
+    cur = np.concatenate([ref[::-1], ref, ref[::2]], axis=0).copy()
+    cur[5, :10] ^= 1  # distance exactly 10 for one pair
+    for thr in (0.0, 1.0, 10.0, 10.5, 60.0, 300.0):
+        ok_g, idx_g = matcher(ftk, thr).ForceMatch(ref, cur)
+        ok_c, idx_c = oracle.force_match(ref, cur, thr)
+        assert np.array_equal(idx_g, idx_c), thr
+    ok_g, idx_g = ftk.BriefMatcher().ForceMatch(ref, cur)  # kMaxValidDescriptorDistance = 0
+    assert (idx_g == -1).all()
+
+
+def test_stale_index_pairs_survive(ftk, oracle):
+    """index_pairs is reset only when its size differs (descriptor_matcher.h:60-62)."""
+    ref, cur, _ = synth.make_descriptors(120, 90, n_bits=256, flips=20)
+    stale = np.arange(120, dtype=np.int32) + 1000
+    ok_g, idx_g = matcher(ftk, 25.0).ForceMatch(ref, cur, stale)
+    ok_c, idx_c = oracle.force_match(ref, cur, 25.0, stale)
+    assert np.array_equal(idx_g, idx_c)
+    assert (idx_g >= 1000).any()
+    ok_g, idx_g = matcher(ftk, 25.0).ForceMatch(ref, cur, stale[:7])
+    ok_c, idx_c = oracle.force_match(ref, cur, 25.0, stale[:7])
+    assert np.array_equal(idx_g, idx_c)
+
+
+def test_empty_inputs(ftk, oracle):
+    ref, cur, _ = synth.make_descriptors(10, 10)
+    ok, _ = matcher(ftk, 60.0).ForceMatch(ref, cur[:0])
+    assert ok is False  # descriptor_matcher.h:58
+    ok, idx = matcher(ftk, 60.0).ForceMatch(ref[:0], cur)
+    assert ok is True and idx.size == 0
+    # empty descriptors: ComputeDistance = kMaxInt32 (test_descriptor_matcher_brief.cpp:34-36)
+    e_ref = np.zeros((4, 0), np.uint8)
+    e_cur = np.zeros((6, 0), np.uint8)
+    for thr in (60.0, 3e9):
+        ok_g, idx_g = matcher(ftk, thr).ForceMatch(e_ref, e_cur)
+        ok_c, idx_c = oracle.force_match(e_ref, e_cur, thr)
+        assert ok_g == ok_c and np.array_equal(idx_g, idx_c), thr
+
+
+@pytest.mark.parametrize("window", [(50, 50), (5, 80), (0, 0), (1000, 1000)])
+def test_nearby_match(ftk, oracle, window):
+    n = 1500
+    ref, cur, perm = synth.make_descriptors(n, n, flips=20)
+    rs = np.random.RandomState(11)
+    cur_uv = np.stack([rs.uniform(0, 640, n), rs.uniform(0, 480, n)], axis=1).astype(np.float32)
+    pred_uv = np.empty_like(cur_uv)
+    pred_uv[perm] = cur_uv + rs.uniform(-30, 30, size=(n, 2)).astype(np.float32)  # ref perm[j] is predicted near cur j
+    m = matcher(ftk, 60.0, col=window[0], row=window[1])
+    ok_g, idx_g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+    ok_c, idx_c = oracle.nearby_match(ref, cur, pred_uv, cur_uv, 60.0, max_col=window[0], max_row=window[1])
+    assert ok_g == ok_c
+    assert np.array_equal(idx_g, idx_c)
+    # pixel-returning overload (descriptor_matcher.h:126-157)
+    ok, matched, st = m.NearbyMatchPixels(ref, cur, pred_uv, cur_uv)
+    omatched, ost = oracle.fill_matched_pixels(idx_c, cur_uv)
+    assert np.array_equal(st, ost) and np.array_equal(matched, omatched)
+
+
+def test_nearby_size_checks(ftk):
+    ref, cur, _ = synth.make_descriptors(10, 10)
+    uv = np.zeros((10, 2), np.float32)
+    ok, _ = matcher(ftk, 60.0).NearbyMatch(ref, cur, uv[:9], uv)
+    assert ok is False  # descriptor_matcher.h:95
+    ok, _ = matcher(ftk, 60.0).NearbyMatch(ref, cur, uv, uv[:9])
+    assert ok is False  # :96
+
+
+def test_config4_brute_force_property(ftk):
+    """BASELINE.json configs[3] size (10 000 x 10 000): cur[j] is ref[perm[j]] with 20 flips, random pairs sit near 128,
+    so the match of ref i must be the inverse permutation — a size-independent check that needs no CPU oracle."""
+    n = 10000
+    ref, cur, perm = synth.make_descriptors(n, n, flips=20)
+    ok, idx = matcher(ftk, 60.0).ForceMatch(ref, cur)
+    assert ok
+    inv = np.empty(n, np.int32)
+    inv[perm] = np.arange(n, dtype=np.int32)
+    assert np.array_equal(idx, inv)

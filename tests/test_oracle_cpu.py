@@ -1,0 +1,238 @@
+"""CPU tests of the oracle (oracle/liboracle.so): hand-derived known answers for the substrate
+definitions and the reference's quirks, analytic anchors on synthetic motion, and the committed
+golden fixtures.  The reference has no golden vectors of its own (its test programs assert nothing),
+so these pin the oracle to what can be derived by hand from the reference's source."""
+import os
+
+import numpy as np
+import pytest
+
+from feature_tracker_amd import synth
+from tests import scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- substrate -------------------------------------------------------------------------------
+
+def test_bilinear_known_values(oracle):
+    img = np.array([[10, 20, 30], [40, 50, 60], [70, 80, 90]], dtype=np.uint8)
+    assert oracle.get_pixel_value(img, 0.0, 0.0) == (True, 10.0)
+    assert oracle.get_pixel_value(img, 2.0, 2.0) == (True, 90.0)  # closed rectangle: rows-1 / cols-1 are valid
+    ok, v = oracle.get_pixel_value(img, 0.5, 0.5)
+    assert ok and v == 30.0  # (10+20+40+50)/4
+    ok, v = oracle.get_pixel_value(img, 1.25, 0.75)
+    w = np.float32
+    expect = (w(0.75) * w(0.25)) * w(40) + (w(0.75) * w(0.75)) * w(50) + (w(0.25) * w(0.25)) * w(70) + (w(0.25) * w(0.75)) * w(80)
+    assert ok and v == float(expect)
+    for r, c in [(-0.01, 1), (1, -0.01), (2.01, 1), (1, 2.01), (float("nan"), 1)]:
+        assert oracle.get_pixel_value(img, r, c)[0] is False
+
+
+def test_pyramid_truncating_box_mean(oracle):
+    img = np.array([[1, 2, 3, 4, 9], [5, 6, 7, 8, 9], [255, 255, 0, 1, 9], [255, 254, 2, 0, 9], [7, 7, 7, 7, 7]], dtype=np.uint8)
+    levels = oracle.create_pyramid(img, 3)
+    assert levels[1].tolist() == [[3, 5], [254, 0]]  # (1+2+5+6)>>2, (3+4+7+8)>>2, 1019>>2, 3>>2
+    assert levels[2].tolist() == [[65]]  # (3+5+254+0)>>2
+    big, _ = synth.make_image_pair(97, 61)
+    for a, b in zip(oracle.create_pyramid(big, 4), synth.build_pyramid(big, 4)):
+        assert np.array_equal(a, b)
+
+
+def test_ldlt_known_answers(oracle):
+    assert oracle.ldlt_solve(np.eye(2), [3, 4]).tolist() == [3.0, 4.0]
+    assert oracle.ldlt_solve([[4, 2], [2, 3]], [2, 1]).tolist() == [0.5, 0.0]
+    # zero matrix -> zero vector (Eigen: zero pivots give a zero component, not NaN)
+    for n in (2, 3, 6):
+        assert oracle.ldlt_solve(np.zeros((n, n)), np.ones(n)).tolist() == [0.0] * n
+    # rank-1 Hessian of a horizontal ramp: pivot on H00, second pivot exactly 0 -> component 0
+    assert oracle.ldlt_solve([[16, 0], [0, 0]], [8, 5]).tolist() == [0.5, 0.0]
+    # pivoting: the larger diagonal entry is eliminated first
+    assert oracle.ldlt_solve([[0, 0], [0, 2]], [1, 4]).tolist() == [0.0, 2.0]
+    # NaN right-hand side -> NaN out (the trackers turn that into kNumericError); a NaN pivot fails
+    # Eigen's |d| > tolerance test and is treated like a zero pivot
+    assert np.isnan(oracle.ldlt_solve([[2, 0], [0, 1]], [np.nan, 1])).any()
+    assert oracle.ldlt_solve([[np.nan, 0], [0, 1]], [1, 1]).tolist() == [0.0, 1.0]
+    rs = np.random.RandomState(0)
+    for n in (2, 3, 6):
+        for _ in range(20):
+            a = rs.randn(n, n + 3)
+            spd = (a @ a.T).astype(np.float32)
+            b = rs.randn(n).astype(np.float32)
+            x = oracle.ldlt_solve(spd, b)
+            ref = np.linalg.solve(spd.astype(np.float64), b.astype(np.float64))
+            assert np.allclose(x, ref, rtol=2e-3, atol=2e-4)
+
+
+def test_extract_extend_patch(oracle):
+    img, _ = synth.make_image_pair(64, 48)
+    cnt, patch, valid = oracle.extract_extend_patch(img, 30.25, 20.5, 7, 9)
+    assert cnt == 63 and valid.all()
+    # top-left lattice pixel = floor(uv) - ex/2 -> row 20-3, col 30-4; shared weights from frac(uv)
+    w = np.float32
+    r, c = 17, 26
+    expect = (w(0.5) * w(0.75)) * w(img[r, c]) + (w(0.5) * w(0.25)) * w(img[r, c + 1]) + (w(0.5) * w(0.75)) * w(img[r + 1, c]) + \
+        (w(0.5) * w(0.25)) * w(img[r + 1, c + 1])
+    assert patch[0, 0] == expect
+    # validity needs row <= rows-2 and col <= cols-2 (optical_flow.cpp:73)
+    cnt, patch, valid = oracle.extract_extend_patch(img, 62.0, 46.0, 5, 5)
+    assert valid[:3, :3].all() and not valid[3:, :].any() and not valid[:, 3:].any() and cnt == 9
+    assert (patch[~valid.astype(bool)] == 0).all()
+    cnt, _, valid = oracle.extract_extend_patch(img, -50.0, 10.0, 5, 5)
+    assert cnt == 0 and not valid.any()
+
+
+# ---- reference quirks, derived by hand ------------------------------------------------------
+
+def ramp_pair(shift):
+    x = np.arange(128, dtype=np.int32)
+    ref = np.tile(np.clip(2 * x, 0, 255).astype(np.uint8), (64, 1))
+    cur = np.tile(np.clip(2 * (x - shift), 0, 255).astype(np.uint8), (64, 1))
+    return ref, cur
+
+
+def test_half_length_gauss_newton_step(oracle):
+    """fx = I(x+1) - I(x-1) has no 1/2 factor (basic_klt.cpp:135-137): on I = 2x, shifted by d = 2 px,
+    fx = 4, ft = -4, H00 = 16 P, b0 = 16 P -> v = 1 = d/2; fy = 0 -> H11 = 0 -> LDLT zero pivot -> v_y = 0."""
+    ref, cur = ramp_pair(2)
+    uv = np.float32([[60.0, 30.0]])
+    for method in ("inverse", "direct", "fast"):
+        ok, c, st, it = oracle.klt_track_single("basic", ref, cur, uv, method=method, half=3, max_iteration=1)
+        assert ok and c.tolist() == [[61.0, 30.0]], method
+        assert it.tolist() == [1]
+        # status untouched by the non-fast path when the loop runs out; fast leaves kLargeResidual
+        assert st.tolist() == ([2] if method == "fast" else [0]), method
+    # second iteration: residual 1 px -> step 0.5, ||v||^2 = 0.25 > 4e-2; third: 0.25 -> 0.0625; fourth: 0.125 -> 0.0156 < 0.04
+    ok, c, st, it = oracle.klt_track_single("basic", ref, cur, uv, method="inverse", half=3)
+    assert c.tolist() == [[61.875, 30.0]] and st.tolist() == [1] and it.tolist() == [4]
+
+
+def test_status_semantics(oracle):
+    ref_levels, cur_levels = scenes.scene(160, 120, 2)
+    uv = np.float32([[80, 60], [80, 60], [80, 60], [80, 60], [80, 60], [300, 300]])
+    status = np.uint8([0, 1, 2, 3, 4, 0])
+    for method in ("inverse", "fast"):
+        ok, c, st, it = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, None, status, method=method, half=4)
+        assert st[:2].tolist() == [1, 1]
+        assert st[2:5].tolist() == [2, 3, 4] and np.array_equal(c[2:5], uv[2:5]) and (it[2:5] == 0).all()  # skipped (basic_klt.cpp:15)
+        assert st[5] == 3  # final outside test (basic_klt.cpp:49-53)
+    # kMaxTrackPointsNumber caps the loop (basic_klt.cpp:9)
+    ok, c, st, it = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv[:2], method="fast", half=4, max_points=1)
+    assert st.tolist() == [1, 0] and np.array_equal(c[1], uv[1])
+    # empty input / level mismatch -> false (optical_flow.cpp:8-9)
+    assert oracle.klt_track_pyramid("basic", ref_levels, cur_levels, np.zeros((0, 2), np.float32))[0] is False
+    assert oracle.klt_track_pyramid("basic", ref_levels, cur_levels[:1], uv)[0] is False
+
+
+def test_lssd_single_level_never_writes_back(oracle):
+    ref_levels, cur_levels = scenes.scene(160, 120, 1)
+    uv = scenes.features(20, 160, 120, half=4, border_fraction=0.0)
+    pred = uv + np.float32([1.0, 1.0])
+    for method in ("inverse", "direct", "fast"):
+        ok, c, st, it = oracle.klt_track_single("lssd", ref_levels[0], cur_levels[0], uv, pred, method=method, half=4)
+        assert np.array_equal(c, pred) and (it > 0).all()  # lssd_klt.cpp:72-89
+
+
+def test_affine_pyramid_ignores_prediction(oracle):
+    ref_levels, cur_levels = scenes.scene(160, 120, 2)
+    uv = scenes.features(30, 160, 120, half=4, border_fraction=0.0)
+    prior = np.float32([[1.3, 0.2], [-0.2, 0.7]])
+    a = oracle.klt_track_pyramid("affine", ref_levels, cur_levels, uv, prior=prior, method="inverse", half=4)
+    b = oracle.klt_track_pyramid("affine", ref_levels, cur_levels, uv, prior=None, method="inverse", half=4)
+    assert np.array_equal(a[1], b[1])  # affine_klt.cpp:21
+    c = oracle.klt_track_single("affine", ref_levels[0], cur_levels[0], uv, prior=prior, method="inverse", half=4)
+    d = oracle.klt_track_single("affine", ref_levels[0], cur_levels[0], uv, prior=None, method="inverse", half=4)
+    assert not np.array_equal(c[1], d[1])  # affine_klt.cpp:70
+
+
+# ---- analytic anchor: synthetic motion is recovered ------------------------------------------
+
+@pytest.mark.parametrize("model", ["basic", "affine", "lssd"])
+@pytest.mark.parametrize("method", ["inverse", "direct", "fast"])
+def test_recovers_known_translation(oracle, model, method):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(150, 320, 240, half=6, border_fraction=0.0)
+    ok, c, st, it = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=6)
+    assert ok
+    tracked = st == 1
+    assert tracked.mean() > 0.95
+    err = np.hypot(c[tracked, 0] - uv[tracked, 0] - 3.3, c[tracked, 1] - uv[tracked, 1] + 2.1)
+    # the convergence threshold stops at ||step|| < 0.2 px with half-length steps -> residual of the same order
+    assert np.median(err) < 0.2 and np.percentile(err, 95) < 0.5
+
+
+def test_method_aliases(oracle):
+    """kSse / kNeon fall through `default:` to the fast path (basic_klt.cpp:31-34)."""
+    ref_levels, cur_levels = scenes.scene(160, 120, 2)
+    uv = scenes.features(40, 160, 120, half=4)
+    base = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method=2, half=4)
+    for alias in (3, 4):
+        other = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method=alias, half=4)
+        assert np.array_equal(base[1], other[1]) and np.array_equal(base[2], other[2])
+
+
+# ---- matcher ---------------------------------------------------------------------------------
+
+def bits(*rows):
+    return np.array(rows, dtype=np.uint8)
+
+
+def test_matcher_known_answers(oracle):
+    ref = bits([0, 0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 0, 0, 0, 0])
+    cur = bits([1, 1, 0, 0, 0, 0, 0, 0],  # d = 2 / 2
+               [1, 0, 0, 0, 0, 0, 0, 0],  # d = 1 / 3
+               [0, 1, 0, 0, 0, 0, 0, 0],  # d = 1 / 3   (tie with j = 1 for ref 0 -> lowest j wins)
+               [1, 1, 1, 1, 0, 0, 0, 1])  # d = 5 / 1
+    ok, idx = oracle.force_match(ref, cur, 3.0)
+    assert ok and idx.tolist() == [1, 3]
+    ok, idx = oracle.force_match(ref, cur, 1.0)  # strict '<': distance == threshold never matches
+    assert idx.tolist() == [-1, -1]
+    ok, idx = oracle.force_match(ref, cur, 0.0)  # the default threshold matches nothing
+    assert idx.tolist() == [-1, -1]
+    ok, idx = oracle.force_match(ref, cur, 1.5, index_pairs=[7, 7])  # stale entries survive (descriptor_matcher.h:60-62)
+    assert idx.tolist() == [1, 3]
+    ok, idx = oracle.force_match(ref, cur, 0.5, index_pairs=[7, 7])
+    assert idx.tolist() == [7, 7]
+    assert oracle.force_match(ref, cur[:0], 3.0)[0] is False
+    # window: only cur 3 is near ref 0's prediction; cur 0 near ref 1's
+    pred = np.float32([[100, 100], [10, 10]])
+    cuv = np.float32([[12, 8], [300, 300], [300, 300], [101, 99]])
+    ok, idx = oracle.nearby_match(ref, cur, pred, cuv, 6.0, max_col=5, max_row=5)
+    assert idx.tolist() == [3, 0]
+    ok, idx = oracle.nearby_match(ref, cur, pred, cuv, 3.0, max_col=5, max_row=5)
+    assert idx.tolist() == [-1, 0]
+    assert oracle.nearby_match(ref, cur, pred[:1], cuv, 6.0)[0] is False
+    assert oracle.nearby_match(ref, cur, pred, cuv[:3], 6.0)[0] is False
+
+
+def test_fill_matched_pixels(oracle):
+    cuv = np.float32([[1, 2], [3, 4], [5, 6]])
+    matched, st = oracle.fill_matched_pixels([2, -1, 0, 7, 1], cuv, status=[0, 0, 3, 1, 1])
+    assert st.tolist() == [1, 2, 3, 2, 1]
+    assert matched[0].tolist() == [5, 6] and matched[4].tolist() == [3, 4] and matched[2].tolist() == [0, 0]
+
+
+def test_matcher_recovers_permutation(oracle):
+    ref, cur, perm = synth.make_descriptors(400, 400, flips=20)
+    ok, idx = oracle.force_match(ref, cur, 60.0)
+    inv = np.empty(400, np.int32)
+    inv[perm] = np.arange(400)
+    assert np.array_equal(idx, inv)
+
+
+# ---- committed golden fixtures (self-generated: regression pins, not reference pins) ---------
+
+def golden_cases():
+    if not os.path.isdir(GOLDEN):
+        return []
+    return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_reproduces_golden(oracle, name):
+    from tests.golden import make_golden
+    z = np.load(os.path.join(GOLDEN, name))
+    got = make_golden.run_case(oracle, z)
+    for key, val in got.items():
+        exp = z["out_" + key]
+        assert np.array_equal(np.asarray(val).view(np.uint8), exp.view(np.uint8)), f"{name}: {key}"
