@@ -1,0 +1,144 @@
+// basic_type.h — minimal stand-in for Slam_Utility's basic_type.h (un-vendored; Eigen is not in this
+// image).  Provides the fixed-size float vector / matrix types the feature_tracker API exposes:
+// Vec2 is laid out as {float x, float y} (8 bytes) exactly like Eigen::Vector2f, so
+// std::vector<Vec2> can be handed to the C ABI as a flat (u, v) array.
+#ifndef _SLAM_UTILITY_BASIC_TYPE_H_
+#define _SLAM_UTILITY_BASIC_TYPE_H_
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <initializer_list>
+#include <limits>
+#include <string>
+#include <vector>
+
+template <int R, int C>
+class FixedMat {
+public:
+    static constexpr int kRows = R;
+    static constexpr int kCols = C;
+
+    FixedMat() { std::memset(d_, 0, sizeof(d_)); }
+    template <int RR = R, int CC = C, typename = typename std::enable_if<RR * CC == 2>::type>
+    FixedMat(float a, float b) {
+        d_[0] = a;
+        d_[1] = b;
+    }
+    template <int RR = R, int CC = C, typename = typename std::enable_if<RR * CC == 3>::type>
+    FixedMat(float a, float b, float c) {
+        d_[0] = a;
+        d_[1] = b;
+        d_[2] = c;
+    }
+
+    static FixedMat Zero() { return FixedMat(); }
+    static FixedMat Identity() {
+        FixedMat m;
+        for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0f;
+        return m;
+    }
+    void setZero() { std::memset(d_, 0, sizeof(d_)); }
+    void setIdentity() { *this = Identity(); }
+
+    // column-major storage, as Eigen's default
+    float &operator()(int r, int c) { return d_[c * R + r]; }
+    const float &operator()(int r, int c) const { return d_[c * R + r]; }
+    float &operator()(int i) { return d_[i]; }
+    const float &operator()(int i) const { return d_[i]; }
+    float &operator[](int i) { return d_[i]; }
+    const float &operator[](int i) const { return d_[i]; }
+    float &x() { return d_[0]; }
+    float &y() { return d_[1]; }
+    float &z() { return d_[2]; }
+    const float &x() const { return d_[0]; }
+    const float &y() const { return d_[1]; }
+    const float &z() const { return d_[2]; }
+    float *data() { return d_; }
+    const float *data() const { return d_; }
+    static constexpr int rows() { return R; }
+    static constexpr int cols() { return C; }
+    static constexpr int size() { return R * C; }
+
+    FixedMat operator+(const FixedMat &o) const {
+        FixedMat m;
+        for (int i = 0; i < R * C; ++i) m.d_[i] = d_[i] + o.d_[i];
+        return m;
+    }
+    FixedMat operator-(const FixedMat &o) const {
+        FixedMat m;
+        for (int i = 0; i < R * C; ++i) m.d_[i] = d_[i] - o.d_[i];
+        return m;
+    }
+    FixedMat operator-() const {
+        FixedMat m;
+        for (int i = 0; i < R * C; ++i) m.d_[i] = -d_[i];
+        return m;
+    }
+    FixedMat operator*(float s) const {
+        FixedMat m;
+        for (int i = 0; i < R * C; ++i) m.d_[i] = d_[i] * s;
+        return m;
+    }
+    FixedMat operator/(float s) const {
+        FixedMat m;
+        for (int i = 0; i < R * C; ++i) m.d_[i] = d_[i] / s;
+        return m;
+    }
+    FixedMat &operator+=(const FixedMat &o) { return *this = *this + o; }
+    FixedMat &operator-=(const FixedMat &o) { return *this = *this - o; }
+    FixedMat &operator*=(float s) { return *this = *this * s; }
+    FixedMat &operator/=(float s) { return *this = *this / s; }
+    bool operator==(const FixedMat &o) const { return std::memcmp(d_, o.d_, sizeof(d_)) == 0; }
+
+    template <int K>
+    FixedMat<R, K> operator*(const FixedMat<C, K> &o) const {
+        FixedMat<R, K> m;
+        for (int r = 0; r < R; ++r)
+            for (int k = 0; k < K; ++k) {
+                float s = 0.0f;
+                for (int c = 0; c < C; ++c) s += (*this)(r, c) * o(c, k);
+                m(r, k) = s;
+            }
+        return m;
+    }
+    FixedMat<C, R> transpose() const {
+        FixedMat<C, R> m;
+        for (int r = 0; r < R; ++r)
+            for (int c = 0; c < C; ++c) m(c, r) = (*this)(r, c);
+        return m;
+    }
+    float dot(const FixedMat &o) const {
+        float s = 0.0f;
+        for (int i = 0; i < R * C; ++i) s += d_[i] * o.d_[i];
+        return s;
+    }
+    float squaredNorm() const { return dot(*this); }
+    float norm() const { return std::sqrt(squaredNorm()); }
+
+private:
+    float d_[R * C];
+};
+
+template <int R, int C>
+inline FixedMat<R, C> operator*(float s, const FixedMat<R, C> &m) {
+    return m * s;
+}
+
+using Vec1 = FixedMat<1, 1>;
+using Vec2 = FixedMat<2, 1>;
+using Vec3 = FixedMat<3, 1>;
+using Vec6 = FixedMat<6, 1>;
+using Mat2 = FixedMat<2, 2>;
+using Mat3 = FixedMat<3, 3>;
+using Mat6 = FixedMat<6, 6>;
+using Mat1x2 = FixedMat<1, 2>;
+using Mat1x3 = FixedMat<1, 3>;
+using Mat2x3 = FixedMat<2, 3>;
+
+static_assert(sizeof(Vec2) == 2 * sizeof(float), "Vec2 must be a packed (u, v) pair");
+
+constexpr int32_t kMaxInt32 = std::numeric_limits<int32_t>::max();
+constexpr float kPai = 3.14159265358979323846f;
+
+#endif  // _SLAM_UTILITY_BASIC_TYPE_H_

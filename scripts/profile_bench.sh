@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   scripts/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/{trace,pmc_*}/...
+# Kernel trace + stats in one run; every PMC group in its own run (never combined with tracing).
+set -u
+TAG=${1:-r1}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace_stdout.log" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  name=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- $BENCH > "$OUT/pmc_${name}_stdout.log" 2>&1 || echo "pmc group failed: $grp" >> "$OUT/errors.log"
+done
+# keep the box->repo merge small: drop everything but csv/log
+find "$OUT" -type f ! -name '*.csv' ! -name '*.log' -delete
+du -sh "$OUT"

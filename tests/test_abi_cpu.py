@@ -64,3 +64,24 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "liboracle" not in text and "ftk_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_cpp_host_layer_builds_and_fails_loudly_without_gpu(tmp_path):
+    """The C++ classes with the reference's names build on a CPU-only box; without a device TrackFeatures returns false and says why."""
+    import subprocess
+    import numpy as np
+    host = os.path.join(ROOT, "feature_tracker_amd", "host")
+    res = subprocess.run(["make", "-C", host, "-j4"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    from feature_tracker_amd import _native
+    if _native.lib().ftk_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    img = (np.arange(64 * 64) % 251).astype(np.uint8).reshape(64, 64)
+    for name in ("ref.pgm", "cur.pgm"):
+        with open(tmp_path / name, "wb") as f:
+            f.write(b"P5\n64 64\n255\n" + img.tobytes())
+    (tmp_path / "f.txt").write_text("0x1p+5 0x1p+5\n")
+    exe = os.path.join(host, "build", "track_cli")
+    out = subprocess.run([exe, "basic", "2", "2", "4", "4", str(tmp_path / "ref.pgm"), str(tmp_path / "cur.pgm"), str(tmp_path / "f.txt")],
+                         capture_output=True, text=True)
+    assert out.returncode == 1 and "ok 0" in out.stdout and "no CPU fallback" in (out.stdout + out.stderr)

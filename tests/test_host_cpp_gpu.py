@@ -1,0 +1,145 @@
+"""GPU tests of the C++ host layer (feature_tracker_amd/host): the reference's class names driven
+through small CLI programs, compared with the oracle bit for bit."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from feature_tracker_amd import synth
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "feature_tracker_amd", "host", "build")
+DATA = os.path.join(ROOT, "tests", "data", "optical_flow")
+METHOD_ID = {"inverse": 0, "direct": 1, "fast": 2}
+
+
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def write_features(path, uv, pred=None, status=None):
+    with open(path, "w") as f:
+        for i in range(len(uv)):
+            line = f"{float(uv[i, 0]).hex()} {float(uv[i, 1]).hex()}"
+            if pred is not None:
+                line += f" {float(pred[i, 0]).hex()} {float(pred[i, 1]).hex()} {int(status[i])}"
+            f.write(line + "\n")
+
+
+def run_track_cli(tmp_path, model, method, levels, half, ref, cur, uv, pred=None, status=None, max_points=100000, prior=None, lum=False):
+    exe = os.path.join(BUILD, "track_cli")
+    assert os.path.exists(exe), "host layer not built (python -c 'import __graft_entry__ as g; g.build()')"
+    write_pgm(tmp_path / "ref.pgm", ref)
+    write_pgm(tmp_path / "cur.pgm", cur)
+    write_features(tmp_path / "f.txt", uv, pred, status)
+    cmd = [exe, model, str(METHOD_ID[method]), str(levels), str(half), str(half), str(tmp_path / "ref.pgm"), str(tmp_path / "cur.pgm"),
+           str(tmp_path / "f.txt"), str(max_points)]
+    pr = np.eye(2, dtype=np.float32) if prior is None else np.asarray(prior, np.float32)
+    cmd += [float(x).hex() for x in pr.reshape(4)] + [str(int(lum))]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0].startswith("ok 1"), res.stdout[:500]
+    rows = [l.split() for l in lines[1:]]
+    uvb = np.array([[int(r[0], 16), int(r[1], 16)] for r in rows], dtype=np.uint32)
+    return uvb.view(np.float32), np.array([int(r[2]) for r in rows], np.uint8), np.array([int(r[3]) for r in rows], np.uint32), lines[0]
+
+
+@pytest.mark.parametrize("model", ["basic", "affine", "lssd"])
+@pytest.mark.parametrize("method", ["inverse", "direct", "fast"])
+def test_cpp_pyramid_tracking_matches_oracle(tmp_path, oracle, model, method):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    uv = scenes.features(150, 320, 240, half=5)
+    c, s, it, head = run_track_cli(tmp_path, model, method, 3, 5, ref_levels[0], cur_levels[0], uv)
+    ok, oc, os_, oit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=5, max_points=100000)
+    assert np.array_equal(s, os_)
+    assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))
+    assert np.array_equal(it, oit)
+    assert {"basic": "Basic-Klt", "affine": "Affine-Klt", "lssd": "Lssd-Klt"}[model] in head
+
+
+@pytest.mark.parametrize("model", ["basic", "affine", "lssd"])
+def test_cpp_single_image_overload_with_prediction(tmp_path, oracle, model):
+    ref_levels, cur_levels = scenes.scene(320, 240, 1, "easy", "similarity")
+    uv = scenes.features(100, 320, 240, half=6)
+    pred = uv + np.float32([2.0, -1.0])
+    status = (np.arange(100) % 4).astype(np.uint8)
+    prior = np.float32([[1.01, 0.02], [-0.02, 0.99]])
+    c, s, it, _ = run_track_cli(tmp_path, model, "fast", 0, 6, ref_levels[0], cur_levels[0], uv, pred, status, max_points=90, prior=prior, lum=True)
+    ok, oc, os_, oit = oracle.klt_track_single(model, ref_levels[0], cur_levels[0], uv, pred, status, prior=prior, consider_luminance=True,
+                                               method="fast", half=6, max_points=90)
+    assert np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32))
+
+
+def write_descriptors(path, ref, cur, ref_uv, cur_uv):
+    with open(path, "w") as f:
+        f.write(f"{len(ref)} {len(cur)} {ref.shape[1]}\n")
+        for d, uv in ((ref, ref_uv), (cur, cur_uv)):
+            for i in range(len(d)):
+                bits = "".join("1" if b else "0" for b in d[i]) or "-"
+                f.write(f"{bits} {float(uv[i, 0]).hex()} {float(uv[i, 1]).hex()}\n")
+
+
+@pytest.mark.parametrize("mode", ["force", "nearby"])
+def test_cpp_brief_matcher_matches_oracle(tmp_path, oracle, mode):
+    ref, cur, perm = synth.make_descriptors(300, 420, flips=20)
+    rs = np.random.RandomState(4)
+    cur_uv = np.stack([rs.uniform(0, 640, 420), rs.uniform(0, 480, 420)], axis=1).astype(np.float32)
+    ref_uv = np.stack([rs.uniform(0, 640, 300), rs.uniform(0, 480, 300)], axis=1).astype(np.float32)
+    ref_uv[perm[:300] % 300] = cur_uv[:300] + 5.0
+    write_descriptors(tmp_path / "d.txt", ref, cur, ref_uv, cur_uv)
+    exe = os.path.join(BUILD, "match_cli")
+    res = subprocess.run([exe, mode, "60", "50", "40", str(tmp_path / "d.txt")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0] == "ok 1" and lines[1] == "ok2 1"
+    rows = [l.split() for l in lines[2:]]
+    idx = np.array([int(r[0]) for r in rows], np.int32)
+    st = np.array([int(r[1]) for r in rows], np.uint8)
+    if mode == "force":
+        ok, oidx = oracle.force_match(ref, cur, 60.0)
+    else:
+        ok, oidx = oracle.nearby_match(ref, cur, ref_uv, cur_uv, 60.0, max_col=50, max_row=40)
+    assert np.array_equal(idx, oidx)
+    omatched, ost = oracle.fill_matched_pixels(oidx, cur_uv)
+    assert np.array_equal(st, ost)
+    got = np.array([[int(r[2], 16), int(r[3], 16)] for r in rows], dtype=np.uint32).view(np.float32)
+    assert np.array_equal(got[ost == 1], omatched[ost == 1])
+
+
+def test_demo_on_reference_example_images():
+    """The reference's own example pair (752x480 PNGs): Harris corners -> pyramids -> 3 trackers; most corners must track."""
+    exe = os.path.join(BUILD, "demo_optical_flow")
+    res = subprocess.run([exe, os.path.join(DATA, "ref_image.png"), os.path.join(DATA, "cur_image.png"), "4", "6", "2"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    import re
+    hits = re.findall(r"(Basic|Affine|Lssd) klt pass 1: ok 1, (\d+) / (\d+) tracked", res.stdout)
+    assert len(hits) == 3, res.stdout
+    for name, tracked, total in hits:
+        assert int(total) >= 100 and int(tracked) >= 0.6 * int(total), res.stdout
+
+
+def test_real_images_python_vs_oracle(ftk, oracle):
+    """Parity on the reference's real example images through the Python binding, all three models, fast method (the tests' default)."""
+    from PIL import Image
+    ref = np.array(Image.open(os.path.join(DATA, "ref_image.png")))
+    cur = np.array(Image.open(os.path.join(DATA, "cur_image.png")))
+    assert ref.shape == (480, 752) and ref.dtype == np.uint8
+    ref_levels, cur_levels = synth.build_pyramid(ref, 4), synth.build_pyramid(cur, 4)
+    uv = synth.make_features(300, 752, 480, seed=3, half=6)
+    for model, cls in (("basic", ftk.OpticalFlowBasicKlt), ("affine", ftk.OpticalFlowAffineKlt), ("lssd", ftk.OpticalFlowLssdKlt)):
+        for method in ("fast", "inverse"):
+            klt = cls()
+            klt.options().kMethod = method
+            ok, c, s = klt.TrackFeatures(ftk.ImagePyramid.from_host_levels(ref_levels), ftk.ImagePyramid.from_host_levels(cur_levels), uv)
+            ok2, oc, os_, oit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=6)
+            assert np.array_equal(s, os_), (model, method)
+            assert np.array_equal(c.view(np.uint32), oc.view(np.uint32)), (model, method)
