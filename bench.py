@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", help="feature_tracker_amd.synth.CONFIGS key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--features", type=int, default=0, help="experiment knob: override the workload's feature count (the reported config says so)")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +108,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = synth.CONFIGS[args.workload]
+    cfg = dict(synth.CONFIGS[args.workload])
+    if args.features > 0:
+        cfg["n"] = args.features
     n, w, h, levels, half = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
     if cfg["model"] == "basic":
         ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))

@@ -80,12 +80,13 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except Exception:
             pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("FTK_LIB_PATH", LIB_PATH)  # e.g. a diagnostic (-DFTK_STAMPS) build
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP extension must be built first "
+            f"{path} is missing: the HIP extension must be built first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C feature_tracker_amd/csrc). "
             "feature_tracker_amd has no CPU fallback.")
-    l = C.CDLL(LIB_PATH)
+    l = C.CDLL(path)
     vp, i32, u32p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)
     l.ftk_abi_version.restype = C.c_int
     l.ftk_device_count.restype = C.c_int

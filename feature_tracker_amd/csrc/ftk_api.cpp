@@ -5,6 +5,7 @@
 // usable every compute entry point fails with FTK_E_NO_DEVICE / FTK_E_HIP.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -150,6 +151,30 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.E = p.ex_rows * p.ex_cols;
     p.magic_pc = div_magic(p.patch_cols);
     p.magic_exc = div_magic(p.ex_cols);
+    p.rwin_rows = p.patch_rows + 3;
+    p.rwin_cols = (p.patch_cols + 3 + 3) & ~3;  // pixel-pair columns, rounded up to a multiple of 4 (8-byte LDS stores)
+    p.cwin_margin = 2;
+    p.cwin_rows = p.rwin_rows + 2 * p.cwin_margin;
+    p.cwin_cols = (p.patch_cols + 3 + 2 * p.cwin_margin + 3) & ~3;
+    p.magic_rwc = div_magic(p.rwin_cols);
+    p.magic_cwc = div_magic(p.cwin_cols);
+    p.magic_rwq = div_magic(p.rwin_cols / 4);
+    p.magic_cwq = div_magic(p.cwin_cols / 4);
+    // Wavefronts per feature.  Small batches are latency-bound: up to 4 waves share the pixel loops
+    // (measured on MI355X, 21x21 patch: 56 / 41 / 32 us per call at 1 / 2 / 4 waves for <= 1024
+    // features).  Larger batches no longer fit the chip at 4 waves per feature (register-limited to
+    // 4 workgroups per CU), so they run 2 waves per feature, which keeps every workgroup resident.
+    int waves = (p.P + 63) / 64;
+    if (waves > 4) {
+        waves = 4;
+    }
+    if (n > 1024 && waves > 2) {
+        waves = 2;
+    }
+    if (const char *env = getenv("FTK_KLT_WAVES")) {
+        waves = atoi(env);  // experiment override
+    }
+    p.waves_per_feature = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
     const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
     if (lds == 0 || lds > 160 * 1024) {
         return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu B of LDS (limit 163840)", p.patch_rows, p.patch_cols, lds);
@@ -478,8 +503,32 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     p.status_out = d_status_out;
     p.iters = d_iters;
     FTK_HIP(ctx, hipSetDevice(ctx->device));
+#ifdef FTK_STAMPS
+    // diagnostic build: per-phase cycle totals (s_memtime ticks at 100 MHz) averaged over features, to stderr
+    unsigned long long *d_stamps = nullptr;
+    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_stamps), sizeof(unsigned long long) * 8 * (size_t)n));
+    FTK_HIP(ctx, hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 8 * (size_t)n, ctx->stream));
+    p.stamps = d_stamps;
+    FTK_HIP(ctx, ftk::klt_launch(model, opt->method, p, ctx->stream));
+    {
+        std::vector<unsigned long long> h(8 * (size_t)n);
+        FTK_HIP(ctx, hipMemcpyAsync(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double avg[8] = {0};
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 8; ++k) avg[k] += (double)h[(size_t)i * 8 + k];
+        static int printed = 0;
+        if (printed++ < 3) {
+            fprintf(stderr, "[ftk stamps] memtime ticks/feature: ref_stage %.0f setup %.0f cur_stage %.0f phaseA %.0f count %.0f chain %.0f solve %.0f total %.0f\n",
+                    avg[0] / n, avg[1] / n, avg[2] / n, avg[3] / n, avg[4] / n, avg[5] / n, avg[6] / n, avg[7] / n);
+        }
+        (void)hipFree(d_stamps);
+    }
+    return FTK_OK;
+#else
     FTK_HIP(ctx, ftk::klt_launch(model, opt->method, p, ctx->stream));
     return FTK_OK;
+#endif
 }
 
 int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *ref_uv,

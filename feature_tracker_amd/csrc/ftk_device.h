@@ -40,11 +40,18 @@ struct KltParams {
     int32_t ex_rows, ex_cols, E;
     uint32_t magic_pc;   // ceil(2^32 / patch_cols): row = umulhi(p, magic_pc)
     uint32_t magic_exc;  // ceil(2^32 / ex_cols)
+    // LDS image windows (16-bit pixel pairs): reference footprint and current footprint + margin
+    int32_t rwin_rows, rwin_cols;
+    int32_t cwin_rows, cwin_cols, cwin_margin;
+    uint32_t magic_rwc, magic_cwc;  // division by window cols
+    uint32_t magic_rwq, magic_cwq;  // division by window cols / 4
+    int32_t waves_per_feature;  // workgroup = 64 * waves_per_feature lanes
+    unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
 };
 
 // LDS bytes a (model, method) variant needs for the given geometry; 0 if the variant is unknown.
 size_t klt_lds_bytes(int model, int method, const KltParams &p);
-// Launches the tracker kernel for (model, method) on `stream`; one 64-lane workgroup per feature.
+// Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
 
 struct MatchParams {

@@ -1,24 +1,28 @@
 // klt_kernels.hip — pyramidal Lucas-Kanade trackers for gfx950 (MI355X), hand-written HIP.
 //
-// One 64-lane wavefront (= one workgroup) owns one feature for the whole call: it walks the
-// pyramid coarse -> fine and runs every Gauss-Newton iteration without leaving the CU, so a
-// TrackFeatures call is ONE launch and the only HBM traffic is the patch footprints it samples
-// (the pyramids of both frames total 0.8-5.5 MB and stay L2 / Infinity-Cache resident).
+// One workgroup of W wavefronts (W = 1..4, chosen from the patch size) owns one feature for the
+// whole call: it walks the pyramid coarse -> fine and runs every Gauss-Newton iteration without
+// leaving the CU, so a TrackFeatures call is ONE launch.  The pyramids of both frames total
+// 0.8-5.5 MB and stay L2 / Infinity-Cache resident; per level each workgroup copies the
+// (2h+4)^2-pixel footprint of its feature from the reference image, and a slightly larger one from
+// the current image, into LDS ("windows", stored as 16-bit pixel pairs so one bilinear sample is
+// two ds_read_u16 + four v_cvt_f32_ubyte), and every sample of the Gauss-Newton loop is served from
+// there.  Samples that fall outside a window (diverging features, strongly warped patches) take a
+// global-memory path with identical arithmetic.
 //
-// Work split inside the wave, per iteration:
-//   phase A (64-wide)  : lane l handles patch pixels l, l+64, ...: bilinear samples (byte loads,
-//                        rows of a patch are contiguous so a wave touches <= 2 cache lines per
-//                        patch row), gradients, residual, and the per-pixel PRODUCTS of every
-//                        normal-equation entry, written to LDS as terms[k][pixel].
-//   phase B (K lanes)  : lane k < K adds terms[k][0..P) strictly in row-major pixel order
-//                        (ds_read_b128 + 4 dependent v_add_f32).  This is the reference's
-//                        sequential accumulation order, so sums are bit-identical to the scalar
-//                        CPU path; the Gauss-Newton convergence test (||v||^2 < 4e-2) amplifies
-//                        any 1-ulp deviation into extra/missing iterations, which is why a
-//                        shuffle-tree reduction is not used here.
-//   phase C (uniform)  : results are broadcast (v_readlane), every lane solves the 2x2 / 3x3 /
-//                        6x6 system with an Eigen-compatible pivoted LDLT held in registers and
-//                        applies the update and the status logic redundantly (no divergence).
+// Work split per iteration:
+//   phase A (64*W lanes): each lane handles patch pixels tid, tid+64W, ...: bilinear samples,
+//                         gradients, residual, and the per-pixel PRODUCTS of every normal-equation
+//                         entry, written to LDS as terms[k][pixel].
+//   phase B (K lanes)   : lane k < K of wave 0 adds terms[k][0..P) strictly in row-major pixel order
+//                         (ds_read_b128 + 4 dependent v_add_f32).  This is the reference's
+//                         sequential accumulation order, so sums are bit-identical to the scalar
+//                         CPU path; the Gauss-Newton convergence test (||v||^2 < 4e-2) amplifies
+//                         any 1-ulp deviation into extra/missing iterations, which is why a
+//                         shuffle-tree reduction is not used here.
+//   phase C (uniform)   : the K sums are broadcast through LDS, every lane solves the 2x2 / 3x3 /
+//                         6x6 system with an Eigen-compatible pivoted LDLT held in registers and
+//                         applies the update and the status logic redundantly (no divergence).
 //
 // Arithmetic contract: IEEE fp32, no FMA contraction (-ffp-contract=off), correctly rounded
 // division / sqrt, bilinear weights and summation order exactly as the reference writes them.
@@ -36,6 +40,21 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Diagnostic build only (-DFTK_STAMPS): per-phase cycle totals of every workgroup, written to a
+// side buffer that no other code reads.  The production build contains none of this.
+#ifdef FTK_STAMPS
+#define FTK_STAMP_BEGIN(b) (b).stamp_t0 = __builtin_amdgcn_s_memtime()
+#define FTK_STAMP_END(b, k)                                           \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        (b).stamp_acc[k] += now_ - (b).stamp_t0;                      \
+        (b).stamp_t0 = now_;                                          \
+    } while (0)
+#else
+#define FTK_STAMP_BEGIN(b)
+#define FTK_STAMP_END(b, k)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------------
@@ -48,40 +67,131 @@ __device__ __forceinline__ float floor_from_trunc(float x, int t) {
     return (f > x) ? f - 1.0f : f;
 }
 __device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[(long long)row * im.cols + col]; }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// GrayImage::GetPixelValueNoCheck(float, float): bilinear, ((tl + tr) + bl) + br
-__device__ __forceinline__ float bilinear(const DevImage &im, float row, float col) {
+// Thread coordinates inside the feature's workgroup.
+struct Blk {
+    int tid, nt, lane, wave, nwaves;
+#ifdef FTK_STAMPS
+    mutable unsigned long long stamp_t0 = 0;
+    mutable unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+};
+
+// An image window resident in LDS.  Element (r, c) packs the pixel pair
+// (img[clamp(r_lo + r)][clamp(c_lo + c)], img[clamp(r_lo + r)][clamp(c_lo + c + 1)]) into 16 bits,
+// clamp = clamp-to-edge, so the 2x2 neighbourhood of any in-image pixel is two ds_read_u16.
+struct Win {
+    const uint16_t *data;
+    int r_lo, c_lo;
+    int rows, cols;  // wave-uniform
+};
+
+__device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols);
+
+// The 2x2 neighbourhood of the in-image pixel (r0, c0), +1 neighbours clamped to the image:
+// from the LDS window when it covers the pixel, from global memory otherwise.
+__device__ __forceinline__ void fetch4(const DevImage &im, const Win &w, int r0, int c0, float &p00, float &p01, float &p10, float &p11) {
+    const int lr = (int)((unsigned)r0 - (unsigned)w.r_lo);
+    const int lc = (int)((unsigned)c0 - (unsigned)w.c_lo);
+    if ((unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols) {
+        const unsigned a = w.data[lr * w.cols + lc];
+        const unsigned bb = w.data[(lr + 1) * w.cols + lc];
+        p00 = (float)(a & 0xFFu);
+        p01 = (float)(a >> 8);
+        p10 = (float)(bb & 0xFFu);
+        p11 = (float)(bb >> 8);
+    } else {
+        const int r1 = (r0 + 1 < im.rows) ? r0 + 1 : r0;
+        const int c1 = (c0 + 1 < im.cols) ? c0 + 1 : c0;
+        p00 = px(im, r0, c0);
+        p01 = px(im, r0, c1);
+        p10 = px(im, r1, c0);
+        p11 = px(im, r1, c1);
+    }
+}
+
+// GrayImage::GetPixelValueNoCheck(float, float): bilinear, ((tl + tr) + bl) + br, any coordinates
+__device__ __forceinline__ float bilinear(const DevImage &im, const Win &w, float row, float col) {
     int r0 = f2i(row);
     int c0 = f2i(col);
     const float sub_row = row - floor_from_trunc(row, r0);
     const float sub_col = col - floor_from_trunc(col, c0);
-    r0 = r0 < 0 ? 0 : (r0 > im.rows - 1 ? im.rows - 1 : r0);
-    c0 = c0 < 0 ? 0 : (c0 > im.cols - 1 ? im.cols - 1 : c0);
-    const int r1 = (r0 + 1 < im.rows) ? r0 + 1 : r0;
-    const int c1 = (c0 + 1 < im.cols) ? c0 + 1 : c0;
+    r0 = clampi(r0, 0, im.rows - 1);
+    c0 = clampi(c0, 0, im.cols - 1);
     const float inv_sub_row = 1.0f - sub_row;
     const float inv_sub_col = 1.0f - sub_col;
     const float w_tl = inv_sub_row * inv_sub_col;
     const float w_tr = inv_sub_row * sub_col;
     const float w_bl = sub_row * inv_sub_col;
     const float w_br = sub_row * sub_col;
-    return w_tl * px(im, r0, c0) + w_tr * px(im, r0, c1) + w_bl * px(im, r1, c0) + w_br * px(im, r1, c1);
+    float p00, p01, p10, p11;
+    fetch4(im, w, r0, c0, p00, p01, p10, p11);
+    return w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
 }
 
-// GrayImage::GetPixelValue(row, col, *value): closed-rectangle validity, NaN invalid
-__device__ __forceinline__ bool sample(const DevImage &im, float row, float col, float &value) {
+// GrayImage::GetPixelValue(row, col, *value): closed-rectangle validity, NaN invalid.  Inside the
+// rectangle truncation equals floor, so the fractions need no floor fix-up.
+__device__ __forceinline__ bool sample(const DevImage &im, const Win &w, float row, float col, float &value) {
     if (!(row >= 0.0f && col >= 0.0f && row <= (float)(im.rows - 1) && col <= (float)(im.cols - 1))) {
         return false;
     }
-    value = bilinear(im, row, col);
+    const int r0 = (int)row;
+    const int c0 = (int)col;
+    const float sub_row = row - (float)r0;
+    const float sub_col = col - (float)c0;
+    const float inv_sub_row = 1.0f - sub_row;
+    const float inv_sub_col = 1.0f - sub_col;
+    const float w_tl = inv_sub_row * inv_sub_col;
+    const float w_tr = inv_sub_row * sub_col;
+    const float w_bl = sub_row * inv_sub_col;
+    const float w_br = sub_row * sub_col;
+    float p00, p01, p10, p11;
+    fetch4(im, w, r0, c0, p00, p01, p10, p11);
+    value = w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
     return true;
+}
+
+// --- straight-line sampling for the hot loops ---------------------------------------------------
+// One image axis of a bilinear tap: validity on the closed interval [0, limit], base index, fraction
+// and its complement — the same quantities sample() derives, computed without branches.
+struct Axis {
+    int i0;
+    float sub, inv;
+    bool valid;
+};
+
+__device__ __forceinline__ Axis make_axis(float x, int limit) {
+    Axis a;
+    a.valid = (x >= 0.0f && x <= (float)limit);
+    a.i0 = (int)x;
+    a.sub = x - (float)a.i0;
+    a.inv = 1.0f - a.sub;
+    return a;
+}
+
+// Bilinear value of (row axis, col axis) read from the LDS window with NO branch: the LDS index is
+// clamped into the window so the read is always safe, and `hit` is cleared when the tap was not
+// really covered (the caller then redoes the pixel through sample(), which can reach global memory).
+// Same weight products and summation order as sample().
+__device__ __forceinline__ float tap(const Win &w, const Axis &ar, const Axis &ac, bool &hit) {
+    const int lr = (int)((unsigned)ar.i0 - (unsigned)w.r_lo);
+    const int lc = (int)((unsigned)ac.i0 - (unsigned)w.c_lo);
+    const bool in = (unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols;
+    hit = hit && in;
+    const int idx = in ? lr * w.cols + lc : 0;
+    const unsigned a = w.data[idx];
+    const unsigned bb = w.data[idx + w.cols];
+    const float w_tl = ar.inv * ac.inv;
+    const float w_tr = ar.inv * ac.sub;
+    const float w_bl = ar.sub * ac.inv;
+    const float w_br = ar.sub * ac.sub;
+    return w_tl * (float)(a & 0xFFu) + w_tr * (float)(a >> 8) + w_bl * (float)(bb & 0xFFu) + w_br * (float)(bb >> 8);
 }
 
 __device__ __forceinline__ bool uv_outside(float u, float v, const DevImage &im) {
     return u < 0.0f || u > (float)(im.cols - 1) || v < 0.0f || v > (float)(im.rows - 1);
 }
-
-__device__ __forceinline__ float bcast(float x, int src_lane) { return __shfl(x, src_lane, kWave); }
 
 template <typename T>
 __device__ __forceinline__ void swap_values(T &a, T &b) {
@@ -230,16 +340,27 @@ __device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N]
 // LDS carve-up of one workgroup (dynamic shared memory)
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    float *terms;    // [K][Ppad] per-pixel products, k-major
-    float *a0;       // 4 float arrays of Epad entries each (meaning depends on the variant)
-    float *a1;
+    float *terms;         // [K][Ppad] per-pixel products, k-major
+    float *a0;            // Epad floats (meaning depends on the variant)
+    float *a1;            // Ppad floats each
     float *a2;
     float *a3;
-    uint8_t *flagsE;  // E bytes
-    uint8_t *flagsP;  // P bytes
+    float *sums;          // 72 floats: [0,K) chain sums, [K..] published solution, [32,68) affine-fast Hessian
+    uint32_t *wave_cnt;   // 8 slots for the workgroup-wide valid-pixel count
+    uint16_t *ref_win;    // reference-image window (rwin_rows x rwin_cols pixel pairs)
+    uint16_t *cur_win;    // current-image window   (cwin_rows x cwin_cols pixel pairs)
+    uint8_t *flagsE;      // Epad bytes
+    uint8_t *flagsP;      // Ppad bytes
 };
 
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
+
+__host__ __device__ inline size_t carve_bytes(int K, const KltParams &p) {
+    const size_t epad = (size_t)pad4(p.E);
+    const size_t floats = (size_t)K * p.Ppad + epad + 3 * (size_t)p.Ppad + 72 + 8;
+    const size_t shorts = (size_t)pad4(p.rwin_rows * p.rwin_cols) + (size_t)pad4(p.cwin_rows * p.cwin_cols);
+    return sizeof(float) * floats + sizeof(uint16_t) * shorts + epad + (size_t)p.Ppad;
+}
 
 __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &p) {
     Carve c;
@@ -247,36 +368,142 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
     c.terms = base;
     c.a0 = c.terms + K * p.Ppad;
     c.a1 = c.a0 + epad;
-    c.a2 = c.a1 + epad;
-    c.a3 = c.a2 + epad;
-    c.flagsE = reinterpret_cast<uint8_t *>(c.a3 + epad);
+    c.a2 = c.a1 + p.Ppad;
+    c.a3 = c.a2 + p.Ppad;
+    c.sums = c.a3 + p.Ppad;
+    c.wave_cnt = reinterpret_cast<uint32_t *>(c.sums + 72);
+    c.ref_win = reinterpret_cast<uint16_t *>(c.wave_cnt + 8);
+    c.cur_win = c.ref_win + pad4(p.rwin_rows * p.rwin_cols);
+    c.flagsE = reinterpret_cast<uint8_t *>(c.cur_win + pad4(p.cwin_rows * p.cwin_cols));
     c.flagsP = c.flagsE + epad;
     return c;
 }
 
-// Phase B: lane k < K returns sum_{px} terms[k][px] accumulated strictly left to right.
-__device__ __forceinline__ float chain_sum(const float *terms, int K, int Ppad, int lane) {
-    float acc = 0.0f;
-    if (lane < K) {
-        const float4 *t = reinterpret_cast<const float4 *>(terms + lane * Ppad);
-        const int n4 = Ppad >> 2;
-        for (int i = 0; i < n4; ++i) {
-            const float4 v = t[i];
-            acc += v.x;
-            acc += v.y;
-            acc += v.z;
-            acc += v.w;
+// Workgroup-wide sum of the per-wave valid-pixel counts.  The leading barrier also publishes the
+// terms written in phase A; the trailing one lets the slots be reused.
+__device__ __forceinline__ uint32_t block_total(const Blk &b, uint32_t wave_sum, uint32_t *slots) {
+    if (b.lane == 0) {
+        slots[b.wave] = wave_sum;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (int w = 0; w < b.nwaves; ++w) {
+        total += slots[w];
+    }
+    __syncthreads();
+    return total;
+}
+
+// Cheaper form for the per-iteration count: the per-wave counts ride on the two barriers of
+// chain_sums (publish before, collect after).  Slots are double-buffered by iteration parity because
+// a fast wave may publish its next count before a slow wave has collected the previous one.
+__device__ __forceinline__ void publish_count(const Blk &b, uint32_t wave_sum, uint32_t *slots, uint32_t parity) {
+    if (b.lane == 0) {
+        slots[(parity & 1u) * 4 + b.wave] = wave_sum;
+    }
+}
+__device__ __forceinline__ uint32_t collect_count(const Blk &b, const uint32_t *slots, uint32_t parity) {
+    uint32_t total = 0;
+    for (int w = 0; w < b.nwaves; ++w) {
+        total += slots[(parity & 1u) * 4 + w];
+    }
+    return total;
+}
+
+// Phase B: lane k < K of wave 0 adds terms[k][0..Ppad) strictly left to right and publishes the sum.
+// The adds form one dependent chain (that IS the reference's order); the LDS reads are software
+// pipelined one round (8 x ds_read_b128 = 32 terms) ahead in two ping-pong register sets, pinned
+// in place with sched_barrier, so that the chain of v_add_f32 — not the ds_read latency — sets the
+// pace.  The prefetch may run up to 16 float4 past the end of a row: it stays inside the
+// workgroup's LDS carve (the arrays behind `terms` are larger than that) and is never consumed.
+constexpr int kChainRound = 8;
+
+__device__ __forceinline__ void chain_load(float4 (&q)[kChainRound], const float4 *t) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        q[d] = t[d];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float chain_consume(float acc, const float4 (&q)[kChainRound], int count) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        if (d < count) {
+            acc += q[d].x;
+            acc += q[d].y;
+            acc += q[d].z;
+            acc += q[d].w;
         }
     }
     return acc;
 }
 
-__device__ __forceinline__ void zero_term_padding(float *terms, int K, const KltParams &p, int lane) {
-    const int extra = p.Ppad - p.P;
-    for (int k = 0; k < K; ++k) {
-        if (lane < extra) {
-            terms[k * p.Ppad + p.P + lane] = 0.0f;
+__device__ __forceinline__ float chain_consume_all(float acc, const float4 (&q)[kChainRound]) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        acc += q[d].x;
+        acc += q[d].y;
+        acc += q[d].z;
+        acc += q[d].w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
+
+__device__ __forceinline__ float chain_lane(const float *row, int Ppad) {
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    const int n4 = Ppad >> 2;
+    float4 qa[kChainRound], qb[kChainRound];
+    float acc = 0.0f;
+    int i = 0;
+    chain_load(qa, t);
+    for (; i + 2 * kChainRound <= n4; i += 2 * kChainRound) {
+        chain_load(qb, t + i + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        chain_load(qa, t + i + 2 * kChainRound);
+        acc = chain_consume_all(acc, qb);
+    }
+    chain_load(qb, t + i + kChainRound);
+    const int rem = n4 - i;  // 0 .. 2*kChainRound-1 float4 left, the first kChainRound already in qa
+    acc = chain_consume(acc, qa, rem);
+    acc = chain_consume(acc, qb, rem - kChainRound);
+    return acc;
+}
+
+__device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int K, int Ppad, float *sums, bool leading_barrier = false) {
+    if (leading_barrier) {
+        __syncthreads();  // phase A's terms (and published counts) become visible
+    }
+    if (b.wave == 0 && b.lane < K) {
+        sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
+    }
+    __syncthreads();
+}
+
+// Phase B + C on wave 0 only: after its chain lanes have published the K sums, wave 0 runs
+// `wave0_work` (the small dense solve) and publishes the solution through LDS; one barrier releases
+// the other waves, which were idle during the chain anyway.  Within one wave LDS operations execute
+// in program order, so wave 0 needs no barrier between its own chain stores and solve loads.
+template <typename F>
+__device__ __forceinline__ void chain_then(const Blk &b, const float *terms, int K, int Ppad, float *sums, bool leading_barrier, F &&wave0_work) {
+    if (leading_barrier) {
+        __syncthreads();  // phase A's terms (and published counts) become visible
+    }
+    if (b.wave == 0) {
+        if (b.lane < K) {
+            sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
         }
+        wave0_work();
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void zero_term_padding(const Blk &b, float *terms, int K, const KltParams &p) {
+    const int extra = p.Ppad - p.P;
+    for (int idx = b.tid; idx < K * extra; idx += b.nt) {
+        const int k = idx / (extra > 0 ? extra : 1);
+        terms[k * p.Ppad + p.P + (idx - k * extra)] = 0.0f;
     }
 }
 
@@ -286,55 +513,262 @@ __device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Window management
+// ---------------------------------------------------------------------------------------------
+
+// Top-left corner of the (2h+4)^2 footprint of a patch centred at (u, v): bilinear bases of the
+// patch pixels and of their +-1 neighbours lie in [floor - h - 1, floor + h + 1], plus one for the
+// +1 bilinear neighbour.
+__device__ __forceinline__ void footprint_origin(const KltParams &p, float u, float v, int &r_lo, int &c_lo) {
+    r_lo = wadd(f2i(floorf(v)), -(p.half_rows + 1));
+    c_lo = wadd(f2i(floorf(u)), -(p.half_cols + 1));
+}
+
+// One pixel-pair element of a window: (img[clamp(r)][clamp(c)], img[clamp(r)][clamp(c + 1)]).
+__device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols) {
+    const int r = (int)__umulhi((unsigned)idx, magic_cols);
+    const int c = idx - r * wcols;
+    const int ir = clampi(wadd(r_lo, r), 0, im.rows - 1);
+    const int ic = wadd(c_lo, c);
+    const int ic0 = clampi(ic, 0, im.cols - 1);
+    const int ic1 = clampi(wadd(ic, 1), 0, im.cols - 1);
+    const uint8_t *rowp = im.data + (long long)ir * im.cols;
+    return (uint16_t)((unsigned)rowp[ic0] | ((unsigned)rowp[ic1] << 8));
+}
+
+// Loads up to kStageBatch window elements per thread with every global load in flight before the
+// first LDS store (the loop body is branch-free: out-of-range slots read element 0 and are not stored).
+constexpr int kStageBatch = 4;
+
+__device__ __forceinline__ void stage_elements(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wcols, uint32_t magic_cols,
+                                               int total) {
+    for (int base = 0; base < total; base += b.nt * kStageBatch) {
+        uint16_t v[kStageBatch];
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+            const int idx = base + k * b.nt + b.tid;
+            v[k] = window_element(im, r_lo, c_lo, idx < total ? idx : 0, wcols, magic_cols);
+        }
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+            const int idx = base + k * b.nt + b.tid;
+            if (idx < total) {
+                dst[idx] = v[k];
+            }
+        }
+    }
+}
+
+// Fast staging for windows that lie completely inside the image: thread (row, quad) fetches 8
+// consecutive bytes with one unaligned global_load_dwordx2, forms the four pixel pairs
+// (b0,b1) (b1,b2) (b2,b3) (b3,b4) with v_alignbyte / v_alignbit and stores them with one
+// ds_write_b64 (wcols is a multiple of 4).  ~1/4 of the instructions of the per-element path.
+__device__ __forceinline__ bool window_inside(const DevImage &im, int r_lo, int c_lo, int wrows, int wcols) {
+    return r_lo >= 0 && c_lo >= 0 && (long long)r_lo + wrows <= im.rows && (long long)c_lo + wcols + 4 <= im.cols;
+}
+
+__device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wrows, int wcols,
+                                                  uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    for (int idx = b.tid; idx < total; idx += b.nt) {
+        const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+        const int q = idx - r * quads;
+        const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+        uint32_t x, y;
+        __builtin_memcpy(&x, src, 4);
+        __builtin_memcpy(&y, src + 4, 4);
+        const uint32_t p0 = x & 0xFFFFu;
+        const uint32_t p1 = (x >> 8) & 0xFFFFu;
+        const uint32_t p2 = x >> 16;
+        const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+        *reinterpret_cast<uint2 *>(dst + r * wcols + 4 * q) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+    }
+}
+
+__device__ __forceinline__ void stage_any(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wrows, int wcols,
+                                          uint32_t magic_cols, uint32_t magic_quads) {
+    if (window_inside(im, r_lo, c_lo, wrows, wcols)) {
+        stage_rows_inside(b, im, dst, r_lo, c_lo, wrows, wcols, magic_quads);
+    } else {
+        stage_elements(b, im, dst, r_lo, c_lo, wcols, magic_cols, wrows * wcols);
+    }
+}
+
+// Both level windows inside their images: every thread issues the 8-byte loads of its reference
+// quads AND its current quads before the first LDS store, so the two global round trips overlap.
+__device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, int c_lo, int idx, int quads, uint32_t magic_quads, int &lds_off,
+                                                 int wcols) {
+    const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+    const int q = idx - r * quads;
+    const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+    uint32_t x, y;
+    __builtin_memcpy(&x, src, 4);
+    __builtin_memcpy(&y, src + 4, 4);
+    const uint32_t p0 = x & 0xFFFFu;
+    const uint32_t p1 = (x >> 8) & 0xFFFFu;
+    const uint32_t p2 = x >> 16;
+    const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+    lds_off = r * wcols + 4 * q;
+    return make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+}
+
+__device__ __forceinline__ void stage_both_inside(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, const Win &rw,
+                                                  const Win &cw, Carve &c) {
+    const int rq = rw.cols >> 2, cq = cw.cols >> 2;
+    const int total_r = rw.rows * rq, total_c = cw.rows * cq;  // total_c >= total_r
+    for (int base = 0; base < total_c; base += 2 * b.nt) {
+        const int i0 = base + b.tid, i1 = base + b.nt + b.tid;
+        int or0, or1, oc0, oc1;
+        const uint2 vr0 = load_quad_pairs(ref, rw.r_lo, rw.c_lo, i0 < total_r ? i0 : 0, rq, p.magic_rwq, or0, rw.cols);
+        const uint2 vr1 = load_quad_pairs(ref, rw.r_lo, rw.c_lo, i1 < total_r ? i1 : 0, rq, p.magic_rwq, or1, rw.cols);
+        const uint2 vc0 = load_quad_pairs(cur, cw.r_lo, cw.c_lo, i0 < total_c ? i0 : 0, cq, p.magic_cwq, oc0, cw.cols);
+        const uint2 vc1 = load_quad_pairs(cur, cw.r_lo, cw.c_lo, i1 < total_c ? i1 : 0, cq, p.magic_cwq, oc1, cw.cols);
+        if (i0 < total_r) {
+            *reinterpret_cast<uint2 *>(c.ref_win + or0) = vr0;
+        }
+        if (i1 < total_r) {
+            *reinterpret_cast<uint2 *>(c.ref_win + or1) = vr1;
+        }
+        if (i0 < total_c) {
+            *reinterpret_cast<uint2 *>(c.cur_win + oc0) = vc0;
+        }
+        if (i1 < total_c) {
+            *reinterpret_cast<uint2 *>(c.cur_win + oc1) = vc1;
+        }
+    }
+}
+
+// Level entry: stages the reference footprint of (ref_u, ref_v) and the current footprint (+ margin)
+// of (cur_u, cur_v) back to back with a single barrier, so the global round trips overlap.
+__device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                    float ref_v, float cur_u, float cur_v, Carve &c, Win &rw, Win &cw) {
+    footprint_origin(p, ref_u, ref_v, rw.r_lo, rw.c_lo);
+    rw.rows = p.rwin_rows;
+    rw.cols = p.rwin_cols;
+    rw.data = c.ref_win;
+    int need_r, need_c;
+    footprint_origin(p, cur_u, cur_v, need_r, need_c);
+    cw.r_lo = wadd(need_r, -p.cwin_margin);
+    cw.c_lo = wadd(need_c, -p.cwin_margin);
+    cw.rows = p.cwin_rows;
+    cw.cols = p.cwin_cols;
+    cw.data = c.cur_win;
+    if (window_inside(ref, rw.r_lo, rw.c_lo, rw.rows, rw.cols) && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols)) {
+        stage_both_inside(b, p, ref, cur, rw, cw, c);
+    } else {
+        stage_any(b, ref, c.ref_win, rw.r_lo, rw.c_lo, rw.rows, rw.cols, p.magic_rwc, p.magic_rwq);
+        stage_any(b, cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
+    }
+    __syncthreads();
+}
+
+// Makes sure the current-image window covers the footprint of a patch centred at (u, v); restages
+// it (with cwin_margin pixels of slack on every side) when it does not.  Wave-uniform decision.
+__device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams &p, const DevImage &cur, float u, float v, Carve &c, Win &w,
+                                                  bool &staged) {
+    int need_r, need_c;
+    footprint_origin(p, u, v, need_r, need_c);
+    const long long nr = need_r, nc = need_c;
+    const bool covered = staged && nr >= (long long)w.r_lo && nr + (2 * p.half_rows + 4) <= (long long)w.r_lo + w.rows &&
+                         nc >= (long long)w.c_lo && nc + (2 * p.half_cols + 4) <= (long long)w.c_lo + w.cols + 1;
+    if (!covered) {
+        w.r_lo = wadd(need_r, -p.cwin_margin);
+        w.c_lo = wadd(need_c, -p.cwin_margin);
+        w.rows = p.cwin_rows;
+        w.cols = p.cwin_cols;
+        w.data = c.cur_win;
+        stage_any(b, cur, c.cur_win, w.r_lo, w.c_lo, w.rows, w.cols, p.magic_cwc, p.magic_cwq);
+        __syncthreads();
+        staged = true;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Shared pieces of the non-fast variants (inverse / direct)
-//   a0 = gx (right - left), a1 = gy (bottom - top), a2 = i_ref, flagsP = ref-side validity.
+//   a1 = gx (right - left), a2 = gy (bottom - top), a3 = i_ref, flagsP = ref-side validity.
 // For METHOD == inverse the five reference-image fetches of a pixel do not change within a
 // level, so they are sampled once per level; the arithmetic per pixel is unchanged.
 // ---------------------------------------------------------------------------------------------
 template <int METHOD>
-__device__ __forceinline__ void nonfast_level_setup(const KltParams &p, const DevImage &ref, float ref_u, float ref_v, Carve &c, int lane) {
-    for (int base = 0; base < p.P; base += kWave) {
-        const int pxi = base + lane;
-        if (pxi < p.P) {
-            int prow, pcol;
-            pixel_rc(p, pxi, prow, pcol);
-            const float row_i = (float)(prow - p.half_rows) + ref_v;
-            const float col_i = (float)(pcol - p.half_cols) + ref_u;
-            float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f, i_ref = 0.0f;
-            bool ok;
-            if (METHOD == FTK_METHOD_INVERSE) {
-                ok = sample(ref, row_i, col_i - 1.0f, left) && sample(ref, row_i, col_i + 1.0f, right) && sample(ref, row_i - 1.0f, col_i, top) &&
-                     sample(ref, row_i + 1.0f, col_i, bottom) && sample(ref, row_i, col_i, i_ref);
-                c.a0[pxi] = right - left;
-                c.a1[pxi] = bottom - top;
-            } else {
-                ok = sample(ref, row_i, col_i, i_ref);
+__device__ __forceinline__ void nonfast_level_setup(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
+                                                    Carve &c) {
+#pragma unroll 2
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        const float row_i = (float)(prow - p.half_rows) + ref_v;
+        const float col_i = (float)(pcol - p.half_cols) + ref_u;
+        const Axis r0 = make_axis(row_i, ref.rows - 1), c0 = make_axis(col_i, ref.cols - 1);
+        float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f, i_ref;
+        bool ok, hit = true;
+        if (METHOD == FTK_METHOD_INVERSE) {
+            const Axis rm = make_axis(row_i - 1.0f, ref.rows - 1), rp = make_axis(row_i + 1.0f, ref.rows - 1);
+            const Axis cm = make_axis(col_i - 1.0f, ref.cols - 1), cp = make_axis(col_i + 1.0f, ref.cols - 1);
+            ok = r0.valid && c0.valid && rm.valid && rp.valid && cm.valid && cp.valid;
+            left = tap(rw, r0, cm, hit);
+            right = tap(rw, r0, cp, hit);
+            top = tap(rw, rm, c0, hit);
+            bottom = tap(rw, rp, c0, hit);
+            i_ref = tap(rw, r0, c0, hit);
+            if (ok && !hit) {  // a tap fell outside the staged window: same samples through the general path
+                sample(ref, rw, row_i, col_i - 1.0f, left);
+                sample(ref, rw, row_i, col_i + 1.0f, right);
+                sample(ref, rw, row_i - 1.0f, col_i, top);
+                sample(ref, rw, row_i + 1.0f, col_i, bottom);
+                sample(ref, rw, row_i, col_i, i_ref);
             }
-            c.a2[pxi] = i_ref;
-            c.flagsP[pxi] = ok ? 1 : 0;
+            c.a1[pxi] = right - left;
+            c.a2[pxi] = bottom - top;
+        } else {
+            ok = r0.valid && c0.valid;
+            i_ref = tap(rw, r0, c0, hit);
+            if (ok && !hit) {
+                sample(ref, rw, row_i, col_i, i_ref);
+            }
         }
+        c.a3[pxi] = i_ref;
+        c.flagsP[pxi] = ok ? 1 : 0;
     }
     __syncthreads();
 }
 
 // Completes the six fetches of one patch pixel for the current iteration.
 template <int METHOD>
-__device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Carve &c, int pxi, float row_j, float col_j, float &gx, float &gy,
-                                               float &i_ref, float &i_cur) {
+__device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &cw, const Carve &c, int pxi, float row_j, float col_j, float &gx,
+                                               float &gy, float &i_ref, float &i_cur) {
     bool ok = c.flagsP[pxi] != 0;
-    i_ref = c.a2[pxi];
-    i_cur = 0.0f;
+    i_ref = c.a3[pxi];
+    const Axis r0 = make_axis(row_j, cur.rows - 1), c0 = make_axis(col_j, cur.cols - 1);
+    bool hit = true;
     if (METHOD == FTK_METHOD_INVERSE) {
-        gx = c.a0[pxi];
-        gy = c.a1[pxi];
-        ok = ok && sample(cur, row_j, col_j, i_cur);
+        gx = c.a1[pxi];
+        gy = c.a2[pxi];
+        const bool valid = r0.valid && c0.valid;
+        i_cur = tap(cw, r0, c0, hit);
+        if (valid && !hit) {
+            sample(cur, cw, row_j, col_j, i_cur);
+        }
+        ok = ok && valid;
     } else {
-        float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f;
-        const bool g = sample(cur, row_j, col_j - 1.0f, left) && sample(cur, row_j, col_j + 1.0f, right) && sample(cur, row_j - 1.0f, col_j, top) &&
-                       sample(cur, row_j + 1.0f, col_j, bottom) && sample(cur, row_j, col_j, i_cur);
+        const Axis rm = make_axis(row_j - 1.0f, cur.rows - 1), rp = make_axis(row_j + 1.0f, cur.rows - 1);
+        const Axis cm = make_axis(col_j - 1.0f, cur.cols - 1), cp = make_axis(col_j + 1.0f, cur.cols - 1);
+        const bool valid = r0.valid && c0.valid && rm.valid && rp.valid && cm.valid && cp.valid;
+        float left = tap(cw, r0, cm, hit);
+        float right = tap(cw, r0, cp, hit);
+        float top = tap(cw, rm, c0, hit);
+        float bottom = tap(cw, rp, c0, hit);
+        i_cur = tap(cw, r0, c0, hit);
+        if (valid && !hit) {
+            sample(cur, cw, row_j, col_j - 1.0f, left);
+            sample(cur, cw, row_j, col_j + 1.0f, right);
+            sample(cur, cw, row_j - 1.0f, col_j, top);
+            sample(cur, cw, row_j + 1.0f, col_j, bottom);
+            sample(cur, cw, row_j, col_j, i_cur);
+        }
         gx = right - left;
         gy = bottom - top;
-        ok = ok && g;
+        ok = ok && valid;
     }
     return ok;
 }
@@ -345,8 +779,10 @@ __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Carve 
 // ---------------------------------------------------------------------------------------------
 
 // OpticalFlow::ExtractExtendPatchInReferenceImage (optical_flow.cpp:49-102); returns the valid count.
-__device__ __forceinline__ uint32_t extract_extended_patch(const KltParams &p, const DevImage &ref, float ref_u, float ref_v, float *ex,
-                                                           uint8_t *exv, int lane) {
+__device__ __forceinline__ uint32_t extract_extended_patch(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u,
+                                                           float ref_v, Carve &c) {
+    float *ex = c.a0;
+    uint8_t *exv = c.flagsE;
     const float int_row = floorf(ref_v);
     const float int_col = floorf(ref_u);
     const float dec_row = ref_v - int_row;
@@ -358,8 +794,8 @@ __device__ __forceinline__ uint32_t extract_extended_patch(const KltParams &p, c
     const int min_row = wadd(f2i(int_row), -(p.ex_rows / 2));
     const int min_col = wadd(f2i(int_col), -(p.ex_cols / 2));
     uint32_t count = 0;
-    for (int base = 0; base < p.E; base += kWave) {
-        const int e = base + lane;
+    for (int base = 0; base < p.E; base += b.nt) {
+        const int e = base + b.tid;
         bool valid = false;
         if (e < p.E) {
             const int erow = (int)__umulhi((unsigned)e, p.magic_exc);
@@ -369,15 +805,16 @@ __device__ __forceinline__ uint32_t extract_extended_patch(const KltParams &p, c
             valid = !(row < 0 || row > ref.rows - 2 || col < 0 || col > ref.cols - 2);
             float value = 0.0f;
             if (valid) {
-                value = w_tl * px(ref, row, col) + w_tr * px(ref, row, col + 1) + w_bl * px(ref, row + 1, col) + w_br * px(ref, row + 1, col + 1);
+                float p00, p01, p10, p11;
+                fetch4(ref, rw, row, col, p00, p01, p10, p11);
+                value = w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
             }
             ex[e] = value;
             exv[e] = valid ? 1 : 0;
         }
         count += (uint32_t)__popcll(__ballot(valid));
     }
-    __syncthreads();
-    return count;
+    return block_total(b, count, c.wave_cnt);
 }
 
 // Central differences on the extended patch: dx = dy = 0 where a 4-neighbour is invalid
@@ -424,14 +861,23 @@ struct BasicState {
 
 // TrackOneFeature, basic_klt.cpp:88-181.  Terms: 0 H00, 1 H11, 2 H01, 3 -fx*ft, 4 -fy*ft.
 template <int METHOD>
-__device__ __forceinline__ void basic_level(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v, BasicState &s,
-                                            uint8_t &status, uint32_t &iters, Carve &c, int lane) {
-    nonfast_level_setup<METHOD>(p, ref, ref_u, ref_v, c, lane);
+__device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
+                                            BasicState &s, uint8_t &status, uint32_t &iters, Carve &c) {
+    FTK_STAMP_BEGIN(b);
+    Win rw, cw;
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    bool cw_staged = true;
+    FTK_STAMP_END(b, 0);
+    nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
+    FTK_STAMP_END(b, 1);
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        FTK_STAMP_BEGIN(b);
+        ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
+        FTK_STAMP_END(b, 2);
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -439,7 +885,7 @@ __device__ __forceinline__ void basic_level(const KltParams &p, const DevImage &
                 const float row_j = (float)(prow - p.half_rows) + s.cur_v;
                 const float col_j = (float)(pcol - p.half_cols) + s.cur_u;
                 float fx, fy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, c, pxi, row_j, col_j, fx, fy, i_ref, i_cur);
+                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, fx, fy, i_ref, i_cur);
                 const float ft = i_cur - i_ref;
                 c.terms[0 * p.Ppad + pxi] = ok ? fx * fx : 0.0f;
                 c.terms[1 * p.Ppad + pxi] = ok ? fy * fy : 0.0f;
@@ -449,26 +895,34 @@ __device__ __forceinline__ void basic_level(const KltParams &p, const DevImage &
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        FTK_STAMP_END(b, 3);
+        publish_count(b, n_valid, c.wave_cnt, iter);
+        FTK_STAMP_END(b, 4);
+        chain_then(b, c.terms, 5, p.Ppad, c.sums, true, [&]() {
+            float m[2][2];
+            float bb[2], sol[2];
+            m[0][0] = c.sums[0];
+            m[1][1] = c.sums[1];
+            m[0][1] = m[1][0] = c.sums[2];
+            bb[0] = c.sums[3];
+            bb[1] = c.sums[4];
+            ldlt_solve<2>(m, bb, sol);
+            c.sums[16] = sol[0];
+            c.sums[17] = sol[1];
+        });
+        FTK_STAMP_END(b, 5);
+        n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, 5, p.Ppad, lane);
-        __syncthreads();
-        float m[2][2];
-        float b[2], v[2];
-        m[0][0] = bcast(acc, 0);
-        m[1][1] = bcast(acc, 1);
-        m[0][1] = m[1][0] = bcast(acc, 2);
-        b[0] = bcast(acc, 3);
-        b[1] = bcast(acc, 4);
-        ldlt_solve<2>(m, b, v);
+        const float v[2] = {c.sums[16], c.sums[17]};
         if (isnan(v[0]) || isnan(v[1])) {
             status = FTK_NUMERIC_ERROR;
             break;
         }
         s.cur_u += v[0];
         s.cur_v += v[1];
+        FTK_STAMP_END(b, 6);
         if (uv_outside(s.cur_u, s.cur_v, cur)) {
             status = FTK_OUTSIDE;
             break;
@@ -481,39 +935,39 @@ __device__ __forceinline__ void basic_level(const KltParams &p, const DevImage &
 }
 
 // TrackOneFeatureFast, basic_klt_fast.cpp:7-195.
-__device__ __forceinline__ void basic_level_fast(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
-                                                 BasicState &s, uint8_t &status, uint32_t &iters, Carve &c, int lane) {
+__device__ __forceinline__ void basic_level_fast(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                 float ref_v, BasicState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     float *ex = c.a0, *dxs = c.a1, *dys = c.a2;
     uint8_t *exv = c.flagsE;
-    if (extract_extended_patch(p, ref, ref_u, ref_v, ex, exv, lane) == 0) {
+    Win rw, cw;
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    bool cw_staged = true;
+    if (extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c) == 0) {
         status = FTK_OUTSIDE;
         return;
     }
     // dx, dy and the fixed Hessian: terms 0 dx*dx, 1 dx*dy, 2 dy*dy
-    for (int base = 0; base < p.P; base += kWave) {
-        const int pxi = base + lane;
-        if (pxi < p.P) {
-            int prow, pcol;
-            pixel_rc(p, pxi, prow, pcol);
-            float dx, dy;
-            ex_gradient(p, ex, exv, prow, pcol, dx, dy);
-            dxs[pxi] = dx;
-            dys[pxi] = dy;
-            c.terms[0 * p.Ppad + pxi] = dx * dx;
-            c.terms[1 * p.Ppad + pxi] = dx * dy;
-            c.terms[2 * p.Ppad + pxi] = dy * dy;
-        }
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        float dx, dy;
+        ex_gradient(p, ex, exv, prow, pcol, dx, dy);
+        dxs[pxi] = dx;
+        dys[pxi] = dy;
+        c.terms[0 * p.Ppad + pxi] = dx * dx;
+        c.terms[1 * p.Ppad + pxi] = dx * dy;
+        c.terms[2 * p.Ppad + pxi] = dy * dy;
     }
     __syncthreads();
-    const float hacc = chain_sum(c.terms, 3, p.Ppad, lane);
-    __syncthreads();
-    const float h00 = bcast(hacc, 0), h01 = bcast(hacc, 1), h11 = bcast(hacc, 2);
+    chain_sums(b, c.terms, 3, p.Ppad, c.sums);
+    const float h00 = c.sums[0], h01 = c.sums[1], h11 = c.sums[2];
 
     status = FTK_LARGE_RESIDUAL;
     float last_squared_step = INFINITY;
     uint32_t large_step_cnt = 0;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
         // ComputeBias (:101-195): one weight set from frac(cur), integer lattice floor(cur) - patch/2
         const float int_row = floorf(s.cur_v);
         const float int_col = floorf(s.cur_u);
@@ -526,8 +980,8 @@ __device__ __forceinline__ void basic_level_fast(const KltParams &p, const DevIm
         const int min_row = wadd(f2i(int_row), -(p.patch_rows / 2));
         const int min_col = wadd(f2i(int_col), -(p.patch_cols / 2));
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -538,8 +992,9 @@ __device__ __forceinline__ void basic_level_fast(const KltParams &p, const DevIm
                 ok = !(row < 0 || row > cur.rows - 2 || col < 0 || col > cur.cols - 2) && exv[ei] != 0;
                 float t0 = 0.0f, t1 = 0.0f;
                 if (ok) {
-                    const float i_cur =
-                        w_tl * px(cur, row, col) + w_tr * px(cur, row, col + 1) + w_bl * px(cur, row + 1, col) + w_br * px(cur, row + 1, col + 1);
+                    float p00, p01, p10, p11;
+                    fetch4(cur, cw, row, col, p00, p01, p10, p11);
+                    const float i_cur = w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
                     const float dt = i_cur - ex[ei];
                     t0 = -(dxs[pxi] * dt);
                     t1 = -(dys[pxi] * dt);
@@ -549,16 +1004,20 @@ __device__ __forceinline__ void basic_level_fast(const KltParams &p, const DevIm
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        publish_count(b, n_valid, c.wave_cnt, iter);
+        chain_then(b, c.terms, 2, p.Ppad, c.sums, true, [&]() {
+            float m[2][2] = {{h00, h01}, {h01, h11}};
+            float bb[2] = {c.sums[0], c.sums[1]};
+            float sol[2];
+            ldlt_solve<2>(m, bb, sol);
+            c.sums[16] = sol[0];
+            c.sums[17] = sol[1];
+        });
+        n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, 2, p.Ppad, lane);
-        __syncthreads();
-        float m[2][2] = {{h00, h01}, {h01, h11}};
-        float b[2] = {bcast(acc, 0), bcast(acc, 1)};
-        float v[2];
-        ldlt_solve<2>(m, b, v);
+        const float v[2] = {c.sums[16], c.sums[17]};
         if (isnan(v[0]) || isnan(v[1])) {
             status = FTK_NUMERIC_ERROR;
             break;
@@ -621,12 +1080,12 @@ __device__ __forceinline__ void affine_bias_terms(const KltParams &p, float *ter
     terms[(first_bias_chain + 5) * p.Ppad + pxi] = ok ? -(dt * dy) : 0.0f;
 }
 
-__device__ __forceinline__ void affine_fill_matrix(float acc, float (&m)[6][6]) {
-    const float h00 = bcast(acc, A_XX_DXDX), h01 = bcast(acc, A_XX_DXDY), h02 = bcast(acc, A_XY_DXDX), h03 = bcast(acc, A_XY_DXDY);
-    const float h04 = bcast(acc, A_X_DXDX), h05 = bcast(acc, A_X_DXDY), h11 = bcast(acc, A_XX_DYDY), h13 = bcast(acc, A_XY_DYDY);
-    const float h15 = bcast(acc, A_X_DYDY), h22 = bcast(acc, A_YY_DXDX), h23 = bcast(acc, A_YY_DXDY), h24 = bcast(acc, A_Y_DXDX);
-    const float h25 = bcast(acc, A_Y_DXDY), h33 = bcast(acc, A_YY_DYDY), h35 = bcast(acc, A_Y_DYDY), h44 = bcast(acc, A_DXDX);
-    const float h45 = bcast(acc, A_DXDY), h55 = bcast(acc, A_DYDY);
+__device__ __forceinline__ void affine_fill_matrix(const float *sums, float (&m)[6][6]) {
+    const float h00 = sums[A_XX_DXDX], h01 = sums[A_XX_DXDY], h02 = sums[A_XY_DXDX], h03 = sums[A_XY_DXDY];
+    const float h04 = sums[A_X_DXDX], h05 = sums[A_X_DXDY], h11 = sums[A_XX_DYDY], h13 = sums[A_XY_DYDY];
+    const float h15 = sums[A_X_DYDY], h22 = sums[A_YY_DXDX], h23 = sums[A_YY_DXDY], h24 = sums[A_Y_DXDX];
+    const float h25 = sums[A_Y_DXDY], h33 = sums[A_YY_DYDY], h35 = sums[A_Y_DYDY], h44 = sums[A_DXDX];
+    const float h45 = sums[A_DXDY], h55 = sums[A_DYDY];
     const float h12 = h03, h14 = h05, h34 = h23;
     const float u[6][6] = {{h00, h01, h02, h03, h04, h05}, {h01, h11, h12, h13, h14, h15}, {h02, h12, h22, h23, h24, h25},
                            {h03, h13, h23, h33, h34, h35}, {h04, h14, h24, h34, h44, h45}, {h05, h15, h25, h35, h45, h55}};
@@ -650,14 +1109,18 @@ __device__ __forceinline__ void affine_apply_step(AffineState &s, const float (&
 
 // TrackOneFeature, affine_klt.cpp:93-273.
 template <int METHOD>
-__device__ __forceinline__ void affine_level(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
-                                             AffineState &s, uint8_t &status, uint32_t &iters, Carve &c, int lane) {
-    nonfast_level_setup<METHOD>(p, ref, ref_u, ref_v, c, lane);
+__device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
+                                             AffineState &s, uint8_t &status, uint32_t &iters, Carve &c) {
+    Win rw, cw;
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    bool cw_staged = true;
+    nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -669,24 +1132,30 @@ __device__ __forceinline__ void affine_level(const KltParams &p, const DevImage 
                 const float row_j = warped_y + s.cur_v;
                 const float col_j = warped_x + s.cur_u;
                 float dx, dy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur);
+                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur);
                 const float dt = i_cur - i_ref;
                 affine_hessian_terms(p, c.terms, pxi, ok, col_j, row_j, dx, dy);
                 affine_bias_terms(p, c.terms, A_B0, pxi, ok, dt, col_j, row_j, dx, dy);
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        publish_count(b, n_valid, c.wave_cnt, iter);
+        chain_then(b, c.terms, A_COUNT, p.Ppad, c.sums, true, [&]() {
+            float m[6][6];
+            affine_fill_matrix(c.sums, m);
+            const float bb[6] = {c.sums[A_B0], c.sums[A_B1], c.sums[A_B2], c.sums[A_B3], c.sums[A_B4], c.sums[A_B5]};
+            float sol[6];
+            ldlt_solve<6>(m, bb, sol);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c.sums[A_COUNT + i] = sol[i];
+            }
+        });
+        n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, A_COUNT, p.Ppad, lane);
-        __syncthreads();
-        float m[6][6];
-        affine_fill_matrix(acc, m);
-        const float b[6] = {bcast(acc, A_B0), bcast(acc, A_B1), bcast(acc, A_B2), bcast(acc, A_B3), bcast(acc, A_B4), bcast(acc, A_B5)};
-        float z[6];
-        ldlt_solve<6>(m, b, z);
+        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         float v[2];
         v[0] = (z[0] * s.cur_u + z[2] * s.cur_v) + z[4];
         v[1] = (z[1] * s.cur_u + z[3] * s.cur_v) + z[5];
@@ -707,43 +1176,51 @@ __device__ __forceinline__ void affine_level(const KltParams &p, const DevImage 
 }
 
 // TrackOneFeatureFast, affine_klt_fast.cpp:7-188.
-__device__ __forceinline__ void affine_level_fast(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
-                                                  AffineState &s, uint8_t &status, uint32_t &iters, Carve &c, int lane) {
+__device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                  float ref_v, AffineState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     float *ex = c.a0, *dxs = c.a1, *dys = c.a2;
     uint8_t *exv = c.flagsE;
-    if (extract_extended_patch(p, ref, ref_u, ref_v, ex, exv, lane) == 0) {
+    Win rw, cw;
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    bool cw_staged = true;
+    if (extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c) == 0) {
         status = FTK_OUTSIDE;
         return;
     }
     // H once per level, anchored at cur_uv on level entry (:95-96)
-    for (int base = 0; base < p.P; base += kWave) {
-        const int pxi = base + lane;
-        if (pxi < p.P) {
-            int prow, pcol;
-            pixel_rc(p, pxi, prow, pcol);
-            float dx, dy;
-            const bool has_gradient = ex_gradient(p, ex, exv, prow, pcol, dx, dy);
-            dxs[pxi] = dx;
-            dys[pxi] = dy;
-            const float x = (float)(pcol - p.half_cols) + s.cur_u;
-            const float y = (float)(prow - p.half_rows) + s.cur_v;
-            affine_hessian_terms(p, c.terms, pxi, has_gradient, x, y, dx, dy);
-        }
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        float dx, dy;
+        const bool has_gradient = ex_gradient(p, ex, exv, prow, pcol, dx, dy);
+        dxs[pxi] = dx;
+        dys[pxi] = dy;
+        const float x = (float)(pcol - p.half_cols) + s.cur_u;
+        const float y = (float)(prow - p.half_rows) + s.cur_v;
+        affine_hessian_terms(p, c.terms, pxi, has_gradient, x, y, dx, dy);
     }
     __syncthreads();
-    const float hacc = chain_sum(c.terms, A_B0, p.Ppad, lane);
-    __syncthreads();
-    float h[6][6];
-    affine_fill_matrix(hacc, h);
+    chain_then(b, c.terms, A_B0, p.Ppad, c.sums, false, [&]() {
+        float h[6][6];
+        affine_fill_matrix(c.sums, h);  // the per-level Hessian lives in LDS (sums[32..67]) for the iterations below
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                c.sums[32 + i * 6 + j] = h[i][j];
+            }
+        }
+    });
 
     status = FTK_LARGE_RESIDUAL;
     float last_squared_step = INFINITY;
     uint32_t large_step_cnt = 0;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -756,29 +1233,35 @@ __device__ __forceinline__ void affine_level_fast(const KltParams &p, const DevI
                 const float col_c = warped_x + s.cur_u;
                 float i_cur = 0.0f;
                 const int ei = (prow + 1) * p.ex_cols + pcol + 1;
-                ok = sample(cur, row_c, col_c, i_cur) && exv[ei] != 0;
+                ok = sample(cur, cw, row_c, col_c, i_cur) && exv[ei] != 0;
                 const float dt = i_cur - ex[ei];
                 affine_bias_terms(p, c.terms, 0, pxi, ok, dt, col_c, row_c, dxs[pxi], dys[pxi]);
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        publish_count(b, n_valid, c.wave_cnt, iter);
+        chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() {
+            float m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    m[i][j] = c.sums[32 + i * 6 + j];
+                }
+            }
+            const float bb[6] = {c.sums[0], c.sums[1], c.sums[2], c.sums[3], c.sums[4], c.sums[5]};
+            float sol[6];
+            ldlt_solve<6>(m, bb, sol);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c.sums[A_COUNT + i] = sol[i];
+            }
+        });
+        n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, 6, p.Ppad, lane);
-        __syncthreads();
-        float m[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                m[i][j] = h[i][j];
-            }
-        }
-        const float b[6] = {bcast(acc, 0), bcast(acc, 1), bcast(acc, 2), bcast(acc, 3), bcast(acc, 4), bcast(acc, 5)};
-        float z[6];
-        ldlt_solve<6>(m, b, z);
+        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         if (isnan(z[0]) || isnan(z[1]) || isnan(z[2]) || isnan(z[3]) || isnan(z[4]) || isnan(z[5])) {
             status = FTK_NUMERIC_ERROR;
             break;
@@ -838,13 +1321,24 @@ __device__ __forceinline__ void lssd_terms(const KltParams &p, float *terms, int
     terms[8 * p.Ppad + pxi] = ok ? -(j2 * residual) : 0.0f;
 }
 
-// Solves the 3x3 system from the nine chain sums and applies the SE(2) update.
-// Returns false (after setting status) on NaN.
-__device__ __forceinline__ bool lssd_solve_and_update(float acc, LssdState &s, float (&v)[3], uint8_t &status) {
-    const float h00 = bcast(acc, 0), h01 = bcast(acc, 1), h02 = bcast(acc, 2), h11 = bcast(acc, 3), h12 = bcast(acc, 4), h22 = bcast(acc, 5);
+// Wave 0: solves the 3x3 system from the nine chain sums and publishes v in sums[16..18].
+__device__ __forceinline__ void lssd_solve(float *sums) {
+    const float h00 = sums[0], h01 = sums[1], h02 = sums[2], h11 = sums[3], h12 = sums[4], h22 = sums[5];
     float m[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, h22}};
-    const float b[3] = {bcast(acc, 6), bcast(acc, 7), bcast(acc, 8)};
-    ldlt_solve<3>(m, b, v);
+    const float bb[3] = {sums[6], sums[7], sums[8]};
+    float sol[3];
+    ldlt_solve<3>(m, bb, sol);
+    sums[16] = sol[0];
+    sums[17] = sol[1];
+    sums[18] = sol[2];
+}
+
+// Every lane: picks up the published solution and applies the SE(2) update.
+// Returns false (after setting status) on NaN.
+__device__ __forceinline__ bool lssd_solve_and_update(const float *sums, LssdState &s, float (&v)[3], uint8_t &status) {
+    v[0] = sums[16];
+    v[1] = sums[17];
+    v[2] = sums[18];
     if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
         status = FTK_NUMERIC_ERROR;
         return false;
@@ -853,18 +1347,27 @@ __device__ __forceinline__ bool lssd_solve_and_update(float acc, LssdState &s, f
     return true;
 }
 
-// TrackOneFeature, lssd_klt.cpp:96-250.  a3 = i_cur of the current iteration.
+// TrackOneFeature, lssd_klt.cpp:96-250.  a0 = i_cur of the current iteration.
 template <int METHOD>
-__device__ __forceinline__ void lssd_level(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v, LssdState &s,
-                                           uint8_t &status, uint32_t &iters, Carve &c, int lane) {
-    nonfast_level_setup<METHOD>(p, ref, ref_u, ref_v, c, lane);
+__device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
+                                           LssdState &s, uint8_t &status, uint32_t &iters, Carve &c) {
+    Win rw, cw;
+    float level_centre_u, level_centre_v;
+    se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
+    bool cw_staged = true;
+    nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
     uint8_t *okflags = c.flagsE;  // per-iteration validity of a pixel (all six fetches)
+    float *icur = c.a0;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        float centre_u, centre_v;
+        se2_apply(s, ref_u, ref_v, centre_u, centre_v);
+        ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
         // pass 1 (:140-184): validity mask and the two patch means (sequential sums)
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -874,53 +1377,51 @@ __device__ __forceinline__ void lssd_level(const KltParams &p, const DevImage &r
                 float row_j, col_j;
                 se2_apply(s, col_i, row_i, col_j, row_j);
                 float gx, gy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, c, pxi, row_j, col_j, gx, gy, i_ref, i_cur);
+                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, gx, gy, i_ref, i_cur);
                 if (METHOD != FTK_METHOD_INVERSE) {
-                    c.a0[pxi] = gx;
-                    c.a1[pxi] = gy;
+                    c.a1[pxi] = gx;
+                    c.a2[pxi] = gy;
                 }
-                c.a3[pxi] = i_cur;
+                icur[pxi] = i_cur;
                 okflags[pxi] = ok ? 1 : 0;
                 c.terms[0 * p.Ppad + pxi] = ok ? i_ref : 0.0f;
                 c.terms[1 * p.Ppad + pxi] = ok ? i_cur : 0.0f;
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
-        const float macc = chain_sum(c.terms, 2, p.Ppad, lane);
-        __syncthreads();
-        const float ref_average = bcast(macc, 0) / (float)n_valid;
-        const float cur_average = bcast(macc, 1) / (float)n_valid;
+        n_valid = block_total(b, n_valid, c.wave_cnt);
+        chain_sums(b, c.terms, 2, p.Ppad, c.sums);
+        const float ref_average = c.sums[0] / (float)n_valid;
+        const float cur_average = c.sums[1] / (float)n_valid;
         const float grad_average = (METHOD == FTK_METHOD_INVERSE) ? ref_average : cur_average;
+        __syncthreads();  // sums[] is rewritten by the second chain below
 
         // pass 2 (:186-247): mean-normalised Jacobian and residual
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
-            if (pxi < p.P) {
-                int prow, pcol;
-                pixel_rc(p, pxi, prow, pcol);
-                const float row_i = (float)(prow - p.half_rows) + ref_v;
-                const float col_i = (float)(pcol - p.half_cols) + ref_u;
-                const bool ok = okflags[pxi] != 0;
-                const float jp0 = c.a0[pxi] / grad_average;
-                const float jp1 = c.a1[pxi] / grad_average;
-                const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
-                const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
-                const float j0 = jp0 * s0 + jp1 * s1;
-                const float j1 = jp0 * 1.0f + jp1 * 0.0f;
-                const float j2 = jp0 * 0.0f + jp1 * 1.0f;
-                const float residual = c.a3[pxi] / cur_average - c.a2[pxi] / ref_average;
-                lssd_terms(p, c.terms, pxi, ok, j0, j1, j2, residual);
-            }
+        for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+            int prow, pcol;
+            pixel_rc(p, pxi, prow, pcol);
+            const float row_i = (float)(prow - p.half_rows) + ref_v;
+            const float col_i = (float)(pcol - p.half_cols) + ref_u;
+            const bool ok = okflags[pxi] != 0;
+            const float jp0 = c.a1[pxi] / grad_average;
+            const float jp1 = c.a2[pxi] / grad_average;
+            const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
+            const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
+            const float j0 = jp0 * s0 + jp1 * s1;
+            const float j1 = jp0 * 1.0f + jp1 * 0.0f;
+            const float j2 = jp0 * 0.0f + jp1 * 1.0f;
+            const float residual = icur[pxi] / cur_average - c.a3[pxi] / ref_average;
+            lssd_terms(p, c.terms, pxi, ok, j0, j1, j2, residual);
         }
         __syncthreads();
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, 9, p.Ppad, lane);
-        __syncthreads();
+        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
         float v[3];
-        if (!lssd_solve_and_update(acc, s, v, status)) {
+        const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+        __syncthreads();  // sums[] is rewritten by the first chain of the next iteration
+        if (!solved) {
             break;
         }
         if (vec3_squared_norm(v) < p.converge) {
@@ -931,39 +1432,40 @@ __device__ __forceinline__ void lssd_level(const KltParams &p, const DevImage &r
 }
 
 // TrackOneFeatureFast, lssd_klt_fast.cpp:7-229.  a3 = current patch, flagsP = its validity.
-__device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
-                                                LssdState &s, uint8_t &status, uint32_t &iters, Carve &c, int lane) {
+__device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                float ref_v, LssdState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     float *ex = c.a0, *dxs = c.a1, *dys = c.a2, *curp = c.a3;
     uint8_t *exv = c.flagsE, *curv = c.flagsP;
-    const uint32_t ref_valid_num = extract_extended_patch(p, ref, ref_u, ref_v, ex, exv, lane);
+    Win rw, cw;
+    float level_centre_u, level_centre_v;
+    se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
+    bool cw_staged = true;
+    const uint32_t ref_valid_num = extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c);
     if (ref_valid_num == 0) {
         status = FTK_OUTSIDE;
         return;
     }
-    for (int base = 0; base < p.P; base += kWave) {
-        const int pxi = base + lane;
-        if (pxi < p.P) {
-            int prow, pcol;
-            pixel_rc(p, pxi, prow, pcol);
-            float dx, dy;
-            ex_gradient(p, ex, exv, prow, pcol, dx, dy);
-            dxs[pxi] = dx;
-            dys[pxi] = dy;
-            // interior of the extended patch in row-major order == the P patch pixels
-            c.terms[pxi] = ex[(prow + 1) * p.ex_cols + pcol + 1];
-        }
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        float dx, dy;
+        ex_gradient(p, ex, exv, prow, pcol, dx, dy);
+        dxs[pxi] = dx;
+        dys[pxi] = dy;
+        // interior of the extended patch in row-major order == the P patch pixels
+        c.terms[pxi] = ex[(prow + 1) * p.ex_cols + pcol + 1];
     }
     __syncthreads();
     if (p.consider_luminance) {
         // :27-46 — numerator: interior of the extended patch; denominator: valid count of the WHOLE extended patch
-        const float racc = chain_sum(c.terms, 1, p.Ppad, lane);
-        __syncthreads();
-        const float ref_average = bcast(racc, 0) / (float)ref_valid_num;
-        for (int i = lane; i < p.P; i += kWave) {
+        chain_sums(b, c.terms, 1, p.Ppad, c.sums);
+        const float ref_average = c.sums[0] / (float)ref_valid_num;
+        for (int i = b.tid; i < p.P; i += b.nt) {
             dxs[i] /= ref_average;
             dys[i] /= ref_average;
         }
-        for (int i = lane; i < p.E; i += kWave) {
+        for (int i = b.tid; i < p.E; i += b.nt) {
             ex[i] /= ref_average;
         }
         __syncthreads();
@@ -977,14 +1479,15 @@ __device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevIma
         // ExtractPatchInCurrentImage (:145-195)
         float centre_u, centre_v;
         se2_apply(s, ref_u, ref_v, centre_u, centre_v);
+        ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
         const int min_row = wadd(f2i(centre_v), -p.patch_rows);
         const int min_col = wadd(f2i(centre_u), -p.patch_cols);
         const int max_row = wadd(min_row, p.patch_rows * 2);
         const int max_col = wadd(min_col, p.patch_cols * 2);
         const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
         uint32_t cur_valid_num = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -995,12 +1498,12 @@ __device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevIma
                 se2_apply(s, col_i, row_i, col_j, row_j);
                 float value = 0.0f;
                 if (partly_outside) {
-                    ok = sample(cur, row_j, col_j, value);
+                    ok = sample(cur, cw, row_j, col_j, value);
                     if (!ok) {
                         value = 0.0f;
                     }
                 } else {
-                    value = bilinear(cur, row_j, col_j);
+                    value = bilinear(cur, cw, row_j, col_j);
                     ok = true;
                 }
                 curp[pxi] = value;
@@ -1011,15 +1514,14 @@ __device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevIma
             }
             cur_valid_num += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        cur_valid_num = block_total(b, cur_valid_num, c.wave_cnt);
         if (cur_valid_num == 0) {
             break;
         }
         if (p.consider_luminance) {
-            const float cacc = chain_sum(c.terms, 1, p.Ppad, lane);
-            __syncthreads();
-            const float cur_average = bcast(cacc, 0) / (float)cur_valid_num;
-            for (int i = lane; i < p.P; i += kWave) {
+            chain_sums(b, c.terms, 1, p.Ppad, c.sums);
+            const float cur_average = c.sums[0] / (float)cur_valid_num;
+            for (int i = b.tid; i < p.P; i += b.nt) {
                 curp[i] /= cur_average;
             }
             __syncthreads();
@@ -1027,8 +1529,8 @@ __device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevIma
 
         // ComputeHessianAndBias (:197-229)
         uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += kWave) {
-            const int pxi = base + lane;
+        for (int base = 0; base < p.P; base += b.nt) {
+            const int pxi = base + b.tid;
             bool ok = false;
             if (pxi < p.P) {
                 int prow, pcol;
@@ -1046,14 +1548,15 @@ __device__ __forceinline__ void lssd_level_fast(const KltParams &p, const DevIma
             }
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
-        __syncthreads();
+        n_valid = block_total(b, n_valid, c.wave_cnt);
         if (n_valid == 0) {
             break;
         }
-        const float acc = chain_sum(c.terms, 9, p.Ppad, lane);
-        __syncthreads();
+        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
         float v[3];
-        if (!lssd_solve_and_update(acc, s, v, status)) {
+        const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+        __syncthreads();  // sums[] may be rewritten by the luminance chain of the next iteration
+        if (!solved) {
             break;
         }
         if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
@@ -1081,10 +1584,25 @@ struct ChainCount<FTK_MODEL_LSSD> {
     static constexpr int value = 9;
 };
 
+constexpr int kMaxWaves = 4;
+
+// Optional register cap (build-time experiment knob): -DFTK_WAVES_PER_EU=n asks the compiler to fit
+// n waves per SIMD so that more feature workgroups are co-resident per CU.
+#ifdef FTK_WAVES_PER_EU
+#define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU, FTK_WAVES_PER_EU)))
+#else
+#define FTK_EU_ATTR
+#endif
+
 template <int MODEL, int METHOD>
-__global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
+__global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
-    const int lane = threadIdx.x;
+    Blk b;
+    b.tid = threadIdx.x;
+    b.nt = blockDim.x;
+    b.lane = b.tid & (kWave - 1);
+    b.wave = b.tid >> 6;
+    b.nwaves = b.nt >> 6;
     const uint32_t id = blockIdx.x;
     if (id >= (uint32_t)p.n) {
         return;
@@ -1093,7 +1611,7 @@ __global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
     uint8_t status = p.status_in[id];
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through
     if (id >= p.n_track || status > FTK_TRACKED) {
-        if (lane == 0) {
+        if (b.tid == 0) {
             p.cur_uv_out[2 * id] = in_u;
             p.cur_uv_out[2 * id + 1] = in_v;
             p.status_out[id] = status;
@@ -1104,9 +1622,12 @@ __global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
         return;
     }
 
+#ifdef FTK_STAMPS
+    const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int K = ChainCount<MODEL>::value;
     Carve c = carve_lds(reinterpret_cast<float *>(lds_raw), K, p);
-    zero_term_padding(c.terms, K, p, lane);
+    zero_term_padding(b, c.terms, K, p);
 
     const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
     const float scale = p.single_level ? 1.0f : (float)(1 << (p.n_levels - 1));
@@ -1136,26 +1657,26 @@ __global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
     for (int level = p.n_levels - 1; level > -1; --level) {
         const DevImage ref = p.ref[level];
         const DevImage cur = p.cur[level];
+        __syncthreads();  // the previous level's readers of the LDS windows / arrays are done
         if (MODEL == FTK_MODEL_BASIC) {
             if (METHOD == FTK_METHOD_FAST) {
-                basic_level_fast(p, ref, cur, ref_u, ref_v, bs, status, iters, c, lane);
+                basic_level_fast(b, p, ref, cur, ref_u, ref_v, bs, status, iters, c);
             } else {
-                basic_level<METHOD>(p, ref, cur, ref_u, ref_v, bs, status, iters, c, lane);
+                basic_level<METHOD>(b, p, ref, cur, ref_u, ref_v, bs, status, iters, c);
             }
         } else if (MODEL == FTK_MODEL_AFFINE) {
             if (METHOD == FTK_METHOD_FAST) {
-                affine_level_fast(p, ref, cur, ref_u, ref_v, as, status, iters, c, lane);
+                affine_level_fast(b, p, ref, cur, ref_u, ref_v, as, status, iters, c);
             } else {
-                affine_level<METHOD>(p, ref, cur, ref_u, ref_v, as, status, iters, c, lane);
+                affine_level<METHOD>(b, p, ref, cur, ref_u, ref_v, as, status, iters, c);
             }
         } else {
             if (METHOD == FTK_METHOD_FAST) {
-                lssd_level_fast(p, ref, cur, ref_u, ref_v, ls, status, iters, c, lane);
+                lssd_level_fast(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
             } else {
-                lssd_level<METHOD>(p, ref, cur, ref_u, ref_v, ls, status, iters, c, lane);
+                lssd_level<METHOD>(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
             }
         }
-        __syncthreads();
 
         if (level == 0) {
             if (MODEL == FTK_MODEL_BASIC) {
@@ -1189,7 +1710,7 @@ __global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
     if (uv_outside(out_u, out_v, p.cur[0])) {
         status = FTK_OUTSIDE;
     }
-    if (lane == 0) {
+    if (b.tid == 0) {
         p.cur_uv_out[2 * id] = out_u;
         p.cur_uv_out[2 * id + 1] = out_v;
         p.status_out[id] = status;
@@ -1197,6 +1718,14 @@ __global__ void __launch_bounds__(kWave) klt_track_kernel(const KltParams p) {
             p.iters[id] = iters;
         }
     }
+#ifdef FTK_STAMPS
+    if (b.tid == 0 && p.stamps) {
+        b.stamp_acc[7] = __builtin_amdgcn_s_memtime() - stamp_kernel_t0;
+        for (int k = 0; k < 8; ++k) {
+            p.stamps[(size_t)id * 8 + k] = b.stamp_acc[k];
+        }
+    }
+#endif
 }
 
 template <int MODEL, int METHOD>
@@ -1208,7 +1737,7 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
             return e;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave), lds_bytes, stream, p);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -1229,11 +1758,13 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p) {
     if (k == 0) {
         return 0;
     }
-    const size_t epad = (size_t)pad4(p.E);
-    return sizeof(float) * ((size_t)k * p.Ppad + 4 * epad) + 2 * epad;
+    return (carve_bytes(k, p) + 15) & ~(size_t)15;
 }
 
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream) {
+    if (p.waves_per_feature < 1 || p.waves_per_feature > kMaxWaves) {
+        return hipErrorInvalidValue;
+    }
     const size_t lds = klt_lds_bytes(model, method, p);
     const int m = (method == FTK_METHOD_INVERSE || method == FTK_METHOD_DIRECT) ? method : FTK_METHOD_FAST;
 #define FTK_DISPATCH(MODEL)                                                               \

@@ -49,9 +49,9 @@ int main(int argc, char **argv) {
     std::vector<Vec2> ref_uv(n_ref), cur_uv(n_cur);
     auto read = [&](std::vector<feature_detector::BriefType> &d, std::vector<Vec2> &uv) {
         for (size_t i = 0; i < d.size(); ++i) {
-            std::string bits;
-            float u = 0, v = 0;
-            in >> bits >> u >> v;
+            std::string bits, su, sv;
+            in >> bits >> su >> sv;  // hex floats: parse with strtof (iostream does not)
+            const float u = std::strtof(su.c_str(), nullptr), v = std::strtof(sv.c_str(), nullptr);
             if (bits == "-") bits.clear();
             d[i].resize(bits.size());
             for (size_t b = 0; b < bits.size(); ++b) d[i][b] = bits[b] == '1';
