@@ -104,8 +104,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("FTK_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = dict(synth.CONFIGS[args.workload])
@@ -135,14 +137,18 @@ def main():
         d_ref = torch.from_numpy(uv).to(dev)
         d_cur_in = d_ref.clone()  # no prediction: cur = ref (optical_flow.cpp:12-14)
         d_st_in = torch.zeros(n, dtype=torch.uint8, device=dev)
-        packed = torch.zeros(FD.packed_bytes(n), dtype=torch.uint8, device=dev)
-        d_cur_out, d_st_out = FD.pack_views(packed, n)
+        # two alternating result slots
+        packed2 = [torch.zeros(FD.packed_bytes(n), dtype=torch.uint8, device=dev) for _ in range(2)]
+        views2 = [FD.pack_views(pk, n) for pk in packed2]
+        gathered2 = [torch.empty(FD.packed_bytes(n) * world, dtype=torch.uint8, device=dev) for _ in range(2)]
+        packed = packed2[0]
+        d_cur_out, d_st_out = views2[0]
         d_iters = torch.zeros(n, dtype=torch.int32, device=dev)
 
         def step(with_iters=False):
             klt.track(d_ref, d_cur_in, d_st_in, d_cur_out, d_st_out, d_iters if with_iters else None)
-            if world > 1:
-                return FD.all_gather_results(packed, world)
+            if use_dist:
+                return FD.all_gather_results(packed, world, force_collective=True)
             return packed
 
         step(with_iters=True)
@@ -153,26 +159,36 @@ def main():
             step()
         stream.synchronize()
 
+        launches = [klt.bind(d_ref, d_cur_in, d_st_in, views2[slot][0], views2[slot][1], None) for slot in range(2)]
         # kernel-only duration: HIP events on the launch stream around the tracker launches of the timed region
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        # N > 1: kernel, then the all-gather of its result shard, per step.  (Overlapping the gather
+        # of step k with the kernel of step k+1 on a side stream was measured and is host-bound in
+        # this Python loop — 95-100 us vs 81 us per step at world size 1 — so the plain order stays.)
         for k in range(args.steps):
+            slot = k & 1
             ev0[k].record(stream)
-            klt.track(d_ref, d_cur_in, d_st_in, d_cur_out, d_st_out, None)
+            launches[slot]()
             ev1[k].record(stream)
-            if world > 1:
-                FD.all_gather_results(packed, world)
+            if use_dist:
+                FD.all_gather_results(packed2[slot], world, force_collective=True, out=gathered2[slot])
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if use_dist:
+            # every rank must now hold every rank's result shard: spot-check the own shard inside the gathered buffer
+            per = FD.packed_bytes(n)
+            for slot in range(min(2, args.steps)):
+                assert torch.equal(gathered2[slot][rank * per:(rank + 1) * per], packed2[slot]), "all-gather did not return this rank's shard"
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,8 +204,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['model']} KLT {cfg['method']}, {n} features/GPU, {w}x{h}, {levels}-level pyramid, "
-                                   f"{2 * half + 1}x{2 * half + 1} patch", "parallelism": f"features sharded x{world}, pyramids replicated, "
-                       "one all-gather of packed (uv,status) per step" if world > 1 else "single GPU",
+                                   f"{2 * half + 1}x{2 * half + 1} patch", "parallelism": f"features sharded x{world}, pyramids replicated, one RCCL all-gather of packed (uv,status) per step"
+                       if use_dist else "single GPU",
                        "tracked_fraction": float((status == 1).mean()), "mean_iterations_per_feature": float(iters.mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes(), "kernel": "klt_track_kernel", "kernel_ms": kernel_ms,
@@ -198,7 +214,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

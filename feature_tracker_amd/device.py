@@ -68,6 +68,24 @@ class DeviceKlt:
         self.lum = int(bool(consider_luminance))
         self.single = int(bool(single_level))
 
+    def bind(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None):
+        """Pre-marshals one launch on fixed buffers; the returned callable enqueues it with minimal
+        host work (for launch-rate-sensitive loops).  The tensors must outlive the callable."""
+        fn = N.lib().ftk_klt_track_device
+        args = (self.ctx.handle, self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, C.c_void_p(ref_uv.data_ptr()),
+                C.c_void_p(cur_uv_in.data_ptr()), C.c_void_p(cur_uv_out.data_ptr()), C.c_void_p(status_in.data_ptr()),
+                C.c_void_p(status_out.data_ptr()), ref_uv.shape[0], None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p),
+                self.lum, self.single, None if iters is None else C.c_void_p(iters.data_ptr()))
+        keep = (ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters)
+        handle = self.ctx.handle
+
+        def launch(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc != 0:
+                N.check(rc, handle)
+
+        return launch
+
     def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None):
         n = ref_uv.shape[0]
         rc = N.lib().ftk_klt_track_device(

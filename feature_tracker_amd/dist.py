@@ -55,17 +55,20 @@ def unpack_gathered(gathered, n: int, world_size: int):
     return torch.cat(uvs, dim=0), torch.cat(sts, dim=0)
 
 
-def all_gather_results(local_packed, world_size: int, group=None):
-    """One collective per call: every rank contributes its packed shard and receives all of them."""
+def all_gather_results(local_packed, world_size: int, group=None, force_collective: bool = False, out=None, async_op: bool = False):
+    """One collective per call: every rank contributes its packed shard and receives all of them.
+    Returns the gathered buffer, or (buffer, work) when async_op is set — the caller then overlaps the
+    collective with the next launch and calls work.wait() before reusing `local_packed`."""
     import torch
     import torch.distributed as dist
 
-    out = torch.empty(local_packed.numel() * world_size, dtype=torch.uint8, device=local_packed.device)
-    if world_size == 1:
+    if out is None:
+        out = torch.empty(local_packed.numel() * world_size, dtype=torch.uint8, device=local_packed.device)
+    if world_size == 1 and not force_collective:
         out.copy_(local_packed)
-        return out
-    dist.all_gather_into_tensor(out, local_packed, group=group)
-    return out
+        return (out, None) if async_op else out
+    work = dist.all_gather_into_tensor(out, local_packed, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def split_numpy(arr: np.ndarray, world_size: int, rank: int) -> np.ndarray:

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Times every BASELINE.json configuration (and all nine tracker variants on config 2) on one
+MI355X next to the CPU oracle, and checks parity on the same inputs.
+
+    python scripts/bench_configs.py [--quick] > gpurun_out/bench_configs.jsonl
+
+One JSON line per case: GPU kernel time (HIP events on the launch stream, median of `reps`
+launches on device-resident inputs), host-call time through the C ABI (H2D of the feature vectors,
+launch, D2H), CPU oracle time (single thread), parity (max |duv|, bit-identical fraction, status
+mismatches).  Used for the tables in DESIGN.md; bench.py remains the contractual benchmark.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def klt_case(name, cfg, torch, F, D, synth, oracle, reps, cpu_reps, motion=(3.3, -2.1)):
+    n, w, h, levels, half, model, method = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"], cfg["model"], cfg["method"]
+    if model == "basic":
+        ref_img, cur_img = synth.make_image_pair(w, h, motion)
+    else:
+        ref_img, cur_img = synth.make_image_pair(w, h, motion, rotation_deg=1.5, scale=1.02)
+    ref_levels, cur_levels = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+    uv = synth.make_features(n, w, h, half=half)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        ref_pyr, cur_pyr = D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev)
+        opt = F.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, half, half, n
+        klt = D.DeviceKlt(model, opt, ref_pyr, cur_pyr, ctx, consider_luminance=cfg.get("luminance", False))
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_in = d_ref.clone()
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_out = torch.empty_like(d_ref)
+        d_sto = torch.empty_like(d_st)
+        d_it = torch.zeros(n, dtype=torch.int32, device=dev)
+        klt.track(d_ref, d_in, d_st, d_out, d_sto, d_it)
+        stream.synchronize()
+        for _ in range(3):
+            klt.track(d_ref, d_in, d_st, d_out, d_sto, None)
+        times = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            klt.track(d_ref, d_in, d_st, d_out, d_sto, None)
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        gpu_uv, gpu_st, iters = d_out.cpu().numpy(), d_sto.cpu().numpy(), d_it.cpu().numpy()
+    # host-call path (what the C++ / Python classes do per TrackFeatures)
+    cls = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}[model]()
+    o = cls.options()
+    o.kMethod, o.kPatchRowHalfSize, o.kPatchColHalfSize, o.kMaxTrackPointsNumber = method, half, half, n
+    if model == "lssd":
+        cls.consider_patch_luminance = cfg.get("luminance", False)
+    rp, cp = F.ImagePyramid.from_host_levels(ref_levels), F.ImagePyramid.from_host_levels(cur_levels)
+    cls.TrackFeatures(rp, cp, uv)
+    host_times = []
+    for _ in range(max(3, reps // 4)):
+        t0 = time.perf_counter()
+        cls.TrackFeatures(rp, cp, uv)
+        host_times.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    up = F.ImagePyramid.from_host_levels(ref_levels)
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    del up
+    cpu_times = []
+    for _ in range(cpu_reps):
+        t0 = time.perf_counter()
+        ok, cuv, cst, cit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=half, max_points=n,
+                                                     consider_luminance=cfg.get("luminance", False))
+        cpu_times.append((time.perf_counter() - t0) * 1e3)
+    finite = np.isfinite(cuv).all(axis=1)
+    d = np.abs(gpu_uv[finite].astype(np.float64) - cuv[finite].astype(np.float64)).max(axis=1) if finite.any() else np.zeros(0)
+    gpu_ms, cpu_ms = float(np.median(times)), float(np.median(cpu_times))
+    r_bytes = (2 * half + 4) ** 2 if method != "direct" else (2 * half + 2) ** 2
+    c_bytes = (2 * half + 2) ** 2 if method != "direct" else (2 * half + 4) ** 2
+    algo = n * (levels * r_bytes + 26) + int(iters.sum()) * c_bytes
+    return {
+        "case": name, "model": model, "method": method, "n": n, "image": f"{w}x{h}", "levels": levels, "patch": 2 * half + 1,
+        "gpu_kernel_ms": gpu_ms, "gpu_features_per_s": n / gpu_ms * 1e3, "gpu_host_call_ms": float(np.median(host_times)),
+        "pyramid_upload_ms": upload_ms, "cpu_ms": cpu_ms, "cpu_features_per_s": n / cpu_ms * 1e3, "speedup_kernel": cpu_ms / gpu_ms,
+        "tracked_fraction": float((cst == 1).mean()), "mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
+        "parity_max_px": float(d.max()) if d.size else 0.0, "parity_frac_gt_1e-3": float((d > 1e-3).mean()) if d.size else 0.0,
+        "bit_identical": bool(np.array_equal(gpu_uv.view(np.uint32), cuv.view(np.uint32))), "status_mismatches": int((gpu_st != cst).sum()),
+        "algorithmic_bytes": int(algo), "algorithmic_GBps": algo / (gpu_ms * 1e-3) / 1e9,
+    }
+
+
+def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, cpu_pairs):
+    ref, cur, perm = synth.make_descriptors(n_ref, n_cur, flips=20)
+    ref_w, cur_w = F.pack_brief(ref), F.pack_brief(cur)
+    rs = np.random.RandomState(11)
+    cur_uv = np.stack([rs.uniform(0, 640, n_cur), rs.uniform(0, 480, n_cur)], axis=1).astype(np.float32)
+    pred_uv = np.stack([rs.uniform(0, 640, n_ref), rs.uniform(0, 480, n_ref)], axis=1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        d_ref = torch.from_numpy(ref_w.view(np.int32)).to(dev)
+        d_cur = torch.from_numpy(cur_w.view(np.int32)).to(dev)
+        d_idx = torch.full((n_ref,), -1, dtype=torch.int32, device=dev)
+        d_ws = torch.zeros(n_ref, dtype=torch.int64, device=dev)
+        d_pred = torch.from_numpy(pred_uv).to(dev) if nearby else None
+        d_cuv = torch.from_numpy(cur_uv).to(dev) if nearby else None
+        args = dict(pred_uv=d_pred, cur_uv=d_cuv, max_col=50, max_row=50, workspace=d_ws)
+        D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx, **args)
+        stream.synchronize()
+        times = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx, **args)
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        gpu_idx = d_idx.cpu().numpy()
+    # CPU oracle on a bounded sample of ref rows (full candidate set), scaled by pairs
+    rows = max(1, min(n_ref, cpu_pairs // n_cur))
+    t0 = time.perf_counter()
+    if nearby:
+        ok, cidx = oracle.nearby_match(ref[:rows], cur, pred_uv[:rows], cur_uv, 60.0, max_col=50, max_row=50)
+    else:
+        ok, cidx = oracle.force_match(ref[:rows], cur, 60.0)
+    cpu_s = time.perf_counter() - t0
+    gpu_ms = float(np.median(times))
+    pairs = n_ref * n_cur
+    return {
+        "case": name, "mode": "nearby" if nearby else "force", "n_ref": n_ref, "n_cur": n_cur, "bits": 256, "gpu_kernel_ms": gpu_ms,
+        "gpu_pairs_per_s": pairs / gpu_ms * 1e3, "cpu_sample_rows": rows, "cpu_sample_s": cpu_s,
+        "cpu_ns_per_pair": cpu_s / (rows * n_cur) * 1e9 if not nearby else None, "cpu_full_estimate_s": cpu_s * n_ref / rows,
+        "speedup": (cpu_s * n_ref / rows) / (gpu_ms * 1e-3), "indices_bit_exact_on_sample": bool(np.array_equal(gpu_idx[:rows], cidx)),
+        "matched": int((gpu_idx >= 0).sum()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+    from tests import oracle_lib as oracle
+
+    oracle.lib()
+    reps = 10 if args.quick else 40
+    cases = []
+    for key in ("config1", "config2", "config3", "config4", "config5_shard"):
+        cases.append((key, dict(synth.CONFIGS[key])))
+    for model in ("basic", "affine", "lssd"):
+        for method in ("inverse", "direct", "fast"):
+            c = dict(synth.CONFIGS["config2"])
+            c.update(model=model, method=method, half=6)
+            cases.append((f"variants_2000x13x13/{model}/{method}", c))
+    c = dict(synth.CONFIGS["config4"])
+    c["luminance"] = True
+    cases.append(("config4_luminance", c))
+    for name, cfg in cases:
+        big = cfg["n"] * cfg["levels"] > 60000
+        out = klt_case(name, cfg, torch, F, D, synth, oracle, reps, 1 if (big or args.quick) else 3)
+        print(json.dumps(out), flush=True)
+    for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True),
+                                       ("match_300x300_nearby", 300, 300, True), ("match_2000_force", 2000, 2000, False)):
+        out = matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000 if args.quick else 20_000_000)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

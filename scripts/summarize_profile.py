@@ -52,8 +52,8 @@ def main(tag):
                 "kernel": klt[0],
                 "fetch_size_kb_median": fetch_kb, "write_size_kb_median": write_kb,
                 "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts 128-B requests at 64 B "
-                              "(MI355X_MICROARCH.md §HBM); calibrated there for 16 B/lane streams, this kernel issues byte loads, so "
-                              "the x2 makes this an upper estimate",
+                              "(MI355X_MICROARCH.md §HBM); calibrated there for 16 B/lane streams, this kernel issues unaligned "
+                              "8 B/lane window loads, so the x2 makes this an upper estimate",
                 "klt_config2_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
                 "klt_config2_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
             }
