@@ -238,3 +238,71 @@ def test_pyramid_build_matches_oracle(ftk, oracle):
         assert pyr.level() == levels
         for i in range(levels):
             assert np.array_equal(pyr.download_level(i), ref[i]), (w, h, i)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_tiny_image_and_coarse_levels_smaller_than_patch(ftk, oracle, model):
+    """Pyramid levels smaller than the patch footprint: every window is clamped at the border."""
+    from feature_tracker_amd import synth
+    ref, cur = synth.make_image_pair(64, 48, (1.3, -0.8))
+    ref_levels, cur_levels = synth.build_pyramid(ref, 3), synth.build_pyramid(cur, 3)
+    uv = scenes.features(96, 64, 48, half=6, border_fraction=0.2)
+    for method in METHODS:
+        gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=6)
+        assert_parity(gpu, cpu, f"tiny {model}/{method}")
+
+
+@pytest.mark.parametrize("model,half", [("basic", 15), ("lssd", 12), ("affine", 9), ("basic", 0), ("lssd", 1)])
+def test_large_and_degenerate_patch_sizes(ftk, oracle, model, half):
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(80, 320, 240, half=max(half, 2))
+    for method in METHODS:
+        gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=half)
+        assert_parity(gpu, cpu, f"half={half} {model}/{method}")
+
+
+def test_unsupported_patch_is_a_clean_error(ftk):
+    from feature_tracker_amd import _native
+    ref_levels, cur_levels = scenes.scene(160, 120, 1)
+    klt = make_tracker(ftk, "affine", "inverse", 30)  # 24 chains x 61^2 terms do not fit 160 KB of LDS
+    with pytest.raises(_native.FtkError) as e:
+        klt.TrackFeatures(ref_levels[0], cur_levels[0], np.float32([[80, 60]]))
+    assert e.value.code == -4
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_non_finite_and_huge_coordinates(ftk, oracle, model):
+    """NaN / inf / absurd coordinates in ref_uv and in the prediction must neither fault nor differ from the CPU path."""
+    ref_levels, cur_levels = scenes.scene(160, 120, 2)
+    good = scenes.features(16, 160, 120, half=4, border_fraction=0.0)
+    weird = np.float32([[np.nan, 50], [50, np.nan], [np.inf, 50], [50, -np.inf], [1e30, 1e30], [-1e30, 5], [3e9, 60], [-3e9, -3e9],
+                        [2147483648.0, 10], [-2147483904.0, 10], [1e-40, 1e-40], [159.0, 119.0]])
+    uv = np.concatenate([good, weird]).astype(np.float32)
+    pred = uv.copy()
+    pred[:8] = weird[:8]  # trackable ref points with poisoned predictions
+    for method in METHODS:
+        for cur_uv in (None, pred):
+            gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=4, cur_uv=cur_uv)
+            ok_g, uv_g, st_g, it_g = gpu
+            ok_c, uv_c, st_c, it_c = cpu
+            assert np.array_equal(st_g, st_c), f"{model}/{method}: {st_g} vs {st_c}"
+            assert np.array_equal(uv_g.view(np.uint32), uv_c.view(np.uint32)) or np.array_equal(np.isnan(uv_g), np.isnan(uv_c)) and \
+                np.array_equal(uv_g[~np.isnan(uv_g)], uv_c[~np.isnan(uv_c)]), f"{model}/{method}"
+            assert np.array_equal(it_g, it_c)
+
+
+def test_many_features_single_launch(ftk, oracle):
+    """100 000 features in one call (grid = 100 000 workgroups); oracle-checked on a slice, size-independent checks on the rest."""
+    ref_levels, cur_levels = scenes.scene(640, 480, 3)
+    uv = scenes.features(100000, 640, 480, half=4, border_fraction=0.01)
+    klt = make_tracker(ftk, "basic", "fast", 4, max_points=100000)
+    ok, c, s = klt.TrackFeatures(ftk.ImagePyramid.from_host_levels(ref_levels), ftk.ImagePyramid.from_host_levels(cur_levels), uv)
+    assert ok and (s == 1).mean() > 0.97
+    d = c[s == 1] - uv[s == 1]
+    assert abs(np.median(d[:, 0]) - 3.3) < 0.15 and abs(np.median(d[:, 1]) + 2.1) < 0.15
+    # idempotent: the same call again gives the same bits; and a 2 000-feature slice matches the oracle
+    ok2, c2, s2 = klt.TrackFeatures(ftk.ImagePyramid.from_host_levels(ref_levels), ftk.ImagePyramid.from_host_levels(cur_levels), uv)
+    assert np.array_equal(c.view(np.uint32), c2.view(np.uint32)) and np.array_equal(s, s2)
+    sl = slice(40000, 42000)
+    okc, cc, sc, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv[sl], method="fast", half=4, max_points=100000)
+    assert np.array_equal(c[sl].view(np.uint32), cc.view(np.uint32)) and np.array_equal(s[sl], sc)
