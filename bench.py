@@ -77,6 +77,59 @@ def cpu_baseline(cfg, ref_levels, cur_levels, uv, budget_s=12.0):
     }
 
 
+def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
+    """Strong scaling: args.shard_total features of the workload's geometry, sharded over the ranks, one all-gather per step."""
+    import torch
+    import torch.distributed as dist
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import dist as FD
+    from feature_tracker_amd import synth
+
+    n, w, h, levels, half = args.shard_total, cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
+    ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))
+    ref_levels, cur_levels = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+    uv = synth.make_features(n, w, h, half=half)  # the same full list on every rank
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, local_rank)
+        opt = F.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = cfg["method"], half, half, n
+        klt = D.DeviceKlt(cfg["model"], opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        sharded = FD.ShardedKlt(klt, n, dev, world, rank)
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_in = d_ref.clone()
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        for _ in range(max(1, args.warmup)):
+            sharded.launch(d_ref, d_in, d_st)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sharded.launch(d_ref, d_in, d_st)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        guv, gst = FD.unpack_gathered(sharded.gathered, n, world)
+        tracked = float((gst == 1).float().mean().item())
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "tracked features/sec (sharded)", "value": n * args.steps / elapsed, "unit": "tracked features/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg['model']} KLT {cfg['method']}, {n} features in total sharded x{world}, {w}x{h}, {levels}-level pyramid, "
+                                   f"{2 * half + 1}x{2 * half + 1} patch", "tracked_fraction": tracked}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +137,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", help="feature_tracker_amd.synth.CONFIGS key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-total", type=int, default=0,
+                    help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
+                         "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
     ap.add_argument("--features", type=int, default=0, help="experiment knob: override the workload's feature count (the reported config says so)")
     args = ap.parse_args()
 
@@ -113,6 +169,8 @@ def main():
     cfg = dict(synth.CONFIGS[args.workload])
     if args.features > 0:
         cfg["n"] = args.features
+    if args.shard_total > 0:
+        return run_sharded(args, cfg, world, rank, local_rank, dev, use_dist)
     n, w, h, levels, half = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
     if cfg["model"] == "basic":
         ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))

@@ -26,6 +26,9 @@ struct ftk_context {
     size_t scratch_bytes = 0;
     unsigned long long *match_keys = nullptr;
     size_t match_keys_count = 0;
+    // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
 };
 
 struct ftk_pyramid {
@@ -75,6 +78,21 @@ int ensure_scratch(ftk_context *ctx, size_t bytes) {
     const size_t want = align_up(bytes + bytes / 2, 4096);
     FTK_HIP(ctx, hipMalloc(&ctx->scratch, want));
     ctx->scratch_bytes = want;
+    return FTK_OK;
+}
+
+int ensure_pinned(ftk_context *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes) {
+        return FTK_OK;
+    }
+    if (ctx->pinned) {
+        FTK_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 2, 4096);
+    FTK_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
     return FTK_OK;
 }
 
@@ -284,6 +302,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->match_keys) {
         (void)hipFree(ctx->match_keys);
     }
+    if (ctx->pinned) {
+        (void)hipHostFree(ctx->pinned);
+    }
     if (ctx->owns_stream) {
         (void)hipStreamDestroy(ctx->stream);
     }
@@ -328,21 +349,26 @@ int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n
         return fail(ctx, FTK_E_OUT_OF_MEMORY, "pyramid_upload: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
     }
     pyr->n_levels = n_levels;
+    // gather the levels in pinned staging, then ONE H2D copy of the whole pyramid
+    if (ensure_pinned(ctx, total) != FTK_OK) {
+        ftk_pyramid_destroy(pyr);
+        return FTK_E_OUT_OF_MEMORY;
+    }
+    uint8_t *staging = static_cast<uint8_t *>(ctx->pinned);
     for (int i = 0; i < n_levels; ++i) {
         const size_t bytes = (size_t)host_levels[i].rows * host_levels[i].cols;
-        e = hipMemcpyAsync(pyr->owned + offsets[i], host_levels[i].data, bytes, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) {
-            ftk_pyramid_destroy(pyr);
-            return fail(ctx, FTK_E_HIP, "pyramid_upload: copy of level %d failed: %s", i, hipGetErrorString(e));
-        }
+        memcpy(staging + offsets[i], host_levels[i].data, bytes);
         pyr->levels[i].data = pyr->owned + offsets[i];
         pyr->levels[i].rows = host_levels[i].rows;
         pyr->levels[i].cols = host_levels[i].cols;
     }
-    e = hipStreamSynchronize(ctx->stream);  // the host buffers may be released by the caller right after return
+    e = hipMemcpyAsync(pyr->owned, staging, total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        e = hipStreamSynchronize(ctx->stream);  // staging and the caller's buffers are free again on return
+    }
     if (e != hipSuccess) {
         ftk_pyramid_destroy(pyr);
-        return fail(ctx, FTK_E_HIP, "pyramid_upload: synchronize failed: %s", hipGetErrorString(e));
+        return fail(ctx, FTK_E_HIP, "pyramid_upload: copy failed: %s", hipGetErrorString(e));
     }
     *out = pyr;
     return FTK_OK;
@@ -546,34 +572,44 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track: null buffer");
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
-    // scratch layout: ref_uv | cur_uv | iters | status
+    // One contiguous block [ref_uv | cur_uv | status | iters], mirrored in pinned host memory:
+    // a single H2D of (ref_uv, cur_uv, status) and a single D2H of (cur_uv, status, iters) per call.
     const size_t uv_bytes = align_up(sizeof(float) * 2 * (size_t)n, 256);
-    const size_t it_bytes = align_up(sizeof(uint32_t) * (size_t)n, 256);
     const size_t st_bytes = align_up((size_t)n, 256);
-    int rc = ensure_scratch(ctx, 2 * uv_bytes + it_bytes + st_bytes);
+    const size_t it_bytes = align_up(sizeof(uint32_t) * (size_t)n, 256);
+    const size_t total = 2 * uv_bytes + st_bytes + it_bytes;
+    int rc = ensure_scratch(ctx, total);
     if (rc != FTK_OK) {
         return rc;
     }
-    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
-    float *d_ref = reinterpret_cast<float *>(base);
-    float *d_cur = reinterpret_cast<float *>(base + uv_bytes);
-    uint32_t *d_it = reinterpret_cast<uint32_t *>(base + 2 * uv_bytes);
-    uint8_t *d_st = base + 2 * uv_bytes + it_bytes;
-    FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    FTK_HIP(ctx, hipMemcpyAsync(d_st, status, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = ensure_pinned(ctx, total);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *dbase = static_cast<uint8_t *>(ctx->scratch);
+    uint8_t *hbase = static_cast<uint8_t *>(ctx->pinned);
+    float *d_ref = reinterpret_cast<float *>(dbase);
+    float *d_cur = reinterpret_cast<float *>(dbase + uv_bytes);
+    uint8_t *d_st = dbase + 2 * uv_bytes;
+    uint32_t *d_it = reinterpret_cast<uint32_t *>(dbase + 2 * uv_bytes + st_bytes);
+    memcpy(hbase, ref_uv, sizeof(float) * 2 * (size_t)n);
+    memcpy(hbase + uv_bytes, cur_uv, sizeof(float) * 2 * (size_t)n);
+    memcpy(hbase + 2 * uv_bytes, status, (size_t)n);
+    FTK_HIP(ctx, hipMemcpyAsync(dbase, hbase, 2 * uv_bytes + st_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = ftk_klt_track_device(ctx, model, opt, ref, cur, d_ref, d_cur, d_cur, d_st, d_st, n, prior, consider_luminance, single_level,
                               iters ? d_it : nullptr);
     if (rc != FTK_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
-    FTK_HIP(ctx, hipMemcpyAsync(cur_uv, d_cur, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    FTK_HIP(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    if (iters) {
-        FTK_HIP(ctx, hipMemcpyAsync(iters, d_it, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    const size_t back = uv_bytes + st_bytes + (iters ? it_bytes : 0);
+    FTK_HIP(ctx, hipMemcpyAsync(hbase + uv_bytes, dbase + uv_bytes, back, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(cur_uv, hbase + uv_bytes, sizeof(float) * 2 * (size_t)n);
+    memcpy(status, hbase + 2 * uv_bytes, (size_t)n);
+    if (iters) {
+        memcpy(iters, hbase + 2 * uv_bytes + st_bytes, sizeof(uint32_t) * (size_t)n);
+    }
     return FTK_OK;
 }
 

@@ -74,3 +74,38 @@ def all_gather_results(local_packed, world_size: int, group=None, force_collecti
 def split_numpy(arr: np.ndarray, world_size: int, rank: int) -> np.ndarray:
     b, e = shard_bounds(arr.shape[0], world_size, rank)
     return arr[b:e]
+
+
+class ShardedKlt:
+    """TrackFeatures over the GPUs of one node (BASELINE.json configs[4]).
+
+    Every rank holds both pyramids (replicated) and the full feature list; rank r tracks the
+    contiguous block ``shard_bounds(n, world, r)`` with ONE kernel launch, writes (u, v) + status into
+    its packed shard, and one all-gather gives every rank the complete result in the original feature
+    order — identical to the single-GPU result because features do not interact.
+
+    ``tracker`` is any object with ``track(ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters)``
+    on torch tensors (``feature_tracker_amd.device.DeviceKlt`` on GPUs).
+    """
+
+    def __init__(self, tracker, n: int, device, world_size: int = 1, rank: int = 0, group=None):
+        import torch
+
+        self.tracker, self.n, self.world, self.rank, self.group = tracker, int(n), int(world_size), int(rank), group
+        self.begin, self.end = shard_bounds(self.n, self.world, self.rank)
+        self.cap = shard_capacity(self.n, self.world)
+        self.packed = torch.zeros(packed_bytes(self.cap), dtype=torch.uint8, device=device)
+        self.gathered = torch.empty(packed_bytes(self.cap) * self.world, dtype=torch.uint8, device=device)
+        self.uv_view, self.status_view = pack_views(self.packed, self.cap)
+
+    def launch(self, ref_uv, cur_uv_in, status_in, iters=None):
+        """Enqueue the local shard's kernel and the all-gather; returns the gathered byte buffer (asynchronous on GPUs)."""
+        m = self.end - self.begin
+        if m > 0:
+            self.tracker.track(ref_uv[self.begin:self.end], cur_uv_in[self.begin:self.end], status_in[self.begin:self.end],
+                               self.uv_view[:m], self.status_view[:m], None if iters is None else iters[self.begin:self.end])
+        return all_gather_results(self.packed, self.world, group=self.group, force_collective=self.world > 1, out=self.gathered)
+
+    def track(self, ref_uv, cur_uv_in, status_in, iters=None):
+        """Returns (cur_uv [n, 2], status [n]) for ALL features, in order."""
+        return unpack_gathered(self.launch(ref_uv, cur_uv_in, status_in, iters), self.n, self.world)

@@ -84,14 +84,16 @@ n = 101
 uv = scenes.features(n, 160, 120, half=4)
 b, e = FD.shard_bounds(n, world, rank)
 cap = FD.shard_capacity(n, world)
-# stand-in for the device kernel on this rank's shard: the oracle (this is a test of the exchange path)
-ok, c, st, it = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv[b:e], method="fast", half=4, max_points=n)
-buf = torch.zeros(FD.packed_bytes(cap), dtype=torch.uint8)
-puv, pst = FD.pack_views(buf, cap)
-puv[: e - b] = torch.from_numpy(c)
-pst[: e - b] = torch.from_numpy(st)
-gathered = FD.all_gather_results(buf, world)
-guv, gst = FD.unpack_gathered(gathered, n, world)
+# stand-in for the device kernel on this rank's shard: the oracle (this is a test of the sharding / exchange path)
+class OracleTracker:
+    def track(self, ref_uv, cur_in, st_in, cur_out, st_out, iters):
+        ok, c, st, it = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, ref_uv.numpy(), cur_in.numpy(), st_in.numpy(),
+                                                     method="fast", half=4, max_points=n)
+        cur_out.copy_(torch.from_numpy(c)); st_out.copy_(torch.from_numpy(st))
+sharded = FD.ShardedKlt(OracleTracker(), n, "cpu", world, rank)
+assert (sharded.begin, sharded.end) == (b, e)
+t_uv = torch.from_numpy(uv)
+guv, gst = sharded.track(t_uv, t_uv.clone(), torch.zeros(n, dtype=torch.uint8))
 ok, c_all, st_all, _ = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="fast", half=4, max_points=n)
 assert np.array_equal(guv.numpy().view(np.uint32), c_all.view(np.uint32)), "gathered uv differs from the unsharded run"
 assert np.array_equal(gst.numpy(), st_all)

@@ -306,3 +306,25 @@ def test_many_features_single_launch(ftk, oracle):
     sl = slice(40000, 42000)
     okc, cc, sc, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv[sl], method="fast", half=4, max_points=100000)
     assert np.array_equal(c[sl].view(np.uint32), cc.view(np.uint32)) and np.array_equal(s[sl], sc)
+
+
+def test_sharded_tracker_on_device_world_size_1(ftk, oracle):
+    """ShardedKlt with the real device tracker (single rank): packed shard layout, gather and unpack on GPU tensors."""
+    import torch
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import dist as FD
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(333, 320, 240, half=5)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        opt = ftk.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = "inverse", 5, 5, 333
+        klt = D.DeviceKlt("basic", opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        sharded = FD.ShardedKlt(klt, 333, dev, 1, 0)
+        d_ref = torch.from_numpy(uv).to(dev)
+        guv, gst = sharded.track(d_ref, d_ref.clone(), torch.zeros(333, dtype=torch.uint8, device=dev))
+        stream.synchronize()
+    ok, c, s, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="inverse", half=5, max_points=333)
+    assert np.array_equal(guv.cpu().numpy().view(np.uint32), c.view(np.uint32)) and np.array_equal(gst.cpu().numpy(), s)
