@@ -167,6 +167,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.ex_rows = p.patch_rows + 2;
     p.ex_cols = p.patch_cols + 2;
     p.E = p.ex_rows * p.ex_cols;
+    {
+        const int32_t epad = (p.E + 3) & ~3, tables = 12 * (p.patch_rows + p.patch_cols);
+        p.a0_floats = epad > tables ? epad : tables;
+    }
     p.magic_pc = div_magic(p.patch_cols);
     p.magic_exc = div_magic(p.ex_cols);
     p.rwin_rows = p.patch_rows + 3;

@@ -38,6 +38,7 @@ struct KltParams {
     // derived patch geometry
     int32_t patch_rows, patch_cols, P, Ppad;  // Ppad = P rounded up to a multiple of 4
     int32_t ex_rows, ex_cols, E;
+    int32_t a0_floats;  // size of the first LDS array: max(E padded, axis tables)
     uint32_t magic_pc;   // ceil(2^32 / patch_cols): row = umulhi(p, magic_pc)
     uint32_t magic_exc;  // ceil(2^32 / ex_cols)
     // LDS image windows (16-bit pixel pairs): reference footprint and current footprint + margin

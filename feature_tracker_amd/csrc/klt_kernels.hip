@@ -35,6 +35,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <type_traits>
+
 namespace ftk {
 namespace {
 
@@ -200,6 +202,46 @@ __device__ __forceinline__ void swap_values(T &a, T &b) {
     b = t;
 }
 
+// Axis tables: the five reference taps of the inverse methods use, per patch pixel, the row axes of
+// (row, row-1, row+1) and the column axes of (col, col-1, col+1).  Those depend on the patch row
+// (resp. column) only, so they are computed once per level into LDS — 3*(rows+cols) entries instead
+// of 6 axes per pixel — with exactly the expressions of the per-pixel form.  Entry layout (float4):
+// x = window-relative base index (int bits, 0 when not covered), y = fraction, z = 1 - fraction,
+// w = flags (int bits: 1 = inside the image, 2 = covered by the staged window).
+__device__ __forceinline__ void build_axis_tables(const Blk &b, const KltParams &p, const DevImage &im, const Win &w, float u, float v,
+                                                  int variants, float4 *tab) {
+    const int nr = variants * p.patch_rows, total = nr + variants * p.patch_cols;
+    for (int t = b.tid; t < total; t += b.nt) {
+        const bool is_row = t < nr;
+        const int k = is_row ? t : t - nr;
+        const int len = is_row ? p.patch_rows : p.patch_cols;
+        const int var = (k >= 2 * len) ? 2 : (k >= len ? 1 : 0);
+        const int d = k - var * len;
+        float x = (float)(d - (is_row ? p.half_rows : p.half_cols)) + (is_row ? v : u);
+        if (var == 1) {
+            x = x - 1.0f;
+        } else if (var == 2) {
+            x = x + 1.0f;
+        }
+        const Axis a = make_axis(x, (is_row ? im.rows : im.cols) - 1);
+        const int rel = (int)((unsigned)a.i0 - (unsigned)(is_row ? w.r_lo : w.c_lo));
+        const bool hit = is_row ? (unsigned)rel < (unsigned)(w.rows - 1) : (unsigned)rel < (unsigned)w.cols;
+        tab[t] = make_float4(__int_as_float(hit ? rel : 0), a.sub, a.inv, __int_as_float((a.valid ? 1 : 0) | (hit ? 2 : 0)));
+    }
+}
+
+// tap() on two table entries.
+__device__ __forceinline__ float tap_table(const Win &w, const float4 &ar, const float4 &ac) {
+    const int idx = __float_as_int(ar.x) * w.cols + __float_as_int(ac.x);
+    const unsigned a = w.data[idx];
+    const unsigned bb = w.data[idx + w.cols];
+    const float w_tl = ar.z * ac.z;
+    const float w_tr = ar.z * ac.y;
+    const float w_bl = ar.y * ac.z;
+    const float w_br = ar.y * ac.y;
+    return w_tl * (float)(a & 0xFFu) + w_tr * (float)(a >> 8) + w_bl * (float)(bb & 0xFFu) + w_br * (float)(bb >> 8);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Eigen-compatible LDLT solve, N in {2, 3, 6}, everything in registers (all loops unrolled,
 // pivot swaps predicated on compile-time indices so nothing is dynamically indexed).
@@ -341,12 +383,12 @@ __device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N]
 // ---------------------------------------------------------------------------------------------
 struct Carve {
     float *terms;         // [K][Ppad] per-pixel products, k-major
-    float *a0;            // Epad floats (meaning depends on the variant)
+    float *a0;            // a0_floats = max(Epad, 12 * (patch_rows + patch_cols)) floats: extended patch / axis tables / i_cur
     float *a1;            // Ppad floats each
     float *a2;
     float *a3;
     float *sums;          // 72 floats: [0,K) chain sums, [K..] published solution, [32,68) affine-fast Hessian
-    uint32_t *wave_cnt;   // 8 slots for the workgroup-wide valid-pixel count
+    uint32_t *wave_cnt;   // 24 slots: per-wave valid counts (2 x 4 by parity), miss flags (2 x 4 by parity, + 2 x 4 for the level setup)
     uint16_t *ref_win;    // reference-image window (rwin_rows x rwin_cols pixel pairs)
     uint16_t *cur_win;    // current-image window   (cwin_rows x cwin_cols pixel pairs)
     uint8_t *flagsE;      // Epad bytes
@@ -357,7 +399,7 @@ __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 
 __host__ __device__ inline size_t carve_bytes(int K, const KltParams &p) {
     const size_t epad = (size_t)pad4(p.E);
-    const size_t floats = (size_t)K * p.Ppad + epad + 3 * (size_t)p.Ppad + 72 + 8;
+    const size_t floats = (size_t)K * p.Ppad + (size_t)p.a0_floats + 3 * (size_t)p.Ppad + 72 + 24;
     const size_t shorts = (size_t)pad4(p.rwin_rows * p.rwin_cols) + (size_t)pad4(p.cwin_rows * p.cwin_cols);
     return sizeof(float) * floats + sizeof(uint16_t) * shorts + epad + (size_t)p.Ppad;
 }
@@ -367,12 +409,12 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
     const int epad = pad4(p.E);
     c.terms = base;
     c.a0 = c.terms + K * p.Ppad;
-    c.a1 = c.a0 + epad;
+    c.a1 = c.a0 + p.a0_floats;
     c.a2 = c.a1 + p.Ppad;
     c.a3 = c.a2 + p.Ppad;
     c.sums = c.a3 + p.Ppad;
     c.wave_cnt = reinterpret_cast<uint32_t *>(c.sums + 72);
-    c.ref_win = reinterpret_cast<uint16_t *>(c.wave_cnt + 8);
+    c.ref_win = reinterpret_cast<uint16_t *>(c.wave_cnt + 24);
     c.cur_win = c.ref_win + pad4(p.rwin_rows * p.rwin_cols);
     c.flagsE = reinterpret_cast<uint8_t *>(c.cur_win + pad4(p.cwin_rows * p.cwin_cols));
     c.flagsP = c.flagsE + epad;
@@ -402,6 +444,23 @@ __device__ __forceinline__ void publish_count(const Blk &b, uint32_t wave_sum, u
         slots[(parity & 1u) * 4 + b.wave] = wave_sum;
     }
 }
+// Workgroup-wide OR of a per-lane flag with ONE barrier (which also publishes whatever phase A
+// stored before it): wave ballots go to parity-indexed slots, every lane reads them back.
+// `bank` selects one of four 4-slot groups so that back-to-back uses never share slots without a
+// barrier in between (0 / 1: iteration parity, 2 / 3: level setup fast / slow pass).
+__device__ __forceinline__ bool block_any(const Blk &b, bool flag, uint32_t *slots, uint32_t bank) {
+    const bool wave_any = __ballot(flag) != 0ull;
+    if (b.lane == 0) {
+        slots[8 + bank * 4 + b.wave] = wave_any ? 1u : 0u;
+    }
+    __syncthreads();
+    uint32_t any = 0;
+    for (int w = 0; w < b.nwaves; ++w) {
+        any |= slots[8 + bank * 4 + w];
+    }
+    return any != 0;
+}
+
 __device__ __forceinline__ uint32_t collect_count(const Blk &b, const uint32_t *slots, uint32_t parity) {
     uint32_t total = 0;
     for (int w = 0; w < b.nwaves; ++w) {
@@ -642,7 +701,7 @@ __device__ __forceinline__ void stage_both_inside(const Blk &b, const KltParams 
 // Level entry: stages the reference footprint of (ref_u, ref_v) and the current footprint (+ margin)
 // of (cur_u, cur_v) back to back with a single barrier, so the global round trips overlap.
 __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
-                                                    float ref_v, float cur_u, float cur_v, Carve &c, Win &rw, Win &cw) {
+                                                    float ref_v, float cur_u, float cur_v, Carve &c, Win &rw, Win &cw, int ref_axis_variants = 0) {
     footprint_origin(p, ref_u, ref_v, rw.r_lo, rw.c_lo);
     rw.rows = p.rwin_rows;
     rw.cols = p.rwin_cols;
@@ -654,6 +713,9 @@ __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParam
     cw.rows = p.cwin_rows;
     cw.cols = p.cwin_cols;
     cw.data = c.cur_win;
+    if (ref_axis_variants > 0) {
+        build_axis_tables(b, p, ref, rw, ref_u, ref_v, ref_axis_variants, reinterpret_cast<float4 *>(c.a0));
+    }
     if (window_inside(ref, rw.r_lo, rw.c_lo, rw.rows, rw.cols) && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols)) {
         stage_both_inside(b, p, ref, cur, rw, cw, c);
     } else {
@@ -690,76 +752,118 @@ __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams 
 // For METHOD == inverse the five reference-image fetches of a pixel do not change within a
 // level, so they are sampled once per level; the arithmetic per pixel is unchanged.
 // ---------------------------------------------------------------------------------------------
-template <int METHOD>
-__device__ __forceinline__ void nonfast_level_setup(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
-                                                    Carve &c) {
-#pragma unroll 2
+// SLOW = false: straight-line taps from the axis tables; a pixel whose taps are not all covered by
+// the staged window only raises `miss` (returned workgroup-wide).  SLOW = true: every sample goes
+// through the general sampler (LDS window or global memory, identical arithmetic).  The slow pass
+// is a separate loop, so the hot loop carries no fallback code.
+template <int METHOD, bool SLOW>
+__device__ __forceinline__ bool nonfast_setup_pass(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
+                                                   Carve &c) {
+    const float4 *tab = reinterpret_cast<const float4 *>(c.a0);
+    const int variants = (METHOD == FTK_METHOD_INVERSE) ? 3 : 1;
+    const float4 *rows0 = tab, *rowsm = tab + p.patch_rows, *rowsp = tab + 2 * p.patch_rows;
+    const float4 *cols0 = tab + variants * p.patch_rows, *colsm = cols0 + p.patch_cols, *colsp = cols0 + 2 * p.patch_cols;
+    bool miss = false;
     for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
         int prow, pcol;
         pixel_rc(p, pxi, prow, pcol);
-        const float row_i = (float)(prow - p.half_rows) + ref_v;
-        const float col_i = (float)(pcol - p.half_cols) + ref_u;
-        const Axis r0 = make_axis(row_i, ref.rows - 1), c0 = make_axis(col_i, ref.cols - 1);
-        float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f, i_ref;
-        bool ok, hit = true;
-        if (METHOD == FTK_METHOD_INVERSE) {
-            const Axis rm = make_axis(row_i - 1.0f, ref.rows - 1), rp = make_axis(row_i + 1.0f, ref.rows - 1);
-            const Axis cm = make_axis(col_i - 1.0f, ref.cols - 1), cp = make_axis(col_i + 1.0f, ref.cols - 1);
-            ok = r0.valid && c0.valid && rm.valid && rp.valid && cm.valid && cp.valid;
-            left = tap(rw, r0, cm, hit);
-            right = tap(rw, r0, cp, hit);
-            top = tap(rw, rm, c0, hit);
-            bottom = tap(rw, rp, c0, hit);
-            i_ref = tap(rw, r0, c0, hit);
-            if (ok && !hit) {  // a tap fell outside the staged window: same samples through the general path
-                sample(ref, rw, row_i, col_i - 1.0f, left);
-                sample(ref, rw, row_i, col_i + 1.0f, right);
-                sample(ref, rw, row_i - 1.0f, col_i, top);
-                sample(ref, rw, row_i + 1.0f, col_i, bottom);
-                sample(ref, rw, row_i, col_i, i_ref);
+        float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f, i_ref = 0.0f;
+        bool ok;
+        if (SLOW) {
+            const float row_i = (float)(prow - p.half_rows) + ref_v;
+            const float col_i = (float)(pcol - p.half_cols) + ref_u;
+            if (METHOD == FTK_METHOD_INVERSE) {
+                ok = sample(ref, rw, row_i, col_i - 1.0f, left) && sample(ref, rw, row_i, col_i + 1.0f, right) &&
+                     sample(ref, rw, row_i - 1.0f, col_i, top) && sample(ref, rw, row_i + 1.0f, col_i, bottom) && sample(ref, rw, row_i, col_i, i_ref);
+            } else {
+                ok = sample(ref, rw, row_i, col_i, i_ref);
             }
+        } else {
+            const float4 r0 = rows0[prow], c0 = cols0[pcol];
+            int flags;
+            if (METHOD == FTK_METHOD_INVERSE) {
+                const float4 rm = rowsm[prow], rp = rowsp[prow], cm = colsm[pcol], cp = colsp[pcol];
+                flags = __float_as_int(r0.w) & __float_as_int(c0.w) & __float_as_int(rm.w) & __float_as_int(rp.w) & __float_as_int(cm.w) &
+                        __float_as_int(cp.w);
+                left = tap_table(rw, r0, cm);
+                right = tap_table(rw, r0, cp);
+                top = tap_table(rw, rm, c0);
+                bottom = tap_table(rw, rp, c0);
+                i_ref = tap_table(rw, r0, c0);
+            } else {
+                flags = __float_as_int(r0.w) & __float_as_int(c0.w);
+                i_ref = tap_table(rw, r0, c0);
+            }
+            ok = (flags & 1) != 0;
+            miss = miss || (flags == 1);  // inside the image but not inside the staged window
+        }
+        if (METHOD == FTK_METHOD_INVERSE) {
             c.a1[pxi] = right - left;
             c.a2[pxi] = bottom - top;
-        } else {
-            ok = r0.valid && c0.valid;
-            i_ref = tap(rw, r0, c0, hit);
-            if (ok && !hit) {
-                sample(ref, rw, row_i, col_i, i_ref);
-            }
         }
         c.a3[pxi] = i_ref;
         c.flagsP[pxi] = ok ? 1 : 0;
     }
-    __syncthreads();
+    return block_any(b, miss, c.wave_cnt, SLOW ? 3u : 2u);
+}
+
+template <int METHOD>
+__device__ __forceinline__ void nonfast_level_setup(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
+                                                    Carve &c) {
+    if (nonfast_setup_pass<METHOD, false>(b, p, ref, rw, ref_u, ref_v, c)) {
+        nonfast_setup_pass<METHOD, true>(b, p, ref, rw, ref_u, ref_v, c);
+    }
 }
 
 // Completes the six fetches of one patch pixel for the current iteration.
-template <int METHOD>
+//   MODE 0: straight-line taps, a tap outside the window only raises `miss` (caller redoes the phase)
+//   MODE 1: every sample through the general sampler
+//   MODE 2: straight-line taps with a per-pixel redo through the general sampler (for warped patches,
+//           whose corner taps leave the window now and then: cheaper than redoing the whole phase)
+enum { kGatherHoisted = 0, kGatherGeneral = 1, kGatherInline = 2 };
+
+template <int METHOD, int MODE>
 __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &cw, const Carve &c, int pxi, float row_j, float col_j, float &gx,
-                                               float &gy, float &i_ref, float &i_cur) {
+                                               float &gy, float &i_ref, float &i_cur, bool &miss) {
     bool ok = c.flagsP[pxi] != 0;
     i_ref = c.a3[pxi];
+    i_cur = 0.0f;
+    if (MODE == kGatherGeneral) {
+        if (METHOD == FTK_METHOD_INVERSE) {
+            gx = c.a1[pxi];
+            gy = c.a2[pxi];
+            ok = sample(cur, cw, row_j, col_j, i_cur) && ok;
+        } else {
+            float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f;
+            const bool g = sample(cur, cw, row_j, col_j - 1.0f, left) && sample(cur, cw, row_j, col_j + 1.0f, right) &&
+                           sample(cur, cw, row_j - 1.0f, col_j, top) && sample(cur, cw, row_j + 1.0f, col_j, bottom) && sample(cur, cw, row_j, col_j, i_cur);
+            gx = right - left;
+            gy = bottom - top;
+            ok = ok && g;
+        }
+        return ok;
+    }
     const Axis r0 = make_axis(row_j, cur.rows - 1), c0 = make_axis(col_j, cur.cols - 1);
     bool hit = true;
+    bool valid;
     if (METHOD == FTK_METHOD_INVERSE) {
         gx = c.a1[pxi];
         gy = c.a2[pxi];
-        const bool valid = r0.valid && c0.valid;
+        valid = r0.valid && c0.valid;
         i_cur = tap(cw, r0, c0, hit);
-        if (valid && !hit) {
+        if (MODE == kGatherInline && valid && !hit) {
             sample(cur, cw, row_j, col_j, i_cur);
         }
-        ok = ok && valid;
     } else {
         const Axis rm = make_axis(row_j - 1.0f, cur.rows - 1), rp = make_axis(row_j + 1.0f, cur.rows - 1);
         const Axis cm = make_axis(col_j - 1.0f, cur.cols - 1), cp = make_axis(col_j + 1.0f, cur.cols - 1);
-        const bool valid = r0.valid && c0.valid && rm.valid && rp.valid && cm.valid && cp.valid;
+        valid = r0.valid && c0.valid && rm.valid && rp.valid && cm.valid && cp.valid;
         float left = tap(cw, r0, cm, hit);
         float right = tap(cw, r0, cp, hit);
         float top = tap(cw, rm, c0, hit);
         float bottom = tap(cw, rp, c0, hit);
         i_cur = tap(cw, r0, c0, hit);
-        if (valid && !hit) {
+        if (MODE == kGatherInline && valid && !hit) {
             sample(cur, cw, row_j, col_j - 1.0f, left);
             sample(cur, cw, row_j, col_j + 1.0f, right);
             sample(cur, cw, row_j - 1.0f, col_j, top);
@@ -768,9 +872,11 @@ __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &c
         }
         gx = right - left;
         gy = bottom - top;
-        ok = ok && valid;
     }
-    return ok;
+    if (MODE == kGatherHoisted) {
+        miss = miss || (valid && !hit);
+    }
+    return ok && valid;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -865,7 +971,7 @@ __device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, co
                                             BasicState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     FTK_STAMP_BEGIN(b);
     Win rw, cw;
-    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw, (METHOD == FTK_METHOD_INVERSE) ? 3 : 1);
     bool cw_staged = true;
     FTK_STAMP_END(b, 0);
     nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
@@ -875,30 +981,42 @@ __device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, co
         FTK_STAMP_BEGIN(b);
         ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
         FTK_STAMP_END(b, 2);
-        uint32_t n_valid = 0;
-        for (int base = 0; base < p.P; base += b.nt) {
-            const int pxi = base + b.tid;
-            bool ok = false;
-            if (pxi < p.P) {
-                int prow, pcol;
-                pixel_rc(p, pxi, prow, pcol);
-                const float row_j = (float)(prow - p.half_rows) + s.cur_v;
-                const float col_j = (float)(pcol - p.half_cols) + s.cur_u;
-                float fx, fy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, fx, fy, i_ref, i_cur);
-                const float ft = i_cur - i_ref;
-                c.terms[0 * p.Ppad + pxi] = ok ? fx * fx : 0.0f;
-                c.terms[1 * p.Ppad + pxi] = ok ? fy * fy : 0.0f;
-                c.terms[2 * p.Ppad + pxi] = ok ? fx * fy : 0.0f;
-                c.terms[3 * p.Ppad + pxi] = ok ? -(fx * ft) : 0.0f;
-                c.terms[4 * p.Ppad + pxi] = ok ? -(fy * ft) : 0.0f;
+        // phase A; slow == true_type redoes it through the general sampler when a tap left the window
+        auto phase_a = [&](auto slow, bool &miss) -> uint32_t {
+            constexpr bool kSlow = decltype(slow)::value;
+            uint32_t wave_valid = 0;
+            for (int base = 0; base < p.P; base += b.nt) {
+                const int pxi = base + b.tid;
+                bool ok = false;
+                if (pxi < p.P) {
+                    int prow, pcol;
+                    pixel_rc(p, pxi, prow, pcol);
+                    const float row_j = (float)(prow - p.half_rows) + s.cur_v;
+                    const float col_j = (float)(pcol - p.half_cols) + s.cur_u;
+                    float fx, fy, i_ref, i_cur;
+                    ok = nonfast_gather<METHOD, kSlow ? kGatherGeneral : kGatherHoisted>(cur, cw, c, pxi, row_j, col_j, fx, fy, i_ref, i_cur, miss);
+                    const float ft = i_cur - i_ref;
+                    c.terms[0 * p.Ppad + pxi] = ok ? fx * fx : 0.0f;
+                    c.terms[1 * p.Ppad + pxi] = ok ? fy * fy : 0.0f;
+                    c.terms[2 * p.Ppad + pxi] = ok ? fx * fy : 0.0f;
+                    c.terms[3 * p.Ppad + pxi] = ok ? -(fx * ft) : 0.0f;
+                    c.terms[4 * p.Ppad + pxi] = ok ? -(fy * ft) : 0.0f;
+                }
+                wave_valid += (uint32_t)__popcll(__ballot(ok));
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
-        }
+            return wave_valid;
+        };
+        bool miss = false;
+        uint32_t n_valid = phase_a(std::false_type{}, miss);
         FTK_STAMP_END(b, 3);
         publish_count(b, n_valid, c.wave_cnt, iter);
+        if (block_any(b, miss, c.wave_cnt, iter & 1u)) {
+            n_valid = phase_a(std::true_type{}, miss);
+            publish_count(b, n_valid, c.wave_cnt, iter);
+            __syncthreads();
+        }
         FTK_STAMP_END(b, 4);
-        chain_then(b, c.terms, 5, p.Ppad, c.sums, true, [&]() {
+        chain_then(b, c.terms, 5, p.Ppad, c.sums, false, [&]() {
             float m[2][2];
             float bb[2], sol[2];
             m[0][0] = c.sums[0];
@@ -1112,13 +1230,14 @@ template <int METHOD>
 __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
                                              AffineState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     Win rw, cw;
-    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw, (METHOD == FTK_METHOD_INVERSE) ? 3 : 1);
     bool cw_staged = true;
     nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
         ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
         uint32_t n_valid = 0;
+        bool miss_unused = false;
         for (int base = 0; base < p.P; base += b.nt) {
             const int pxi = base + b.tid;
             bool ok = false;
@@ -1132,7 +1251,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
                 const float row_j = warped_y + s.cur_v;
                 const float col_j = warped_x + s.cur_u;
                 float dx, dy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur);
+                ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
                 const float dt = i_cur - i_ref;
                 affine_hessian_terms(p, c.terms, pxi, ok, col_j, row_j, dx, dy);
                 affine_bias_terms(p, c.terms, A_B0, pxi, ok, dt, col_j, row_j, dx, dy);
@@ -1354,7 +1473,7 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
     Win rw, cw;
     float level_centre_u, level_centre_v;
     se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
-    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw, (METHOD == FTK_METHOD_INVERSE) ? 3 : 1);
     bool cw_staged = true;
     nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
     uint8_t *okflags = c.flagsE;  // per-iteration validity of a pixel (all six fetches)
@@ -1366,6 +1485,7 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
         ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
         // pass 1 (:140-184): validity mask and the two patch means (sequential sums)
         uint32_t n_valid = 0;
+        bool miss_unused = false;
         for (int base = 0; base < p.P; base += b.nt) {
             const int pxi = base + b.tid;
             bool ok = false;
@@ -1377,7 +1497,7 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
                 float row_j, col_j;
                 se2_apply(s, col_i, row_i, col_j, row_j);
                 float gx, gy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD>(cur, cw, c, pxi, row_j, col_j, gx, gy, i_ref, i_cur);
+                ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, gx, gy, i_ref, i_cur, miss_unused);
                 if (METHOD != FTK_METHOD_INVERSE) {
                     c.a1[pxi] = gx;
                     c.a2[pxi] = gy;
@@ -1586,13 +1706,12 @@ struct ChainCount<FTK_MODEL_LSSD> {
 
 constexpr int kMaxWaves = 4;
 
-// Optional register cap (build-time experiment knob): -DFTK_WAVES_PER_EU=n asks the compiler to fit
-// n waves per SIMD so that more feature workgroups are co-resident per CU.
-#ifdef FTK_WAVES_PER_EU
-#define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU, FTK_WAVES_PER_EU)))
-#else
-#define FTK_EU_ATTR
+// Register cap: the compiler is asked to fit FTK_WAVES_PER_EU waves per SIMD so that enough feature
+// workgroups are co-resident per CU (the kernel is issue / latency bound, not register bound).
+#ifndef FTK_WAVES_PER_EU
+#define FTK_WAVES_PER_EU 4  // <= 128 VGPRs: 8 two-wave (or 4 four-wave) feature workgroups per CU
 #endif
+#define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU)))
 
 template <int MODEL, int METHOD>
 __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
