@@ -29,6 +29,9 @@ struct ftk_context {
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    // BRIEF sampling pattern resident on the device, cached per (n_bits, half)
+    int8_t *brief_pattern = nullptr;
+    int32_t brief_bits = 0, brief_half = 0;
 };
 
 struct ftk_pyramid {
@@ -308,6 +311,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->pinned) {
         (void)hipHostFree(ctx->pinned);
+    }
+    if (ctx->brief_pattern) {
+        (void)hipFree(ctx->brief_pattern);
     }
     if (ctx->owns_stream) {
         (void)hipStreamDestroy(ctx->stream);
@@ -641,6 +647,99 @@ int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t l
     FTK_HIP(ctx, hipMemcpyAsync(ex_patch, d_patch, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipMemcpyAsync(valid, d_valid, n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipMemcpyAsync(valid_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- BRIEF descriptors (producer of the matcher's input) ----------------------------------- */
+
+static int ensure_brief_pattern(ftk_context *ctx, int32_t n_bits, int32_t half) {
+    if (ctx->brief_pattern && ctx->brief_bits == n_bits && ctx->brief_half == half) {
+        return FTK_OK;
+    }
+    if (ctx->brief_pattern) {
+        FTK_HIP(ctx, hipFree(ctx->brief_pattern));
+        ctx->brief_pattern = nullptr;
+    }
+    // LCG pattern: x <- 1664525 x + 1013904223 (seed 0x2545F491), offset = ((x >> 8) mod (2 half + 1)) - half
+    std::vector<int8_t> pattern((size_t)4 * n_bits);
+    uint32_t state = 0x2545F491u;
+    const uint32_t span = (uint32_t)(2 * half + 1);
+    for (auto &v : pattern) {
+        state = state * 1664525u + 1013904223u;
+        v = (int8_t)((int32_t)((state >> 8) % span) - half);
+    }
+    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->brief_pattern), pattern.size()));
+    FTK_HIP(ctx, hipMemcpy(ctx->brief_pattern, pattern.data(), pattern.size(), hipMemcpyHostToDevice));
+    ctx->brief_bits = n_bits;
+    ctx->brief_half = half;
+    return FTK_OK;
+}
+
+int ftk_brief_compute_device(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *d_uv, int32_t n, int32_t n_bits,
+                             int32_t half_patch, uint32_t *d_words) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "brief_compute_device: null context");
+    }
+    if (!image || level < 0 || level >= image->n_levels || n < 0 || n_bits <= 0 || half_patch <= 0 || half_patch > 63) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute_device: bad arguments (n %d, bits %d, half %d)", n, n_bits, half_patch);
+    }
+    if (n == 0) {
+        return FTK_OK;
+    }
+    if (!d_uv || !d_words) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute_device: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = ensure_brief_pattern(ctx, n_bits, half_patch);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    ftk::BriefParams p;
+    p.img = image->levels[level];
+    p.uv = d_uv;
+    p.words = d_words;
+    p.pattern = ctx->brief_pattern;
+    p.n = n;
+    p.n_bits = n_bits;
+    p.n_words = (n_bits + 31) / 32;
+    p.half = half_patch;
+    FTK_HIP(ctx, ftk::brief_launch(p, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *uv, int32_t n, int32_t n_bits,
+                      int32_t half_patch, uint32_t *words) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "brief_compute: null context");
+    }
+    if (n < 0 || n_bits <= 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute: bad sizes");
+    }
+    if (n == 0) {
+        return FTK_OK;
+    }
+    if (!uv || !words) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n_words = (size_t)(n_bits + 31) / 32;
+    const size_t uv_bytes = align_up(sizeof(float) * 2 * (size_t)n, 256);
+    const size_t w_bytes = align_up(sizeof(uint32_t) * n_words * (size_t)n, 256);
+    int rc = ensure_scratch(ctx, uv_bytes + w_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_uv = reinterpret_cast<float *>(base);
+    uint32_t *d_words = reinterpret_cast<uint32_t *>(base + uv_bytes);
+    FTK_HIP(ctx, hipMemcpyAsync(d_uv, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = ftk_brief_compute_device(ctx, image, level, d_uv, n, n_bits, half_patch, d_words);
+    if (rc != FTK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(words, d_words, sizeof(uint32_t) * n_words * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
 }

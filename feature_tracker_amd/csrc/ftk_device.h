@@ -69,6 +69,15 @@ struct MatchParams {
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 
+struct BriefParams {
+    DevImage img;
+    const float *uv;
+    uint32_t *words;        // n * n_words, bit i of a descriptor in bit (i % 32) of word i / 32
+    const int8_t *pattern;  // 4 offsets per bit, device memory
+    int32_t n, n_bits, n_words, half;
+};
+hipError_t brief_launch(const BriefParams &p, hipStream_t stream);
+
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream);
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);

@@ -105,3 +105,10 @@ def hamming_match_device(ctx: Context, ref_words, cur_words, n_bits: int, max_di
         None if cur_uv is None else C.c_void_p(cur_uv.data_ptr()), int(max_col), int(max_row), C.c_void_p(index_pairs.data_ptr()),
         None if workspace is None else C.c_void_p(workspace.data_ptr()))
     N.check(rc, ctx.handle)
+
+
+def brief_compute_device(ctx: Context, image_pyr: ImagePyramid, uv, n_bits: int, half_patch: int, words_out, level: int = 0):
+    """BRIEF descriptors of CUDA-resident features straight into packed CUDA words ([n, ceil(n_bits/32)] int32)."""
+    rc = N.lib().ftk_brief_compute_device(ctx.handle, image_pyr.handle, int(level), C.c_void_p(uv.data_ptr()), uv.shape[0], int(n_bits),
+                                          int(half_patch), C.c_void_p(words_out.data_ptr()))
+    N.check(rc, ctx.handle)

@@ -1,47 +1,50 @@
+// descriptor_brief.cpp — BriefDescriptor::Compute on the device (ftk_brief_compute); the per-bit
+// containers the reference's callers expect are unpacked from the device's packed words.
 #include "descriptor_brief.h"
 
-namespace feature_detector {
+#include <string>
 
-void BriefDescriptor::CreatePattern() {
-    pattern_length_ = options_.kLength;
-    pattern_half_ = options_.kHalfPatchSize;
-    pattern_.resize(size_t(pattern_length_) * 4);
-    uint32_t state = 0x2545F491u;
-    const int32_t span = 2 * pattern_half_ + 1;
-    for (auto &v : pattern_) {
-        state = state * 1664525u + 1013904223u;
-        v = static_cast<int8_t>(int32_t((state >> 8) % uint32_t(span)) - pattern_half_);
-    }
-}
+#include "device_runtime.h"
+#include "ftk.h"
+#include "slam_log_reporter.h"
+
+namespace feature_detector {
 
 bool BriefDescriptor::Compute(const GrayImage &image, const std::vector<Vec2> &pixel_uv, std::vector<BriefType> &descriptor) {
     if (image.data() == nullptr || options_.kLength <= 0 || options_.kHalfPatchSize <= 0) {
         return false;
     }
-    if (pattern_length_ != options_.kLength || pattern_half_ != options_.kHalfPatchSize) {
-        CreatePattern();
-    }
-    const int32_t rows = image.rows(), cols = image.cols();
-    auto smooth = [&](int32_t r, int32_t c) {
-        int32_t s = 0;
-        for (int32_t dr = -1; dr <= 1; ++dr) {
-            for (int32_t dc = -1; dc <= 1; ++dc) {
-                s += image.GetPixelValueNoCheck(r + dr, c + dc);
-            }
-        }
-        return s;
-    };
     descriptor.clear();
+    if (pixel_uv.empty()) {
+        return true;
+    }
+    std::string error;
+    ftk_context *ctx = feature_tracker::device::SharedContext(&error);
+    if (ctx == nullptr) {
+        ReportError("[BriefDescriptor] " << error);
+        return false;
+    }
+    ftk_image level = {image.data(), image.rows(), image.cols()};
+    ftk_pyramid *dev = nullptr;
+    if (ftk_pyramid_upload(ctx, &level, 1, &dev) != FTK_OK) {
+        ReportError("[BriefDescriptor] " << ftk_last_error(ctx));
+        return false;
+    }
+    const int32_t n = static_cast<int32_t>(pixel_uv.size());
+    const int32_t n_words = (options_.kLength + 31) / 32;
+    std::vector<uint32_t> words(static_cast<size_t>(n) * n_words);
+    const int rc = ftk_brief_compute(ctx, dev, 0, pixel_uv[0].data(), n, options_.kLength, options_.kHalfPatchSize, words.data());
+    ftk_pyramid_destroy(dev);
+    if (rc != FTK_OK) {
+        ReportError("[BriefDescriptor] " << ftk_last_error(ctx));
+        return false;
+    }
     descriptor.reserve(pixel_uv.size());
-    const int32_t margin = pattern_half_ + 1;
-    for (const Vec2 &uv : pixel_uv) {
-        BriefType bits(size_t(pattern_length_), false);
-        const int32_t r = int32_t(uv.y() + 0.5f), c = int32_t(uv.x() + 0.5f);
-        if (r >= margin && c >= margin && r < rows - margin && c < cols - margin) {
-            for (int32_t i = 0; i < pattern_length_; ++i) {
-                const int8_t *o = &pattern_[size_t(i) * 4];
-                bits[i] = smooth(r + o[0], c + o[1]) < smooth(r + o[2], c + o[3]);
-            }
+    for (int32_t f = 0; f < n; ++f) {
+        BriefType bits(static_cast<size_t>(options_.kLength), false);
+        const uint32_t *w = &words[static_cast<size_t>(f) * n_words];
+        for (int32_t i = 0; i < options_.kLength; ++i) {
+            bits[i] = ((w[i >> 5] >> (i & 31)) & 1u) != 0;
         }
         descriptor.emplace_back(std::move(bits));
     }

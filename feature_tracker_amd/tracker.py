@@ -290,6 +290,51 @@ def pack_brief(bits: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(packed).view("<u4").reshape(n, words)
 
 
+def unpack_brief(words: np.ndarray, n_bits: int) -> np.ndarray:
+    """(n, n_words) uint32 -> per-bit (n, n_bits) uint8, the inverse of pack_brief."""
+    words = np.ascontiguousarray(words, dtype="<u4")
+    bits = np.unpackbits(words.view(np.uint8).reshape(words.shape[0], -1), axis=1, bitorder="little")
+    return np.ascontiguousarray(bits[:, :n_bits])
+
+
+class BriefDescriptorOptions:
+    def __init__(self):
+        self.kLength = 256
+        self.kHalfPatchSize = 8
+
+
+class BriefDescriptor:
+    """feature_detector::BriefDescriptor (un-vendored Feature_Detector; used by
+    test/test_descriptor_matcher_brief.cpp:70-76) computed on the device with this repo's sampling
+    pattern.  ``Compute`` returns the per-bit container the reference produces; ``compute_packed``
+    returns the words ftk_hamming_match reads."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+        self._options = BriefDescriptorOptions()
+
+    def options(self) -> BriefDescriptorOptions:
+        return self._options
+
+    def compute_packed(self, image, pixel_uv) -> np.ndarray:
+        ctx = self._ctx or default_context()
+        uv = np.ascontiguousarray(pixel_uv, dtype=np.float32).reshape(-1, 2)
+        n, n_bits = uv.shape[0], int(self._options.kLength)
+        words = np.zeros((n, (n_bits + 31) // 32), dtype=np.uint32)
+        if n == 0:
+            return words
+        pyr = image if isinstance(image, ImagePyramid) else ImagePyramid.from_host_levels([image], ctx)
+        N.check(N.lib().ftk_brief_compute(ctx.handle, pyr.handle, 0, _ptr(uv), n, n_bits, int(self._options.kHalfPatchSize), _ptr(words)),
+                ctx.handle)
+        return words
+
+    def Compute(self, image, pixel_uv):
+        """Returns (ok, descriptors) with descriptors a (n, kLength) 0/1 uint8 array."""
+        if int(self._options.kLength) <= 0 or int(self._options.kHalfPatchSize) <= 0:
+            return False, np.zeros((0, 0), np.uint8)
+        return True, unpack_brief(self.compute_packed(image, pixel_uv), int(self._options.kLength))
+
+
 class DescriptorMatcherOptions:
     """descriptor_matcher.h:16-20."""
 

@@ -146,6 +146,22 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
 int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t level, float u, float v, int32_t ex_rows, int32_t ex_cols,
                              float *ex_patch, uint8_t *valid, uint32_t *valid_count);
 
+/* ---- BRIEF descriptors (the step in front of the matcher) ------ */
+
+/*
+ * Replaces feature_detector::BriefDescriptor::Compute (un-vendored Feature_Detector repo; call
+ * sites test/test_descriptor_matcher_brief.cpp:70-76, kLength = 256, kHalfPatchSize = 8) for the
+ * sampling pattern this repo defines (oracle/oracle_brief.c): bit i = S(p + a_i) < S(p + b_i) on
+ * the 3x3 box sums S, p = the feature rounded to the pixel grid, offsets from a fixed-seed LCG.
+ * Output is bit-packed — ceil(n_bits / 32) uint32 words per descriptor, bit i in bit (i % 32) of
+ * word i / 32 — i.e. exactly what ftk_hamming_match* reads, so on the device path the descriptors
+ * never visit the host.  Features closer than half_patch + 1 px to the border get all-zero words.
+ */
+int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *uv, int32_t n, int32_t n_bits,
+                      int32_t half_patch, uint32_t *words);
+int ftk_brief_compute_device(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *d_uv, int32_t n, int32_t n_bits,
+                             int32_t half_patch, uint32_t *d_words);
+
 /* ---- descriptor matcher ------------------------------------------------------------------ */
 
 /*

@@ -107,6 +107,10 @@ int orc_nearby_match_bits(const uint8_t *ref_bits, int32_t n_ref, const uint8_t 
 /* descriptor_matcher.h:135-157 */
 int orc_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const float *cur_uv, int32_t n_cur, float *matched_uv, uint8_t *status);
 
+/* BRIEF descriptor producer of the matcher (normative definition in oracle_brief.c). */
+void orc_brief_pattern(int32_t n_bits, int32_t half, int8_t *pattern);
+int orc_brief_compute(const orc_image *img, const float *uv, int32_t n, int32_t n_bits, int32_t half, uint8_t *bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,12 @@ def fill_matched_pixels(index_pairs, cur_uv, status=None):
     lib().orc_fill_matched_pixels(index_pairs.ctypes.data_as(C.c_void_p), n_ref, cur_uv.ctypes.data_as(C.c_void_p), cur_uv.shape[0],
                                   matched.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
     return matched, st
+
+
+def brief_compute(image, uv, n_bits=256, half=8):
+    """Per-bit BRIEF descriptors (n, n_bits) uint8 of the repo's normative definition (oracle_brief.c)."""
+    arr, keep = _images([image])
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    bits = np.zeros((uv.shape[0], n_bits), dtype=np.uint8)
+    ok = lib().orc_brief_compute(arr, uv.ctypes.data_as(C.c_void_p), uv.shape[0], int(n_bits), int(half), bits.ctypes.data_as(C.c_void_p))
+    return bool(ok), bits

@@ -236,3 +236,20 @@ def test_oracle_reproduces_golden(oracle, name):
     for key, val in got.items():
         exp = z["out_" + key]
         assert np.array_equal(np.asarray(val).view(np.uint8), exp.view(np.uint8)), f"{name}: {key}"
+
+
+def test_brief_oracle_known_answers(oracle):
+    """Hand-checkable BRIEF cases: a constant image gives all-zero bits (strict '<'), a horizontal ramp gives bit = (dc1 < dc2)."""
+    import ctypes as C
+    flat = np.full((40, 40), 90, np.uint8)
+    ok, bits = oracle.brief_compute(flat, np.float32([[20, 20]]), 256, 8)
+    assert ok and not bits.any()
+    ramp = np.tile((np.arange(40) * 3).astype(np.uint8), (40, 1))
+    ok, bits = oracle.brief_compute(ramp, np.float32([[20.4, 19.6], [8.4, 20], [8.5, 20]]), 64, 8)
+    pattern = np.zeros(4 * 64, np.int8)
+    oracle.lib().orc_brief_pattern(64, 8, pattern.ctypes.data_as(C.c_void_p))
+    pattern = pattern.reshape(64, 4)
+    assert pattern.min() >= -8 and pattern.max() <= 8
+    assert np.array_equal(bits[0], (pattern[:, 1] < pattern[:, 3]).astype(np.uint8))
+    # margin = half + 1 = 9: u = 8.4 rounds to column 8 (outside -> all zero), u = 8.5 rounds to column 9 (inside)
+    assert not bits[1].any() and bits[2].any()
