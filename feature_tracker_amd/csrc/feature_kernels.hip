@@ -68,7 +68,138 @@ __global__ void __launch_bounds__(64) brief_kernel(const BriefParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Harris corners (definition: oracle/oracle_harris.c).  Four streaming passes over the image:
+// Sobel gradients (int16), 5x5 structure tensor + response (fp32, integer sums are exact so the
+// summation order is free), separable window maximum of a sortable 64-bit key
+// (response bits << 32 | ~pixel index), and compaction of the survivors.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHarrisHalf = 2;
+constexpr int kHarrisBorder = 11;
+
+__global__ void __launch_bounds__(256) harris_gradient_kernel(DevImage im, short *gx, short *gy) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)im.rows * im.cols;
+    if (i >= total) {
+        return;
+    }
+    const int r = (int)(i / im.cols), c = (int)(i - (long long)r * im.cols);
+    int vx = 0, vy = 0;
+    if (r >= 1 && c >= 1 && r < im.rows - 1 && c < im.cols - 1) {
+        const uint8_t *p = im.data + (long long)r * im.cols + c;
+        const int tl = p[-im.cols - 1], tc = p[-im.cols], tr = p[-im.cols + 1];
+        const int ml = p[-1], mr = p[1];
+        const int bl = p[im.cols - 1], bc = p[im.cols], br = p[im.cols + 1];
+        vx = (tr + 2 * mr + br) - (tl + 2 * ml + bl);
+        vy = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
+    }
+    gx[i] = (short)vx;
+    gy[i] = (short)vy;
+}
+
+__device__ __forceinline__ unsigned sortable_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void __launch_bounds__(256) harris_response_kernel(int rows, int cols, const short *gx, const short *gy, float min_response,
+                                                              float *response, unsigned long long *key) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows * cols;
+    if (i >= total) {
+        return;
+    }
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    float resp = 0.0f;
+    unsigned long long k = 0ull;
+    if (r >= kHarrisBorder && c >= kHarrisBorder && r < rows - kHarrisBorder && c < cols - kHarrisBorder) {
+        int a = 0, b = 0, d = 0;
+        for (int dr = -kHarrisHalf; dr <= kHarrisHalf; ++dr) {
+            const long long base = (long long)(r + dr) * cols + c;
+#pragma unroll
+            for (int dc = -kHarrisHalf; dc <= kHarrisHalf; ++dc) {
+                const int x = gx[base + dc], y = gy[base + dc];
+                a += x * x;
+                b += x * y;
+                d += y * y;
+            }
+        }
+        const float fa = (float)a, fb = (float)b, fd = (float)d;
+        const float det = fa * fd - fb * fb;
+        const float tr = fa + fd;
+        resp = (det - (0.04f * tr) * tr) * 1e-6f;
+        if (resp > min_response) {
+            k = ((unsigned long long)sortable_bits(resp) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    if (response) {
+        response[i] = resp;
+    }
+    key[i] = k;
+}
+
+// out[r][c] = max over |offset| <= reach of in along a row (horizontal != 0) or a column
+__global__ void __launch_bounds__(256) harris_window_max_kernel(int rows, int cols, int reach, int horizontal, const unsigned long long *in,
+                                                                unsigned long long *out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows * cols;
+    if (i >= total) {
+        return;
+    }
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    unsigned long long m = 0ull;
+    if (horizontal) {
+        const int lo = max(c - reach, 0), hi = min(c + reach, cols - 1);
+        const unsigned long long *row = in + (long long)r * cols;
+        for (int cc = lo; cc <= hi; ++cc) {
+            const unsigned long long v = row[cc];
+            m = v > m ? v : m;
+        }
+    } else {
+        const int lo = max(r - reach, 0), hi = min(r + reach, rows - 1);
+        for (int rr = lo; rr <= hi; ++rr) {
+            const unsigned long long v = in[(long long)rr * cols + c];
+            m = v > m ? v : m;
+        }
+    }
+    out[i] = m;
+}
+
+__global__ void __launch_bounds__(256) harris_collect_kernel(long long total, const unsigned long long *key, const unsigned long long *window_max,
+                                                             unsigned long long *list, unsigned *count, unsigned capacity) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) {
+        return;
+    }
+    const unsigned long long k = key[i];
+    if (k != 0ull && k == window_max[i]) {
+        const unsigned slot = atomicAdd(count, 1u);
+        if (slot < capacity) {
+            list[slot] = k;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t harris_launch(const HarrisParams &p, hipStream_t stream) {
+    const long long total = (long long)p.img.rows * p.img.cols;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(harris_gradient_kernel, dim3(blocks), dim3(256), 0, stream, p.img, p.gx, p.gy);
+    hipLaunchKernelGGL(harris_response_kernel, dim3(blocks), dim3(256), 0, stream, p.img.rows, p.img.cols, p.gx, p.gy, p.min_response, p.response,
+                       p.key);
+    if (p.list) {
+        const int reach = (p.min_distance > 1 ? p.min_distance : 1) - 1;
+        hipLaunchKernelGGL(harris_window_max_kernel, dim3(blocks), dim3(256), 0, stream, p.img.rows, p.img.cols, reach, 1, p.key, p.tmp);
+        hipLaunchKernelGGL(harris_window_max_kernel, dim3(blocks), dim3(256), 0, stream, p.img.rows, p.img.cols, reach, 0, p.tmp, p.wmax);
+        hipError_t e = hipMemsetAsync(p.count, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) {
+            return e;
+        }
+        hipLaunchKernelGGL(harris_collect_kernel, dim3(blocks), dim3(256), 0, stream, total, p.key, p.wmax, p.list, p.count, p.capacity);
+    }
+    return hipGetLastError();
+}
 
 hipError_t brief_launch(const BriefParams &p, hipStream_t stream) {
     if (p.n <= 0) {

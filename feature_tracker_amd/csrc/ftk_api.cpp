@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -741,6 +742,102 @@ int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
     }
     FTK_HIP(ctx, hipMemcpyAsync(words, d_words, sizeof(uint32_t) * n_words * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- Harris corners (producer of the trackers' input) -------------------------------------- */
+
+static int harris_run(ftk_context *ctx, const ftk_pyramid *image, int32_t level, int32_t min_distance, float min_response, float *response_out,
+                      std::vector<unsigned long long> *survivors) {
+    if (!image || level < 0 || level >= image->n_levels) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris: bad image / level");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const DevImage img = image->levels[level];
+    const size_t px = (size_t)img.rows * img.cols;
+    const size_t capacity = px;  // worst case (min_distance 1): every candidate is its own window maximum
+    const size_t g_bytes = align_up(sizeof(short) * px, 256), f_bytes = align_up(sizeof(float) * px, 256);
+    const size_t k_bytes = align_up(sizeof(unsigned long long) * px, 256), l_bytes = align_up(sizeof(unsigned long long) * capacity, 256);
+    const int rc = ensure_scratch(ctx, 2 * g_bytes + f_bytes + 3 * k_bytes + l_bytes + 256);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    ftk::HarrisParams p;
+    p.img = img;
+    p.gx = reinterpret_cast<short *>(base);
+    p.gy = reinterpret_cast<short *>(base + g_bytes);
+    p.response = response_out ? reinterpret_cast<float *>(base + 2 * g_bytes) : nullptr;
+    p.key = reinterpret_cast<unsigned long long *>(base + 2 * g_bytes + f_bytes);
+    p.tmp = p.key + k_bytes / sizeof(unsigned long long);
+    p.wmax = p.tmp + k_bytes / sizeof(unsigned long long);
+    p.list = survivors ? p.wmax + k_bytes / sizeof(unsigned long long) : nullptr;
+    p.count = reinterpret_cast<unsigned *>(base + 2 * g_bytes + f_bytes + 3 * k_bytes + l_bytes);
+    p.capacity = (unsigned)capacity;
+    p.min_distance = min_distance;
+    p.min_response = min_response;
+    FTK_HIP(ctx, ftk::harris_launch(p, ctx->stream));
+    if (response_out) {
+        FTK_HIP(ctx, hipMemcpyAsync(response_out, p.response, sizeof(float) * px, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (survivors) {
+        unsigned count = 0;
+        FTK_HIP(ctx, hipMemcpyAsync(&count, p.count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (count > p.capacity) {
+            return fail(ctx, FTK_E_UNSUPPORTED, "harris: %u survivors exceed the list capacity %u", count, p.capacity);
+        }
+        survivors->resize(count);
+        if (count > 0) {
+            FTK_HIP(ctx, hipMemcpy(survivors->data(), p.list, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost));
+        }
+    } else {
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t level, float *response) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_response: null context");
+    }
+    if (!response) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris_response: null buffer");
+    }
+    return harris_run(ctx, image, level, 1, 0.0f, response, nullptr);
+}
+
+int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level, int32_t max_count, int32_t min_distance, float min_response,
+                      float *uv, int32_t *n_out) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_detect: null context");
+    }
+    if (!n_out || max_count < 0 || (max_count > 0 && !uv)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris_detect: bad output arguments");
+    }
+    *n_out = 0;
+    if (!image || level < 0 || level >= image->n_levels) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris_detect: bad image / level");
+    }
+    const DevImage img = image->levels[level];
+    if (max_count == 0 || img.rows < 23 || img.cols < 23) {
+        return FTK_OK;
+    }
+    std::vector<unsigned long long> survivors;
+    const int rc = harris_run(ctx, image, level, min_distance, min_response, nullptr, &survivors);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    // key order == (response descending, pixel index ascending): the final top-N selection is a sort of
+    // a few thousand 64-bit keys on the host
+    std::sort(survivors.begin(), survivors.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
+    const size_t n = survivors.size() < (size_t)max_count ? survivors.size() : (size_t)max_count;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(survivors[i] & 0xFFFFFFFFull);
+        uv[2 * i] = (float)(idx % (unsigned)img.cols);
+        uv[2 * i + 1] = (float)(idx / (unsigned)img.cols);
+    }
+    *n_out = (int32_t)n;
     return FTK_OK;
 }
 

@@ -78,6 +78,19 @@ struct BriefParams {
 };
 hipError_t brief_launch(const BriefParams &p, hipStream_t stream);
 
+struct HarrisParams {
+    DevImage img;
+    short *gx, *gy;                  // rows*cols each
+    float *response;                 // rows*cols or null
+    unsigned long long *key, *tmp, *wmax;  // rows*cols each (tmp / wmax unused when list is null)
+    unsigned long long *list;        // survivors (keys), capacity entries; null = response only
+    unsigned *count;
+    unsigned capacity;
+    int32_t min_distance;
+    float min_response;
+};
+hipError_t harris_launch(const HarrisParams &p, hipStream_t stream);
+
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream);
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);

@@ -297,6 +297,42 @@ def unpack_brief(words: np.ndarray, n_bits: int) -> np.ndarray:
     return np.ascontiguousarray(bits[:, :n_bits])
 
 
+class HarrisOptions:
+    def __init__(self):
+        self.kMinFeatureDistance = 20
+        self.kMinValidResponse = 40.0
+
+
+class FeaturePointHarrisDetector:
+    """feature_detector::FeaturePointHarrisDetector (un-vendored Feature_Detector; used by
+    test/test_optical_flow.cpp:34-39) on the device, with this repo's definition (oracle/oracle_harris.c)."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+        self._options = HarrisOptions()
+
+    def options(self) -> HarrisOptions:
+        return self._options
+
+    def DetectGoodFeatures(self, image, needed_feature_num: int):
+        """Returns (ok, features) with features an (n, 2) float32 array of (u, v), strongest first."""
+        ctx = self._ctx or default_context()
+        pyr = image if isinstance(image, ImagePyramid) else ImagePyramid.from_host_levels([image], ctx)
+        uv = np.zeros((max(1, int(needed_feature_num)), 2), dtype=np.float32)
+        n = C.c_int32(0)
+        N.check(N.lib().ftk_harris_detect(ctx.handle, pyr.handle, 0, int(needed_feature_num), int(self._options.kMinFeatureDistance),
+                                          float(self._options.kMinValidResponse), _ptr(uv), C.byref(n)), ctx.handle)
+        return True, uv[: n.value].copy()
+
+    def response(self, image) -> np.ndarray:
+        ctx = self._ctx or default_context()
+        pyr = image if isinstance(image, ImagePyramid) else ImagePyramid.from_host_levels([image], ctx)
+        _, rows, cols = pyr.level_desc(0)
+        out = np.zeros((rows, cols), dtype=np.float32)
+        N.check(N.lib().ftk_harris_response(ctx.handle, pyr.handle, 0, _ptr(out)), ctx.handle)
+        return out
+
+
 class BriefDescriptorOptions:
     def __init__(self):
         self.kLength = 256

@@ -162,6 +162,21 @@ int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
 int ftk_brief_compute_device(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *d_uv, int32_t n, int32_t n_bits,
                              int32_t half_patch, uint32_t *d_words);
 
+/* ---- Harris corners (the step in front of the trackers) -------- */
+
+/*
+ * Replaces feature_detector::FeaturePointHarrisDetector::DetectGoodFeatures (un-vendored
+ * Feature_Detector repo; call sites test/test_optical_flow.cpp:34-39: kMinFeatureDistance = 25,
+ * kMinValidResponse = 40, at most 300 features) for the definition in oracle/oracle_harris.c:
+ * 3x3 Sobel, 5x5 structure tensor in exact integers, response = (det - 0.04 tr^2) * 1e-6 in fp32,
+ * candidates above min_response, window-maximum suppression over (2*min_distance - 1)^2, strongest
+ * max_count survivors as (u, v) = (col, row).  uv holds 2*max_count floats; *n_out <= max_count.
+ */
+int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level, int32_t max_count, int32_t min_distance, float min_response,
+                      float *uv, int32_t *n_out);
+/* The response map alone (rows*cols floats, host memory; 0 outside the 11-pixel border). */
+int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t level, float *response);
+
 /* ---- descriptor matcher ------------------------------------------------------------------ */
 
 /*

@@ -111,6 +111,10 @@ int orc_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const flo
 void orc_brief_pattern(int32_t n_bits, int32_t half, int8_t *pattern);
 int orc_brief_compute(const orc_image *img, const float *uv, int32_t n, int32_t n_bits, int32_t half, uint8_t *bits);
 
+/* Harris corner detector feeding the trackers (normative definition in oracle_harris.c). */
+void orc_harris_response(const orc_image *img, float *response);
+int32_t orc_harris_detect(const orc_image *img, int32_t max_count, int32_t min_distance, float min_response, float *uv_out);
+
 #ifdef __cplusplus
 }
 #endif

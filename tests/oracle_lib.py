@@ -220,3 +220,17 @@ def brief_compute(image, uv, n_bits=256, half=8):
     bits = np.zeros((uv.shape[0], n_bits), dtype=np.uint8)
     ok = lib().orc_brief_compute(arr, uv.ctypes.data_as(C.c_void_p), uv.shape[0], int(n_bits), int(half), bits.ctypes.data_as(C.c_void_p))
     return bool(ok), bits
+
+
+def harris_response(image):
+    arr, keep = _images([image])
+    out = np.zeros(keep[0].shape, dtype=np.float32)
+    lib().orc_harris_response(arr, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def harris_detect(image, max_count=300, min_distance=25, min_response=40.0):
+    arr, keep = _images([image])
+    uv = np.zeros((max(1, max_count), 2), dtype=np.float32)
+    n = lib().orc_harris_detect(arr, int(max_count), int(min_distance), C.c_float(min_response), uv.ctypes.data_as(C.c_void_p))
+    return uv[:n].copy()
