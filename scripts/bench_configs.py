@@ -145,6 +145,42 @@ def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, c
     }
 
 
+def producer_cases(torch, F, D, synth, oracle, reps):
+    """Harris detection and BRIEF description on the reference's example-sized image."""
+    from PIL import Image
+    img = np.array(Image.open(os.path.join(ROOT, "tests", "data", "optical_flow", "ref_image.png")))
+    out = []
+    det = F.FeaturePointHarrisDetector()
+    det.options().kMinFeatureDistance, det.options().kMinValidResponse = 25, 40.0
+    pyr = F.ImagePyramid.from_host_levels([img])
+    det.DetectGoodFeatures(pyr, 300)
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ok, uv = det.DetectGoodFeatures(pyr, 300)
+        t.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    ouv = oracle.harris_detect(img, 300, 25, 40.0)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    out.append({"case": "harris_752x480_300", "gpu_host_call_ms": float(np.median(t)), "cpu_ms": cpu_ms, "features": int(len(uv)),
+                "identical": bool(np.array_equal(uv, ouv))})
+    for n in (300, 10000):
+        fuv = synth.make_features(n, 752, 480, seed=5, half=8)
+        d = F.BriefDescriptor()
+        d.compute_packed(pyr, fuv)
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            words = d.compute_packed(pyr, fuv)
+            t.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        okc, bits = oracle.brief_compute(img, fuv, 256, 8)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        out.append({"case": f"brief256_{n}", "gpu_host_call_ms": float(np.median(t)), "cpu_ms": cpu_ms,
+                    "identical": bool(np.array_equal(words, F.pack_brief(bits)))})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -172,6 +208,8 @@ def main():
     for name, cfg in cases:
         big = cfg["n"] * cfg["levels"] > 60000
         out = klt_case(name, cfg, torch, F, D, synth, oracle, reps, 1 if (big or args.quick) else 3)
+        print(json.dumps(out), flush=True)
+    for out in producer_cases(torch, F, D, synth, oracle, reps):
         print(json.dumps(out), flush=True)
     for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True),
                                        ("match_300x300_nearby", 300, 300, True), ("match_2000_force", 2000, 2000, False)):
