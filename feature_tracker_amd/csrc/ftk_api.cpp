@@ -201,6 +201,33 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         waves = atoi(env);  // experiment override
     }
     p.waves_per_feature = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    // Basic KLT inverse runs the pipelined kernel (klt_basic_kernels.hip) when its single-wave table
+    // builders can hold the patch (<= 64 rows / columns) and coordinates stay exact integers in fp32.
+    p.pb_enabled = 0;
+    if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.patch_rows <= 64 && p.patch_cols <= 64) {
+        bool small = true;
+        for (int i = 0; i < p.n_levels; ++i) {
+            small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);
+        }
+        const char *env = getenv("FTK_KLT_PIPELINED");
+        p.pb_enabled = (small && !(env && atoi(env) == 0)) ? 1 : 0;
+    }
+    p.pb_rwin_rows = p.patch_rows + 4;
+    p.pb_rwin_cols = (p.patch_cols + 4 + 3) & ~3;
+    p.pb_magic_rwc = div_magic(p.pb_rwin_cols);
+    p.pb_magic_rwq = div_magic(p.pb_rwin_cols / 4);
+    {
+        // extras per axis: a unit step crosses at most log2(len + 2) + 3 binade boundaries, two nodes each
+        auto extras = [](int len) {
+            int bits = 0;
+            while ((1 << bits) < len + 2) {
+                ++bits;
+            }
+            return 2 * (bits + 3);
+        };
+        p.pb_cap_r = p.patch_rows + 2 + extras(p.patch_rows);
+        p.pb_cap_c = p.patch_cols + 2 + extras(p.patch_cols);
+    }
     const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
     if (lds == 0 || lds > 160 * 1024) {
         return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu B of LDS (limit 163840)", p.patch_rows, p.patch_cols, lds);

@@ -47,6 +47,11 @@ struct KltParams {
     uint32_t magic_rwc, magic_cwc;  // division by window cols
     uint32_t magic_rwq, magic_cwq;  // division by window cols / 4
     int32_t waves_per_feature;  // workgroup = 64 * waves_per_feature lanes
+    // pipelined Basic-KLT inverse kernel (klt_basic_kernels.hip); pb_enabled = 0 selects the generic kernel
+    int32_t pb_enabled;
+    int32_t pb_rwin_rows, pb_rwin_cols;  // reference window incl. the rounding row / column: 2h+5 (cols padded to 4)
+    uint32_t pb_magic_rwc, pb_magic_rwq;
+    int32_t pb_cap_r, pb_cap_c;          // lattice node capacity per axis: len + 2 + provable maximum of extras
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
 };
 
@@ -54,6 +59,9 @@ struct KltParams {
 size_t klt_lds_bytes(int model, int method, const KltParams &p);
 // Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
+// Pipelined kernel for (FTK_MODEL_BASIC, FTK_METHOD_INVERSE); klt_launch dispatches to it when p.pb_enabled.
+size_t klt_basic_pipelined_lds_bytes(const KltParams &p);
+hipError_t klt_basic_pipelined_launch(const KltParams &p, hipStream_t stream);
 
 struct MatchParams {
     const uint32_t *ref_words;

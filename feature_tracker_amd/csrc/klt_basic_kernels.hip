@@ -1,0 +1,560 @@
+// klt_basic_kernels.hip — Basic KLT, inverse method (the headline configuration): pipelined kernel.
+//
+// Same contract as klt_track_kernel<FTK_MODEL_BASIC, FTK_METHOD_INVERSE> (klt_kernels.hip) — one
+// workgroup per feature, ONE launch per TrackFeatures call, sums in the reference's row-major order,
+// results bit-identical to the scalar CPU path (basic_klt.cpp:7-181) — with three structural changes
+// that remove most of the instruction and latency cost of the generic kernel:
+//
+//  1. Reference-side LATTICE instead of five taps per pixel.  The five reference taps of pixel
+//     (r, c) sit at (y_r, x_c), (y_r, x_c -+ 1), (y_r -+ 1, x_c) with y_r = float(r - h) + v,
+//     x_c = float(c - h) + u (basic_klt.cpp:127-134).  Along one axis the tap coordinates take only a
+//     few distinct float values: the len + 2 values {y_0 - 1, y_0 ... y_{len-1}, y_{len-1} + 1},
+//     plus an "extra" node wherever fl(y_r - 1) != y_{r-1} or fl(y_r + 1) != y_{r+1} bitwise —
+//     that happens only where the unit step crosses a binade boundary, so at most
+//     2 * (log2(len + 2) + 3) times per axis.  Every tap of the patch is therefore the bilinear value
+//     at a node pair (row node, column node), computed ONCE per level with exactly the per-tap
+//     expressions (same fractions, same weights, same sum order): ~(len + 2)^2 bilinears instead of
+//     5 * len^2.  Per patch row / column an index triple (centre, minus, plus) says which nodes
+//     its taps use; gx, gy and i_ref are read back from the lattice each iteration.
+//
+//  2. Windows prefetched.  At level entry the global loads of the current-image window and of the
+//     NEXT level's reference window are issued into registers, the node tables and the lattice of
+//     this level are built meanwhile, and only then are the loads consumed (LDS stores).  The
+//     reference window is one row / column larger than the generic kernel's so that a valid tap
+//     is always covered (a coordinate sum may round up to the next integer), hence no
+//     global-memory fallback sampler exists here.
+//
+//  3. Producer / consumer waves.  Wave 0 runs the five exact-order chains (one lane each) over
+//     64-pixel chunks while the other wave(s) compute the next chunk's per-pixel products; chunks
+//     travel through a two-slot LDS ring, one barrier per chunk.  The chain — 441 dependent adds
+//     per iteration at 21x21, the latency floor of bit-identical sums — then overlaps the sampling
+//     instead of following it.  With one wave per feature the same loop runs both roles in turn.
+//
+// Arithmetic contract as in klt_kernels.hip: IEEE fp32, no contraction, correctly rounded division.
+#define FTK_CHAIN_ROUND 4  // 16 terms per round: the consumer wave holds 32 VGPRs of prefetched terms
+#include "klt_common.h"
+
+namespace ftk {
+namespace {
+
+constexpr int kChunk = 64;  // pixels per chunk = one producer wave round
+constexpr int kTerms = 5;   // 0 H00, 1 H11, 2 H01, 3 -fx*ft, 4 -fy*ft (basic_klt.cpp:139-144)
+constexpr int kCurQuads = 4;  // 8-byte window loads a thread may hold in flight (current window)
+constexpr int kRefQuads = 3;  // ... (next level's reference window)
+
+__host__ __device__ inline int pb_pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int pb_producers(int waves) { return waves > 1 ? waves - 1 : 1; }
+
+// LDS carve-up (float4 regions first so that every region keeps its natural alignment).
+struct PbLds {
+    float4 *rnodes, *cnodes;  // lattice nodes per axis: {window element offset, fraction, 1 - fraction, valid}
+    uint4 *ridx, *cidx;       // per patch row / column: {centre node, minus node, plus node, all three valid}
+    float4 *ctab;             // per producer wave: 2 float4 per patch row, then per patch column (see cur_tables)
+    float *ring;              // [2][producers][kTerms][kChunk]
+    float *lattice;           // [n_r][n_c] reference bilinear values
+    float *sol;               // 4 floats: published solution
+    uint32_t *slots;          // 16: node counts (0, 1), valid-pixel counts by iteration parity (4 + 4 * parity + wave)
+    uint16_t *ref_win;        // two reference windows (this level, next level), ref_win_stride apart
+    int ref_win_stride;
+    uint16_t *cur_win;
+};
+
+__host__ __device__ inline size_t pb_lds_bytes(const KltParams &p, int waves) {
+    const int np = pb_producers(waves);
+    size_t bytes = 16 * (size_t)(p.pb_cap_r + p.pb_cap_c);
+    bytes += 16 * (size_t)(p.patch_rows + p.patch_cols);
+    bytes += 16 * (size_t)np * 2 * (p.patch_rows + p.patch_cols);
+    bytes += 4 * (size_t)2 * np * kTerms * kChunk;
+    bytes += 4 * (size_t)pb_pad4(p.pb_cap_r * p.pb_cap_c);
+    bytes += 4 * 4 + 4 * 16;
+    bytes += 2 * (size_t)2 * pb_pad4(p.pb_rwin_rows * p.pb_rwin_cols);
+    bytes += 2 * (size_t)pb_pad4(p.cwin_rows * p.cwin_cols);
+    return (bytes + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ PbLds pb_carve(float4 *base, const KltParams &p, int waves) {
+    const int np = pb_producers(waves);
+    PbLds c;
+    c.rnodes = base;
+    c.cnodes = c.rnodes + p.pb_cap_r;
+    c.ridx = reinterpret_cast<uint4 *>(c.cnodes + p.pb_cap_c);
+    c.cidx = c.ridx + p.patch_rows;
+    c.ctab = reinterpret_cast<float4 *>(c.cidx + p.patch_cols);
+    c.ring = reinterpret_cast<float *>(c.ctab + np * 2 * (p.patch_rows + p.patch_cols));
+    c.lattice = c.ring + 2 * np * kTerms * kChunk;
+    c.sol = c.lattice + pb_pad4(p.pb_cap_r * p.pb_cap_c);
+    c.slots = reinterpret_cast<uint32_t *>(c.sol + 4);
+    c.ref_win = reinterpret_cast<uint16_t *>(c.slots + 16);
+    c.ref_win_stride = pb_pad4(p.pb_rwin_rows * p.pb_rwin_cols);
+    c.cur_win = c.ref_win + 2 * c.ref_win_stride;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window prefetch: raw 8-byte loads issued early, turned into pixel pairs and stored late.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct RawQuads {
+    uint32_t x[N], y[N];
+};
+
+template <int N>
+__device__ __forceinline__ void issue_quads(RawQuads<N> &q, const Blk &b, const DevImage &im, int r_lo, int c_lo, int wrows, int wcols,
+                                            uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    const int tid = opaque(b.tid);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int idx = tid + k * b.nt;
+        idx = idx < total ? idx : 0;
+        const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+        const int qq = idx - r * quads;
+        const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * qq;
+        __builtin_memcpy(&q.x[k], src, 4);
+        __builtin_memcpy(&q.y[k], src + 4, 4);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void store_quads(const RawQuads<N> &q, const Blk &b, uint16_t *dst, int wrows, int wcols, uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    const int tid = opaque(b.tid);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int idx = tid + k * b.nt;
+        if (idx < total) {
+            const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+            const int qq = idx - r * quads;
+            const uint32_t x = q.x[k], y = q.y[k];
+            const uint32_t p0 = x & 0xFFFFu;
+            const uint32_t p1 = (x >> 8) & 0xFFFFu;
+            const uint32_t p2 = x >> 16;
+            const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+            *reinterpret_cast<uint2 *>(dst + r * wcols + 4 * qq) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lattice nodes of one axis (executed by ONE wavefront; len <= 64).
+//   x_t = float(t - h) + centre  — the coordinate of patch row / column t, as basic_klt.cpp:127-130
+//   nodes: 0 = x_0 - 1, t + 1 = x_t, len + 1 = x_{len-1} + 1, then the extras.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 node_entry(float x, int limit, int lo, int extent, int pitch) {
+    const Axis a = make_axis(x, limit);
+    const int rel = (int)((unsigned)a.i0 - (unsigned)lo);
+    const bool hit = (unsigned)rel < (unsigned)extent;
+    // valid implies hit by construction of the windows; `hit` only keeps the LDS read in bounds
+    return make_float4(__int_as_float(hit ? rel * pitch : 0), a.sub, a.inv, __int_as_float((a.valid && hit) ? 1 : 0));
+}
+
+__device__ __forceinline__ void build_axis_nodes(int lane, int len, int h, float centre, int limit, int lo, int extent, int pitch, int cap,
+                                                 float4 *nodes, uint4 *idx, uint32_t *n_out) {
+    const int t = lane;
+    const bool act = t < len;
+    const float lim = (float)limit;
+    const float x0 = (float)(t - h) + centre;
+    const float xm = x0 - 1.0f;
+    const float xp = x0 + 1.0f;
+    const float xprev = (float)(t - 1 - h) + centre;
+    const float xnext = (float)(t + 1 - h) + centre;
+    const bool v0 = x0 >= 0.0f && x0 <= lim;
+    const bool vm = xm >= 0.0f && xm <= lim;
+    const bool vp = xp >= 0.0f && xp <= lim;
+    const bool needm = act && t > 0 && vm && __float_as_uint(xm) != __float_as_uint(xprev);
+    const bool needp = act && t < len - 1 && vp && __float_as_uint(xp) != __float_as_uint(xnext);
+    const unsigned long long bm = __ballot(needm), bp = __ballot(needp);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int nm = (int)__popcll(bm);
+    int em = len + 2 + (int)__popcll(bm & below);
+    int ep = len + 2 + nm + (int)__popcll(bp & below);
+    int total = len + 2 + nm + (int)__popcll(bp);
+    // capacity guard (cap covers the provable maximum of extras; this only keeps LDS accesses in range)
+    em = em < cap ? em : cap - 1;
+    ep = ep < cap ? ep : cap - 1;
+    total = total < cap ? total : cap;
+    if (act) {
+        nodes[t + 1] = node_entry(x0, limit, lo, extent, pitch);
+        if (t == 0) {
+            nodes[0] = node_entry(xm, limit, lo, extent, pitch);
+        }
+        if (t == len - 1) {
+            nodes[len + 1] = node_entry(xp, limit, lo, extent, pitch);
+        }
+        if (needm) {
+            nodes[em] = node_entry(xm, limit, lo, extent, pitch);
+        }
+        if (needp) {
+            nodes[ep] = node_entry(xp, limit, lo, extent, pitch);
+        }
+        const int im = (t == 0) ? 0 : (needm ? em : t);
+        const int ip = (t == len - 1) ? len + 1 : (needp ? ep : t + 2);
+        idx[t] = make_uint4((unsigned)(t + 1), (unsigned)im, (unsigned)ip, (v0 && vm && vp) ? 1u : 0u);
+    }
+    if (lane == 0) {
+        *n_out = (uint32_t)total;
+    }
+}
+
+// Bilinear value of a node pair from an LDS window: tap_table() of the generic kernel.
+__device__ __forceinline__ float node_tap(const uint16_t *win, int wcols, const float4 &nr, const float4 &nc) {
+    const int idx = __float_as_int(nr.x) + __float_as_int(nc.x);
+    const unsigned a = win[idx];
+    const unsigned bb = win[idx + wcols];
+    const float w_tl = nr.z * nc.z;
+    const float w_tr = nr.z * nc.y;
+    const float w_bl = nr.y * nc.z;
+    const float w_br = nr.y * nc.y;
+    return w_tl * (float)(a & 0xFFu) + w_tr * (float)(a >> 8) + w_bl * (float)(bb & 0xFFu) + w_br * (float)(bb >> 8);
+}
+
+// Per-iteration tables of the current-image taps, private to one producer wave (so no barrier):
+// entry 2t   = node_entry of the current coordinate of patch row / column t, w = valid AND the
+//              reference-side validity of that row / column
+// entry 2t+1 = lattice offsets {centre, minus, plus} of that row (pre-multiplied by n_c) / column
+__device__ __forceinline__ void cur_tables(int lane, const KltParams &p, const PbLds &c, float4 *tab, const DevImage &cur, const Win &cw, float cur_u,
+                                           float cur_v, int n_c) {
+    const int total = p.patch_rows + p.patch_cols;
+    for (int t = lane; t < total; t += kWave) {
+        const bool is_row = t < p.patch_rows;
+        const int d = is_row ? t : t - p.patch_rows;
+        const float x = (float)(d - (is_row ? p.half_rows : p.half_cols)) + (is_row ? cur_v : cur_u);
+        float4 e = node_entry(x, (is_row ? cur.rows : cur.cols) - 1, is_row ? cw.r_lo : cw.c_lo, is_row ? cw.rows - 1 : cw.cols,
+                              is_row ? cw.cols : 1);
+        const uint4 id = is_row ? c.ridx[d] : c.cidx[d];
+        e.w = __int_as_float(__float_as_int(e.w) & (int)id.w);
+        const int mul = is_row ? n_c : 1;
+        tab[2 * t] = e;
+        tab[2 * t + 1] = make_float4(__int_as_float((int)id.x * mul), __int_as_float((int)id.y * mul), __int_as_float((int)id.z * mul), 0.0f);
+    }
+}
+
+// The per-pixel products of one 64-pixel chunk -> ring slot; returns the lane's validity.
+__device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltParams &p, const PbLds &c, const float4 *tab, const Win &cw, float *slot) {
+    const int pxi = chunk * kChunk + lane;
+    const bool in = pxi < p.P;
+    const int pp = in ? pxi : 0;
+    int prow, pcol;
+    pixel_rc(p, pp, prow, pcol);
+    const float4 r0 = tab[2 * prow], r1 = tab[2 * prow + 1];
+    const float4 c0 = tab[2 * (p.patch_rows + pcol)], c1 = tab[2 * (p.patch_rows + pcol) + 1];
+    const float i_cur = node_tap(cw.data, cw.cols, r0, c0);
+    const float *lat = c.lattice;
+    const int rc = __float_as_int(r1.x), rm = __float_as_int(r1.y), rp = __float_as_int(r1.z);
+    const int cc = __float_as_int(c1.x), cm = __float_as_int(c1.y), cp = __float_as_int(c1.z);
+    const float left = lat[rc + cm];
+    const float right = lat[rc + cp];
+    const float top = lat[rm + cc];
+    const float bottom = lat[rp + cc];
+    const float i_ref = lat[rc + cc];
+    const bool ok = in && ((__float_as_int(r0.w) & __float_as_int(c0.w)) != 0);
+    // basic_klt.cpp:135-144; an unused pixel contributes exact zeros (x + (+-0) == x)
+    const float fx = ok ? right - left : 0.0f;
+    const float fy = ok ? bottom - top : 0.0f;
+    const float ft = ok ? i_cur - i_ref : 0.0f;
+    slot[0 * kChunk + lane] = fx * fx;
+    slot[1 * kChunk + lane] = fy * fy;
+    slot[2 * kChunk + lane] = fx * fy;
+    slot[3 * kChunk + lane] = -(fx * ft);
+    slot[4 * kChunk + lane] = -(fy * ft);
+    return ok;
+}
+
+// 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave).
+__device__ __forceinline__ float chain_chunk(float acc, const float *row) {
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    float4 qa[kChainRound], qb[kChainRound];
+    chain_load(qa, t);
+#pragma unroll
+    for (int i = 0; i < kChunk / 4; i += 2 * kChainRound) {
+        chain_load(qb, t + i + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        if (i + 2 * kChainRound < kChunk / 4) {
+            chain_load(qa, t + i + 2 * kChainRound);
+        }
+        acc = chain_consume_all(acc, qb);
+    }
+    return acc;
+}
+
+
+// Exact ceil(2^20 / d) for 1 <= d <= 4096: q = (i * m) >> 20 equals i / d for i < 2^20 / d... (i * d < 2^20)
+__device__ __forceinline__ uint32_t magic20(int d) {
+    uint32_t m = (uint32_t)(1048576.0f / (float)d);
+    while (m * (uint32_t)d < 1048576u) {
+        ++m;
+    }
+    return m;
+}
+
+#ifndef FTK_WAVES_PER_EU
+#define FTK_WAVES_PER_EU 4
+#endif
+
+__global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p) {
+    extern __shared__ float4 lds_raw[];
+    Blk b;
+    b.tid = threadIdx.x;
+    b.nt = blockDim.x;
+    b.lane = b.tid & (kWave - 1);
+    b.wave = b.tid >> 6;
+    b.nwaves = b.nt >> 6;
+    const uint32_t id = blockIdx.x;
+    if (id >= (uint32_t)p.n) {
+        return;
+    }
+    const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
+    uint8_t status = p.status_in[id];
+    // features beyond kMaxTrackPointsNumber and features that already failed are passed through (basic_klt.cpp:9,15)
+    if (id >= p.n_track || status > FTK_TRACKED) {
+        if (b.tid == 0) {
+            p.cur_uv_out[2 * id] = in_u;
+            p.cur_uv_out[2 * id + 1] = in_v;
+            p.status_out[id] = status;
+            if (p.iters) {
+                p.iters[id] = 0;
+            }
+        }
+        return;
+    }
+#ifdef FTK_STAMPS
+    const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const PbLds c = pb_carve(lds_raw, p, b.nwaves);
+    const int np = pb_producers(b.nwaves);
+    const bool producer = (b.nwaves == 1) || b.wave > 0;
+    const bool consumer = b.wave == 0;
+    const int pw = (b.nwaves == 1) ? 0 : b.wave - 1;  // producer index
+    float4 *const my_tab = c.ctab + pw * 2 * (p.patch_rows + p.patch_cols);
+    const int n_chunks = (p.P + kChunk - 1) / kChunk;
+    const int n_steps = (n_chunks + np - 1) / np;
+
+    // basic_klt.cpp:10,18-19 (pyramid) / :59-86 (single level)
+    const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
+    const float scale = p.single_level ? 1.0f : (float)(1 << (p.n_levels - 1));
+    float ref_u = p.single_level ? full_ref_u : full_ref_u / scale;
+    float ref_v = p.single_level ? full_ref_v : full_ref_v / scale;
+    float cur_u = p.single_level ? in_u : in_u / scale;
+    float cur_v = p.single_level ? in_v : in_v / scale;
+
+    const int rrows = p.pb_rwin_rows, rcols = p.pb_rwin_cols;
+    const int ref_quads_total = rrows * (rcols >> 2), cur_quads_total = p.cwin_rows * (p.cwin_cols >> 2);
+    const bool ref_fits = ref_quads_total <= kRefQuads * b.nt, cur_fits = cur_quads_total <= kCurQuads * b.nt;
+
+    FTK_STAMP_BEGIN(b);
+    int buf = 0;
+    {
+        // the coarsest level's reference window: nothing to overlap it with yet
+        const DevImage ref = p.ref[p.n_levels - 1];
+        int r_lo, c_lo;
+        footprint_origin(p, ref_u, ref_v, r_lo, c_lo);
+        stage_any(opaque_blk(b), ref, c.ref_win, r_lo, c_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
+    }
+    uint32_t iters = 0;
+    float out_u = in_u, out_v = in_v;
+    for (int level = p.n_levels - 1; level > -1; --level) {
+        const DevImage ref = p.ref[level];
+        const DevImage cur = p.cur[level];
+        // ---- level entry: issue the window loads, build the node tables meanwhile ----
+        Win rw, cw;
+        rw.data = c.ref_win + buf * c.ref_win_stride;
+        rw.rows = rrows;
+        rw.cols = rcols;
+        footprint_origin(p, ref_u, ref_v, rw.r_lo, rw.c_lo);
+        int need_r, need_c;
+        footprint_origin(p, cur_u, cur_v, need_r, need_c);
+        cw.data = c.cur_win;
+        cw.r_lo = wadd(need_r, -p.cwin_margin);
+        cw.c_lo = wadd(need_c, -p.cwin_margin);
+        cw.rows = p.cwin_rows;
+        cw.cols = p.cwin_cols;
+        int nr_lo = 0, nc_lo = 0;
+        if (level > 0) {
+            footprint_origin(p, ref_u * 2.0f, ref_v * 2.0f, nr_lo, nc_lo);
+        }
+        const bool cur_async = cur_fits && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols);
+        const bool next_async = level > 0 && ref_fits && window_inside(p.ref[level > 0 ? level - 1 : 0], nr_lo, nc_lo, rrows, rcols);
+        if (b.wave == 0) {
+            build_axis_nodes(opaque(b.lane), p.patch_rows, p.half_rows, ref_v, ref.rows - 1, rw.r_lo, rw.rows - 1, rw.cols, p.pb_cap_r, c.rnodes, c.ridx,
+                             &c.slots[0]);
+        }
+        if (b.wave == (b.nwaves > 1 ? 1 : 0)) {
+            build_axis_nodes(opaque(b.lane), p.patch_cols, p.half_cols, ref_u, ref.cols - 1, rw.c_lo, rw.cols, 1, p.pb_cap_c, c.cnodes, c.cidx, &c.slots[1]);
+        }
+        __syncthreads();  // B1: node tables (and this level's reference window) visible
+        FTK_STAMP_END(b, 0);
+        // the window loads fly while the lattice is built
+        RawQuads<kCurQuads> qc;
+        RawQuads<kRefQuads> qn;
+        if (cur_async) {
+            issue_quads(qc, b, cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwq);
+        }
+        if (next_async) {
+            issue_quads(qn, b, p.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
+        }
+        // ---- lattice: one bilinear per node pair ----
+        const int n_r = (int)c.slots[0], n_c = (int)c.slots[1];
+        {
+            const int total = n_r * n_c;
+            const uint32_t m = magic20(n_c);
+            for (int idx = opaque(b.tid); idx < total; idx += b.nt) {
+                const int r = (int)(((uint32_t)idx * m) >> 20);
+                const int cc = idx - r * n_c;
+                c.lattice[idx] = node_tap(rw.data, rw.cols, c.rnodes[r], c.cnodes[cc]);
+            }
+        }
+        // ---- consume the prefetched loads ----
+        if (cur_async) {
+            store_quads(qc, b, c.cur_win, cw.rows, cw.cols, p.magic_cwq);
+        } else {
+            stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
+        }
+        if (level > 0) {
+            if (next_async) {
+                store_quads(qn, b, c.ref_win + (buf ^ 1) * c.ref_win_stride, rrows, rcols, p.pb_magic_rwq);
+            } else {
+                stage_any(opaque_blk(b), p.ref[level - 1], c.ref_win + (buf ^ 1) * c.ref_win_stride, nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
+            }
+        }
+        __syncthreads();  // B2: lattice and windows visible
+        FTK_STAMP_END(b, 1);
+
+        // ---- Gauss-Newton iterations (TrackOneFeature, basic_klt.cpp:88-116) ----
+        for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
+            ++iters;
+            FTK_STAMP_BEGIN(b);
+            if (iter > 0) {
+                // restage the current window when the patch has left it (wave-uniform)
+                footprint_origin(p, cur_u, cur_v, need_r, need_c);
+                const long long nr = need_r, nc = need_c;
+                const bool covered = nr >= (long long)cw.r_lo && nr + (2 * p.half_rows + 4) <= (long long)cw.r_lo + cw.rows &&
+                                     nc >= (long long)cw.c_lo && nc + (2 * p.half_cols + 4) <= (long long)cw.c_lo + cw.cols + 1;
+                if (!covered) {
+                    cw.r_lo = wadd(need_r, -p.cwin_margin);
+                    cw.c_lo = wadd(need_c, -p.cwin_margin);
+                    stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
+                    __syncthreads();
+                }
+            }
+            FTK_STAMP_END(b, 2);
+            uint32_t wave_valid = 0;
+            float acc = 0.0f;
+            if (producer) {
+                cur_tables(b.lane, p, c, my_tab, cur, cw, cur_u, cur_v, n_c);
+                __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from reordering across
+            }
+            for (int s = 0; s < n_steps; ++s) {
+                if (producer) {
+                    const int chunk = s * np + pw;
+                    if (chunk < n_chunks) {
+                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & 1) * np + pw) * kTerms * kChunk);
+                        wave_valid += (uint32_t)__popcll(__ballot(ok));
+                    }
+                    if (s == n_steps - 1 && b.lane == 0) {
+                        c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;
+                    }
+                }
+                __syncthreads();
+                if (consumer && b.lane < kTerms) {
+                    for (int q = 0; q < np; ++q) {
+                        if (s * np + q < n_chunks) {
+                            acc = chain_chunk(acc, c.ring + (((s & 1) * np + q) * kTerms + b.lane) * kChunk);
+                        }
+                    }
+                }
+            }
+            FTK_STAMP_END(b, 3);
+            if (consumer) {
+                float m[2][2], bb[2], sol[2];
+                const int acc_bits = __float_as_int(acc);
+                m[0][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0));
+                m[1][1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
+                m[0][1] = m[1][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2));
+                bb[0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
+                bb[1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4));
+                ldlt_solve<2>(m, bb, sol);  // basic_klt.cpp:97
+                if (b.lane == 0) {
+                    c.sol[0] = sol[0];
+                    c.sol[1] = sol[1];
+                }
+            }
+            __syncthreads();  // B3: solution and valid counts visible
+            FTK_STAMP_END(b, 5);
+            uint32_t n_valid = 0;
+            for (int w = (b.nwaves == 1 ? 0 : 1); w < b.nwaves; ++w) {
+                n_valid += c.slots[4 + 4 * (iter & 1u) + w];
+            }
+            if (n_valid == 0) {
+                break;  // basic_klt.cpp:94
+            }
+            const float v0 = c.sol[0], v1 = c.sol[1];
+            if (isnan(v0) || isnan(v1)) {
+                status = FTK_NUMERIC_ERROR;
+                break;
+            }
+            cur_u += v0;
+            cur_v += v1;
+            if (uv_outside(cur_u, cur_v, cur)) {
+                status = FTK_OUTSIDE;
+                break;
+            }
+            if (v0 * v0 + v1 * v1 < p.converge) {
+                status = FTK_TRACKED;
+                break;
+            }
+        }
+
+        if (level == 0) {
+            out_u = cur_u;
+            out_v = cur_v;
+            break;
+        }
+        ref_u *= 2.0f;
+        ref_v *= 2.0f;
+        cur_u *= 2.0f;
+        cur_v *= 2.0f;
+        buf ^= 1;
+        FTK_STAMP_BEGIN(b);
+    }
+
+    if (uv_outside(out_u, out_v, p.cur[0])) {
+        status = FTK_OUTSIDE;  // basic_klt.cpp:49-53
+    }
+    if (b.tid == 0) {
+        p.cur_uv_out[2 * id] = out_u;
+        p.cur_uv_out[2 * id + 1] = out_v;
+        p.status_out[id] = status;
+        if (p.iters) {
+            p.iters[id] = iters;
+        }
+    }
+#ifdef FTK_STAMPS
+    if (b.tid == 0 && p.stamps) {
+        b.stamp_acc[7] = __builtin_amdgcn_s_memtime() - stamp_kernel_t0;
+        for (int k = 0; k < 8; ++k) {
+            p.stamps[(size_t)id * 8 + k] = b.stamp_acc[k];
+        }
+    }
+#endif
+}
+
+}  // namespace
+
+size_t klt_basic_pipelined_lds_bytes(const KltParams &p) { return pb_lds_bytes(p, p.waves_per_feature); }
+
+hipError_t klt_basic_pipelined_launch(const KltParams &p, hipStream_t stream) {
+    const size_t lds = klt_basic_pipelined_lds_bytes(p);
+    auto kernel = klt_basic_inverse_pipelined_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ftk

@@ -1,0 +1,538 @@
+// klt_common.h — device helpers shared by the tracker kernels (klt_kernels.hip: all nine variants on
+// the generic path; klt_basic_kernels.hip: the pipelined Basic-KLT inverse kernel): scalar
+// semantics of the reference (x86 float->int, bilinear samplers), LDS image windows and their
+// staging, the Eigen-compatible LDLT, and the exact-order chain primitives.
+#pragma once
+
+#include "ftk_device.h"
+
+#include <limits.h>
+#include <math.h>
+
+#include <type_traits>
+
+namespace ftk {
+namespace {
+
+constexpr int kWave = 64;
+
+// Diagnostic build only (-DFTK_STAMPS): per-phase cycle totals of every workgroup, written to a
+// side buffer that no other code reads.  The production build contains none of this.
+#ifdef FTK_STAMPS
+#define FTK_STAMP_BEGIN(b) (b).stamp_t0 = __builtin_amdgcn_s_memtime()
+#define FTK_STAMP_END(b, k)                                           \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        (b).stamp_acc[k] += now_ - (b).stamp_t0;                      \
+        (b).stamp_t0 = now_;                                          \
+    } while (0)
+#else
+#define FTK_STAMP_BEGIN(b)
+#define FTK_STAMP_END(b, k)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------------
+
+// static_cast<int32_t>(float) as x86-64 cvttss2si does it (out of range / NaN -> INT_MIN)
+__device__ __forceinline__ int f2i(float x) { return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : INT_MIN; }
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ float floor_from_trunc(float x, int t) {
+    const float f = (float)t;
+    return (f > x) ? f - 1.0f : f;
+}
+__device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[(long long)row * im.cols + col]; }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// Thread coordinates inside the feature's workgroup.
+struct Blk {
+    int tid, nt, lane, wave, nwaves;
+#ifdef FTK_STAMPS
+    mutable unsigned long long stamp_t0 = 0;
+    mutable unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+};
+
+// Returns x behind an optimisation barrier: per-thread index math derived from it is recomputed where
+// it is used instead of being hoisted out of the level loop and held in VGPRs for the whole kernel.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ Blk opaque_blk(const Blk &b) {
+    Blk o = b;
+    o.tid = opaque(b.tid);
+    o.lane = opaque(b.lane);
+    return o;
+}
+
+// An image window resident in LDS.  Element (r, c) packs the pixel pair
+// (img[clamp(r_lo + r)][clamp(c_lo + c)], img[clamp(r_lo + r)][clamp(c_lo + c + 1)]) into 16 bits,
+// clamp = clamp-to-edge, so the 2x2 neighbourhood of any in-image pixel is two ds_read_u16.
+struct Win {
+    const uint16_t *data;
+    int r_lo, c_lo;
+    int rows, cols;  // wave-uniform
+};
+
+__device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols);
+
+// The 2x2 neighbourhood of the in-image pixel (r0, c0), +1 neighbours clamped to the image:
+// from the LDS window when it covers the pixel, from global memory otherwise.
+__device__ __forceinline__ void fetch4(const DevImage &im, const Win &w, int r0, int c0, float &p00, float &p01, float &p10, float &p11) {
+    const int lr = (int)((unsigned)r0 - (unsigned)w.r_lo);
+    const int lc = (int)((unsigned)c0 - (unsigned)w.c_lo);
+    if ((unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols) {
+        const unsigned a = w.data[lr * w.cols + lc];
+        const unsigned bb = w.data[(lr + 1) * w.cols + lc];
+        p00 = (float)(a & 0xFFu);
+        p01 = (float)(a >> 8);
+        p10 = (float)(bb & 0xFFu);
+        p11 = (float)(bb >> 8);
+    } else {
+        const int r1 = (r0 + 1 < im.rows) ? r0 + 1 : r0;
+        const int c1 = (c0 + 1 < im.cols) ? c0 + 1 : c0;
+        p00 = px(im, r0, c0);
+        p01 = px(im, r0, c1);
+        p10 = px(im, r1, c0);
+        p11 = px(im, r1, c1);
+    }
+}
+
+// GrayImage::GetPixelValueNoCheck(float, float): bilinear, ((tl + tr) + bl) + br, any coordinates
+__device__ __forceinline__ float bilinear(const DevImage &im, const Win &w, float row, float col) {
+    int r0 = f2i(row);
+    int c0 = f2i(col);
+    const float sub_row = row - floor_from_trunc(row, r0);
+    const float sub_col = col - floor_from_trunc(col, c0);
+    r0 = clampi(r0, 0, im.rows - 1);
+    c0 = clampi(c0, 0, im.cols - 1);
+    const float inv_sub_row = 1.0f - sub_row;
+    const float inv_sub_col = 1.0f - sub_col;
+    const float w_tl = inv_sub_row * inv_sub_col;
+    const float w_tr = inv_sub_row * sub_col;
+    const float w_bl = sub_row * inv_sub_col;
+    const float w_br = sub_row * sub_col;
+    float p00, p01, p10, p11;
+    fetch4(im, w, r0, c0, p00, p01, p10, p11);
+    return w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
+}
+
+// GrayImage::GetPixelValue(row, col, *value): closed-rectangle validity, NaN invalid.  Inside the
+// rectangle truncation equals floor, so the fractions need no floor fix-up.
+__device__ __forceinline__ bool sample(const DevImage &im, const Win &w, float row, float col, float &value) {
+    if (!(row >= 0.0f && col >= 0.0f && row <= (float)(im.rows - 1) && col <= (float)(im.cols - 1))) {
+        return false;
+    }
+    const int r0 = (int)row;
+    const int c0 = (int)col;
+    const float sub_row = row - (float)r0;
+    const float sub_col = col - (float)c0;
+    const float inv_sub_row = 1.0f - sub_row;
+    const float inv_sub_col = 1.0f - sub_col;
+    const float w_tl = inv_sub_row * inv_sub_col;
+    const float w_tr = inv_sub_row * sub_col;
+    const float w_bl = sub_row * inv_sub_col;
+    const float w_br = sub_row * sub_col;
+    float p00, p01, p10, p11;
+    fetch4(im, w, r0, c0, p00, p01, p10, p11);
+    value = w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
+    return true;
+}
+
+// --- straight-line sampling for the hot loops ---------------------------------------------------
+// One image axis of a bilinear tap: validity on the closed interval [0, limit], base index, fraction
+// and its complement — the same quantities sample() derives, computed without branches.
+struct Axis {
+    int i0;
+    float sub, inv;
+    bool valid;
+};
+
+__device__ __forceinline__ Axis make_axis(float x, int limit) {
+    Axis a;
+    a.valid = (x >= 0.0f && x <= (float)limit);
+    a.i0 = (int)x;
+    a.sub = x - (float)a.i0;
+    a.inv = 1.0f - a.sub;
+    return a;
+}
+
+// Bilinear value of (row axis, col axis) read from the LDS window with NO branch: the LDS index is
+// clamped into the window so the read is always safe, and `hit` is cleared when the tap was not
+// really covered (the caller then redoes the pixel through sample(), which can reach global memory).
+// Same weight products and summation order as sample().
+__device__ __forceinline__ float tap(const Win &w, const Axis &ar, const Axis &ac, bool &hit) {
+    const int lr = (int)((unsigned)ar.i0 - (unsigned)w.r_lo);
+    const int lc = (int)((unsigned)ac.i0 - (unsigned)w.c_lo);
+    const bool in = (unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols;
+    hit = hit && in;
+    const int idx = in ? lr * w.cols + lc : 0;
+    const unsigned a = w.data[idx];
+    const unsigned bb = w.data[idx + w.cols];
+    const float w_tl = ar.inv * ac.inv;
+    const float w_tr = ar.inv * ac.sub;
+    const float w_bl = ar.sub * ac.inv;
+    const float w_br = ar.sub * ac.sub;
+    return w_tl * (float)(a & 0xFFu) + w_tr * (float)(a >> 8) + w_bl * (float)(bb & 0xFFu) + w_br * (float)(bb >> 8);
+}
+
+__device__ __forceinline__ bool uv_outside(float u, float v, const DevImage &im) {
+    return u < 0.0f || u > (float)(im.cols - 1) || v < 0.0f || v > (float)(im.rows - 1);
+}
+
+template <typename T>
+__device__ __forceinline__ void swap_values(T &a, T &b) {
+    const T t = a;
+    a = b;
+    b = t;
+}
+
+// Axis tables: the five reference taps of the inverse methods use, per patch pixel, the row axes of
+// (row, row-1, row+1) and the column axes of (col, col-1, col+1).  Those depend on the patch row
+// (resp. column) only, so they are computed once per level into LDS — 3*(rows+cols) entries instead
+// of 6 axes per pixel — with exactly the expressions of the per-pixel form.  Entry layout (float4):
+// x = window-relative base index (int bits, 0 when not covered), y = fraction, z = 1 - fraction,
+// w = flags (int bits: 1 = inside the image, 2 = covered by the staged window).
+__device__ __forceinline__ void build_axis_tables(const Blk &b, const KltParams &p, const DevImage &im, const Win &w, float u, float v,
+                                                  int variants, float4 *tab) {
+    const int nr = variants * p.patch_rows, total = nr + variants * p.patch_cols;
+    for (int t = b.tid; t < total; t += b.nt) {
+        const bool is_row = t < nr;
+        const int k = is_row ? t : t - nr;
+        const int len = is_row ? p.patch_rows : p.patch_cols;
+        const int var = (k >= 2 * len) ? 2 : (k >= len ? 1 : 0);
+        const int d = k - var * len;
+        float x = (float)(d - (is_row ? p.half_rows : p.half_cols)) + (is_row ? v : u);
+        if (var == 1) {
+            x = x - 1.0f;
+        } else if (var == 2) {
+            x = x + 1.0f;
+        }
+        const Axis a = make_axis(x, (is_row ? im.rows : im.cols) - 1);
+        const int rel = (int)((unsigned)a.i0 - (unsigned)(is_row ? w.r_lo : w.c_lo));
+        const bool hit = is_row ? (unsigned)rel < (unsigned)(w.rows - 1) : (unsigned)rel < (unsigned)w.cols;
+        tab[t] = make_float4(__int_as_float(hit ? rel : 0), a.sub, a.inv, __int_as_float((a.valid ? 1 : 0) | (hit ? 2 : 0)));
+    }
+}
+
+// tap() on two table entries.
+__device__ __forceinline__ float tap_table(const Win &w, const float4 &ar, const float4 &ac) {
+    const int idx = __float_as_int(ar.x) * w.cols + __float_as_int(ac.x);
+    const unsigned a = w.data[idx];
+    const unsigned bb = w.data[idx + w.cols];
+    const float w_tl = ar.z * ac.z;
+    const float w_tr = ar.z * ac.y;
+    const float w_bl = ar.y * ac.z;
+    const float w_br = ar.y * ac.y;
+    return w_tl * (float)(a & 0xFFu) + w_tr * (float)(a >> 8) + w_bl * (float)(bb & 0xFFu) + w_br * (float)(bb >> 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Eigen-compatible LDLT solve, N in {2, 3, 6}, everything in registers (all loops unrolled,
+// pivot swaps predicated on compile-time indices so nothing is dynamically indexed).
+// Mirrors the published Eigen 3.3.7+ algorithm; see oracle/oracle_substrate.c for the statement.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N], float (&x)[N]) {
+    int tr[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        tr[k] = k;
+    }
+    bool degenerate = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (!degenerate) {
+            int p = k;
+            float biggest = fabsf(m[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const float cand = fabsf(m[i][i]);
+                if (cand > biggest) {
+                    biggest = cand;
+                    p = i;
+                }
+            }
+            tr[k] = p;
+#pragma unroll
+            for (int q = k + 1; q < N; ++q) {
+                if (p == q) {
+#pragma unroll
+                    for (int j = 0; j < k; ++j) {
+                        swap_values(m[k][j], m[q][j]);
+                    }
+#pragma unroll
+                    for (int i = q + 1; i < N; ++i) {
+                        swap_values(m[i][k], m[i][q]);
+                    }
+                    swap_values(m[k][k], m[q][q]);
+#pragma unroll
+                    for (int i = k + 1; i < q; ++i) {
+                        swap_values(m[i][k], m[q][i]);
+                    }
+                }
+            }
+            if (k > 0) {
+                float temp[N];
+#pragma unroll
+                for (int j = 0; j < k; ++j) {
+                    temp[j] = m[j][j] * m[k][j];
+                }
+                float dot = m[k][0] * temp[0];
+#pragma unroll
+                for (int j = 1; j < k; ++j) {
+                    dot += m[k][j] * temp[j];
+                }
+                m[k][k] -= dot;
+#pragma unroll
+                for (int i = k + 1; i < N; ++i) {
+                    float s = m[i][0] * temp[0];
+#pragma unroll
+                    for (int j = 1; j < k; ++j) {
+                        s += m[i][j] * temp[j];
+                    }
+                    m[i][k] -= s;
+                }
+            }
+            const float akk = m[k][k];
+            const bool pivot_valid = fabsf(akk) > 0.0f;
+            if (k == 0 && !pivot_valid) {
+                tr[0] = 0;
+                degenerate = true;
+            } else if (pivot_valid) {
+#pragma unroll
+                for (int i = k + 1; i < N; ++i) {
+                    m[i][k] /= akk;
+                }
+            }
+        }
+    }
+
+    float y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        y[i] = b[i];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int q = k + 1; q < N; ++q) {
+            if (tr[k] == q) {
+                swap_values(y[k], y[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        float s = m[i][0] * y[0];
+#pragma unroll
+        for (int j = 1; j < i; ++j) {
+            s += m[i][j] * y[j];
+        }
+        y[i] -= s;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (fabsf(m[i][i]) > 1.17549435e-38f) {
+            y[i] /= m[i][i];
+        } else {
+            y[i] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) {
+        float s = m[i + 1][i] * y[i + 1];
+#pragma unroll
+        for (int j = i + 2; j < N; ++j) {
+            s += m[j][i] * y[j];
+        }
+        y[i] -= s;
+    }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+        for (int q = k + 1; q < N; ++q) {
+            if (tr[k] == q) {
+                swap_values(y[k], y[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x[i] = y[i];
+    }
+}
+
+// Phase B: lane k < K of wave 0 adds terms[k][0..Ppad) strictly left to right and publishes the sum.
+// The adds form one dependent chain (that IS the reference's order); the LDS reads are software
+// pipelined one round (8 x ds_read_b128 = 32 terms) ahead in two ping-pong register sets, pinned
+// in place with sched_barrier, so that the chain of v_add_f32 — not the ds_read latency — sets the
+// pace.  The prefetch may run up to 16 float4 past the end of a row: it stays inside the
+// workgroup's LDS carve (the arrays behind `terms` are larger than that) and is never consumed.
+#ifndef FTK_CHAIN_ROUND
+#define FTK_CHAIN_ROUND 8
+#endif
+constexpr int kChainRound = FTK_CHAIN_ROUND;
+
+__device__ __forceinline__ void chain_load(float4 (&q)[kChainRound], const float4 *t) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        q[d] = t[d];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float chain_consume(float acc, const float4 (&q)[kChainRound], int count) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        if (d < count) {
+            acc += q[d].x;
+            acc += q[d].y;
+            acc += q[d].z;
+            acc += q[d].w;
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float chain_consume_all(float acc, const float4 (&q)[kChainRound]) {
+#pragma unroll
+    for (int d = 0; d < kChainRound; ++d) {
+        acc += q[d].x;
+        acc += q[d].y;
+        acc += q[d].z;
+        acc += q[d].w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
+
+__device__ __forceinline__ float chain_lane(const float *row, int Ppad) {
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    const int n4 = Ppad >> 2;
+    float4 qa[kChainRound], qb[kChainRound];
+    float acc = 0.0f;
+    int i = 0;
+    chain_load(qa, t);
+    for (; i + 2 * kChainRound <= n4; i += 2 * kChainRound) {
+        chain_load(qb, t + i + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        chain_load(qa, t + i + 2 * kChainRound);
+        acc = chain_consume_all(acc, qb);
+    }
+    chain_load(qb, t + i + kChainRound);
+    const int rem = n4 - i;  // 0 .. 2*kChainRound-1 float4 left, the first kChainRound already in qa
+    acc = chain_consume(acc, qa, rem);
+    acc = chain_consume(acc, qb, rem - kChainRound);
+    return acc;
+}
+
+__device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow, int &pcol) {
+    prow = (p.patch_cols == 1) ? pxi : (int)__umulhi((unsigned)pxi, p.magic_pc);
+    pcol = pxi - prow * p.patch_cols;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window management
+// ---------------------------------------------------------------------------------------------
+
+// Top-left corner of the (2h+4)^2 footprint of a patch centred at (u, v): bilinear bases of the
+// patch pixels and of their +-1 neighbours lie in [floor - h - 1, floor + h + 1], plus one for the
+// +1 bilinear neighbour.
+__device__ __forceinline__ void footprint_origin(const KltParams &p, float u, float v, int &r_lo, int &c_lo) {
+    r_lo = wadd(f2i(floorf(v)), -(p.half_rows + 1));
+    c_lo = wadd(f2i(floorf(u)), -(p.half_cols + 1));
+}
+
+// One pixel-pair element of a window: (img[clamp(r)][clamp(c)], img[clamp(r)][clamp(c + 1)]).
+__device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols) {
+    const int r = (int)__umulhi((unsigned)idx, magic_cols);
+    const int c = idx - r * wcols;
+    const int ir = clampi(wadd(r_lo, r), 0, im.rows - 1);
+    const int ic = wadd(c_lo, c);
+    const int ic0 = clampi(ic, 0, im.cols - 1);
+    const int ic1 = clampi(wadd(ic, 1), 0, im.cols - 1);
+    const uint8_t *rowp = im.data + (long long)ir * im.cols;
+    return (uint16_t)((unsigned)rowp[ic0] | ((unsigned)rowp[ic1] << 8));
+}
+
+// Loads up to kStageBatch window elements per thread with every global load in flight before the
+// first LDS store (the loop body is branch-free: out-of-range slots read element 0 and are not stored).
+constexpr int kStageBatch = 4;
+
+__device__ __forceinline__ void stage_elements(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wcols, uint32_t magic_cols,
+                                               int total) {
+    for (int base = 0; base < total; base += b.nt * kStageBatch) {
+        uint16_t v[kStageBatch];
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+            const int idx = base + k * b.nt + b.tid;
+            v[k] = window_element(im, r_lo, c_lo, idx < total ? idx : 0, wcols, magic_cols);
+        }
+#pragma unroll
+        for (int k = 0; k < kStageBatch; ++k) {
+            const int idx = base + k * b.nt + b.tid;
+            if (idx < total) {
+                dst[idx] = v[k];
+            }
+        }
+    }
+}
+
+// Fast staging for windows that lie completely inside the image: thread (row, quad) fetches 8
+// consecutive bytes with one unaligned global_load_dwordx2, forms the four pixel pairs
+// (b0,b1) (b1,b2) (b2,b3) (b3,b4) with v_alignbyte / v_alignbit and stores them with one
+// ds_write_b64 (wcols is a multiple of 4).  ~1/4 of the instructions of the per-element path.
+__device__ __forceinline__ bool window_inside(const DevImage &im, int r_lo, int c_lo, int wrows, int wcols) {
+    return r_lo >= 0 && c_lo >= 0 && (long long)r_lo + wrows <= im.rows && (long long)c_lo + wcols + 4 <= im.cols;
+}
+
+__device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wrows, int wcols,
+                                                  uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    for (int idx = b.tid; idx < total; idx += b.nt) {
+        const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+        const int q = idx - r * quads;
+        const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+        uint32_t x, y;
+        __builtin_memcpy(&x, src, 4);
+        __builtin_memcpy(&y, src + 4, 4);
+        const uint32_t p0 = x & 0xFFFFu;
+        const uint32_t p1 = (x >> 8) & 0xFFFFu;
+        const uint32_t p2 = x >> 16;
+        const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+        *reinterpret_cast<uint2 *>(dst + r * wcols + 4 * q) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+    }
+}
+
+__device__ __forceinline__ void stage_any(const Blk &b, const DevImage &im, uint16_t *dst, int r_lo, int c_lo, int wrows, int wcols,
+                                          uint32_t magic_cols, uint32_t magic_quads) {
+    if (window_inside(im, r_lo, c_lo, wrows, wcols)) {
+        stage_rows_inside(b, im, dst, r_lo, c_lo, wrows, wcols, magic_quads);
+    } else {
+        stage_elements(b, im, dst, r_lo, c_lo, wcols, magic_cols, wrows * wcols);
+    }
+}
+
+// One quad of a window that lies inside the image: 8 bytes -> four pixel pairs (see stage_rows_inside).
+__device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, int c_lo, int idx, int quads, uint32_t magic_quads, int &lds_off,
+                                                 int wcols) {
+    const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+    const int q = idx - r * quads;
+    const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+    uint32_t x, y;
+    __builtin_memcpy(&x, src, 4);
+    __builtin_memcpy(&y, src + 4, 4);
+    const uint32_t p0 = x & 0xFFFFu;
+    const uint32_t p1 = (x >> 8) & 0xFFFFu;
+    const uint32_t p2 = x >> 16;
+    const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+    lds_off = r * wcols + 4 * q;
+    return make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+}
+
+}  // namespace
+}  // namespace ftk
