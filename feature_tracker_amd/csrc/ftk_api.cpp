@@ -586,6 +586,32 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             fprintf(stderr, "[ftk stamps] memtime ticks/feature: ref_stage %.0f setup %.0f cur_stage %.0f phaseA %.0f count %.0f chain %.0f solve %.0f total %.0f\n",
                     avg[0] / n, avg[1] / n, avg[2] / n, avg[3] / n, avg[4] / n, avg[5] / n, avg[6] / n, avg[7] / n);
         }
+        if (const char *dump = getenv("FTK_STAMPS_DUMP")) {
+            if (FILE *f = fopen(dump, "wb")) {
+                fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+                fclose(f);
+            }
+        }
+        if (p.pb_enabled && printed <= 3) {
+            // pipelined kernel: slots 6 / 4 hold s_memrealtime (100 MHz) at workgroup start / end
+            unsigned long long t_min = ~0ull, t_max = 0, life = 0;
+            for (int i = 0; i < n; ++i) {
+                const unsigned long long t0 = h[(size_t)i * 8 + 6], t1 = h[(size_t)i * 8 + 4];
+                if (t0 == 0) continue;
+                t_min = t0 < t_min ? t0 : t_min;
+                t_max = t1 > t_max ? t1 : t_max;
+                life += t1 - t0;
+            }
+            unsigned long long last_start = 0, first_end = ~0ull;
+            for (int i = 0; i < n; ++i) {
+                const unsigned long long t0 = h[(size_t)i * 8 + 6], t1 = h[(size_t)i * 8 + 4];
+                if (t0 == 0) continue;
+                last_start = t0 > last_start ? t0 : last_start;
+                first_end = t1 < first_end ? t1 : first_end;
+            }
+            fprintf(stderr, "[ftk stamps] realtime: span %.2f us, mean workgroup life %.2f us, last start +%.2f us, first end +%.2f us\n",
+                    (double)(t_max - t_min) * 0.01, (double)life * 0.01 / n, (double)(last_start - t_min) * 0.01, (double)(first_end - t_min) * 0.01);
+        }
         (void)hipFree(d_stamps);
     }
     return FTK_OK;

@@ -104,13 +104,14 @@ __device__ __forceinline__ void issue_quads(RawQuads<N> &q, const Blk &b, const 
     const int quads = wcols >> 2;
     const int total = wrows * quads;
     const int tid = opaque(b.tid);
+    const uint8_t *base = im.data + (long long)r_lo * im.cols + c_lo;  // wave-uniform: scalar base + 32-bit lane offset
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         int idx = tid + k * b.nt;
         idx = idx < total ? idx : 0;
         const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
         const int qq = idx - r * quads;
-        const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * qq;
+        const uint8_t *src = base + (size_t)(unsigned)(r * im.cols + 4 * qq);
         __builtin_memcpy(&q.x[k], src, 4);
         __builtin_memcpy(&q.y[k], src + 4, 4);
     }
@@ -150,10 +151,34 @@ __device__ __forceinline__ float4 node_entry(float x, int limit, int lo, int ext
     return make_float4(__int_as_float(hit ? rel * pitch : 0), a.sub, a.inv, __int_as_float((a.valid && hit) ? 1 : 0));
 }
 
-__device__ __forceinline__ void build_axis_nodes(int lane, int len, int h, float centre, int limit, int lo, int extent, int pitch, int cap,
-                                                 float4 *nodes, uint4 *idx, uint32_t *n_out) {
-    const int t = lane;
+struct AxisSpec {
+    int len, h, limit, lo, extent, pitch, cap;
+    float centre;
+    float4 *nodes;
+    uint4 *idx;
+    uint32_t *n_out;
+};
+
+// One pass of one wavefront over up to two axes: lanes [0, A.len) work on axis A, lanes
+// [A.len, A.len + B.len) on axis B (B.len == 0: A alone).  Requires A.len + B.len <= 64.
+__device__ __forceinline__ void build_nodes_pass(int lane, const AxisSpec &A, const AxisSpec &B) {
+    const bool is_b = lane >= A.len;
+    const int len = is_b ? B.len : A.len;
+    const int h = is_b ? B.h : A.h;
+    const int limit = is_b ? B.limit : A.limit;
+    const int lo = is_b ? B.lo : A.lo;
+    const int extent = is_b ? B.extent : A.extent;
+    const int pitch = is_b ? B.pitch : A.pitch;
+    const int cap = is_b ? B.cap : A.cap;
+    const float centre = is_b ? B.centre : A.centre;
+    float4 *nodes = is_b ? B.nodes : A.nodes;
+    uint4 *idx = is_b ? B.idx : A.idx;
+    const int t = is_b ? lane - A.len : lane;
     const bool act = t < len;
+    const unsigned long long mask_a = (A.len >= 64) ? ~0ull : ((1ull << A.len) - 1ull);
+    const unsigned long long mask_ab = (A.len + B.len >= 64) ? ~0ull : ((1ull << (A.len + B.len)) - 1ull);
+    const unsigned long long mine = is_b ? (mask_ab & ~mask_a) : mask_a;
+
     const float lim = (float)limit;
     const float x0 = (float)(t - h) + centre;
     const float xm = x0 - 1.0f;
@@ -167,34 +192,36 @@ __device__ __forceinline__ void build_axis_nodes(int lane, int len, int h, float
     const bool needp = act && t < len - 1 && vp && __float_as_uint(xp) != __float_as_uint(xnext);
     const unsigned long long bm = __ballot(needm), bp = __ballot(needp);
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int nm = (int)__popcll(bm);
-    int em = len + 2 + (int)__popcll(bm & below);
-    int ep = len + 2 + nm + (int)__popcll(bp & below);
-    int total = len + 2 + nm + (int)__popcll(bp);
+    const int nm = (int)__popcll(bm & mine);
+    int em = len + 2 + (int)__popcll(bm & mine & below);
+    int ep = len + 2 + nm + (int)__popcll(bp & mine & below);
+    int total = len + 2 + nm + (int)__popcll(bp & mine);
     // capacity guard (cap covers the provable maximum of extras; this only keeps LDS accesses in range)
     em = em < cap ? em : cap - 1;
     ep = ep < cap ? ep : cap - 1;
     total = total < cap ? total : cap;
     if (act) {
         nodes[t + 1] = node_entry(x0, limit, lo, extent, pitch);
+        if (t == 0 || t == len - 1) {
+            nodes[t == 0 ? 0 : len + 1] = node_entry(t == 0 ? xm : xp, limit, lo, extent, pitch);
+        }
+        const int im = (t == 0) ? 0 : (needm ? em : t);
+        const int ip = (t == len - 1) ? len + 1 : (needp ? ep : t + 2);
+        idx[t] = make_uint4((unsigned)(t + 1), (unsigned)im, (unsigned)ip, (v0 && vm && vp) ? 1u : 0u);
         if (t == 0) {
-            nodes[0] = node_entry(xm, limit, lo, extent, pitch);
+            *(is_b ? B.n_out : A.n_out) = (uint32_t)total;
         }
-        if (t == len - 1) {
-            nodes[len + 1] = node_entry(xp, limit, lo, extent, pitch);
-        }
+    }
+    if (len == 1 && act) {
+        nodes[2] = node_entry(xp, limit, lo, extent, pitch);  // a one-pixel axis: lane 0 owns both edge nodes
+    }
+    if ((bm | bp) != 0ull) {  // wave-uniform: most levels have no extra node
         if (needm) {
             nodes[em] = node_entry(xm, limit, lo, extent, pitch);
         }
         if (needp) {
             nodes[ep] = node_entry(xp, limit, lo, extent, pitch);
         }
-        const int im = (t == 0) ? 0 : (needm ? em : t);
-        const int ip = (t == len - 1) ? len + 1 : (needp ? ep : t + 2);
-        idx[t] = make_uint4((unsigned)(t + 1), (unsigned)im, (unsigned)ip, (v0 && vm && vp) ? 1u : 0u);
-    }
-    if (lane == 0) {
-        *n_out = (uint32_t)total;
     }
 }
 
@@ -321,6 +348,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     }
 #ifdef FTK_STAMPS
     const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_real_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, common to all CUs
 #endif
     const PbLds c = pb_carve(lds_raw, p, b.nwaves);
     const int np = pb_producers(b.nwaves);
@@ -357,6 +385,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     for (int level = p.n_levels - 1; level > -1; --level) {
         const DevImage ref = p.ref[level];
         const DevImage cur = p.cur[level];
+        set_level_priority(level);
         // ---- level entry: issue the window loads, build the node tables meanwhile ----
         Win rw, cw;
         rw.data = c.ref_win + buf * c.ref_win_stride;
@@ -377,11 +406,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         const bool cur_async = cur_fits && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols);
         const bool next_async = level > 0 && ref_fits && window_inside(p.ref[level > 0 ? level - 1 : 0], nr_lo, nc_lo, rrows, rcols);
         if (b.wave == 0) {
-            build_axis_nodes(opaque(b.lane), p.patch_rows, p.half_rows, ref_v, ref.rows - 1, rw.r_lo, rw.rows - 1, rw.cols, p.pb_cap_r, c.rnodes, c.ridx,
-                             &c.slots[0]);
-        }
-        if (b.wave == (b.nwaves > 1 ? 1 : 0)) {
-            build_axis_nodes(opaque(b.lane), p.patch_cols, p.half_cols, ref_u, ref.cols - 1, rw.c_lo, rw.cols, 1, p.pb_cap_c, c.cnodes, c.cidx, &c.slots[1]);
+            // both axes' node tables in one pass of wave 0 (two passes when the patch has more than 64 rows + columns)
+            AxisSpec ar = {p.patch_rows, p.half_rows, ref.rows - 1, rw.r_lo, rw.rows - 1, rw.cols, p.pb_cap_r, ref_v, c.rnodes, c.ridx, &c.slots[0]};
+            AxisSpec ac = {p.patch_cols, p.half_cols, ref.cols - 1, rw.c_lo, rw.cols, 1, p.pb_cap_c, ref_u, c.cnodes, c.cidx, &c.slots[1]};
+            const int lane = opaque(b.lane);
+            if (p.patch_rows + p.patch_cols <= kWave) {
+                build_nodes_pass(lane, ar, ac);
+            } else {
+                AxisSpec none = ar;
+                none.len = 0;
+                build_nodes_pass(lane, ar, none);
+                build_nodes_pass(lane, ac, none);
+            }
         }
         __syncthreads();  // B1: node tables (and this level's reference window) visible
         FTK_STAMP_END(b, 0);
@@ -533,6 +569,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 #ifdef FTK_STAMPS
     if (b.tid == 0 && p.stamps) {
         b.stamp_acc[7] = __builtin_amdgcn_s_memtime() - stamp_kernel_t0;
+        b.stamp_acc[6] = stamp_real_t0;
+        b.stamp_acc[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 11) | 20) << 32) |  // XCC_ID (hwreg 20), all bits
+                         (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID (hwreg 4): wave, simd, cu, sh, se
+        b.stamp_acc[4] = __builtin_amdgcn_s_memrealtime();
         for (int k = 0; k < 8; ++k) {
             p.stamps[(size_t)id * 8 + k] = b.stamp_acc[k];
         }

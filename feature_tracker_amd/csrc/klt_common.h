@@ -67,6 +67,23 @@ __device__ __forceinline__ Blk opaque_blk(const Blk &b) {
     return o;
 }
 
+// All features of a call are resident at once and the hardware arbitrates oldest-wave-first, which
+// lets the first-dispatched features finish early and leaves the youngest ones to run the tail
+// alone at single-wave issue rate.  Waves therefore raise their own priority while they are
+// behind (coarse pyramid level) and lower it as they advance: the co-resident features progress
+// evenly and the last one finishes ~10 % earlier (measured: 53.9 -> 49.3 us span at 2000 features).
+__device__ __forceinline__ void set_level_priority(int level) {
+    if (level >= 3) {
+        __builtin_amdgcn_s_setprio(3);
+    } else if (level == 2) {
+        __builtin_amdgcn_s_setprio(2);
+    } else if (level == 1) {
+        __builtin_amdgcn_s_setprio(1);
+    } else {
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
 // An image window resident in LDS.  Element (r, c) packs the pixel pair
 // (img[clamp(r_lo + r)][clamp(c_lo + c)], img[clamp(r_lo + r)][clamp(c_lo + c + 1)]) into 16 bits,
 // clamp = clamp-to-edge, so the 2x2 neighbourhood of any in-image pixel is two ds_read_u16.

@@ -1276,6 +1276,7 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
         const DevImage cur = p.cur[level];
         __syncthreads();  // the previous level's readers of the LDS windows / arrays are done
         const Blk b = opaque_blk(b0);  // per-thread index math stays inside the level (see opaque())
+        set_level_priority(level);
         if (MODEL == FTK_MODEL_BASIC) {
             if (METHOD == FTK_METHOD_FAST) {
                 basic_level_fast(b, p, ref, cur, ref_u, ref_v, bs, status, iters, c);
