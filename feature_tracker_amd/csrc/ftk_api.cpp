@@ -186,16 +186,23 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.magic_cwc = div_magic(p.cwin_cols);
     p.magic_rwq = div_magic(p.rwin_cols / 4);
     p.magic_cwq = div_magic(p.cwin_cols / 4);
-    // Wavefronts per feature.  Small batches are latency-bound: up to 4 waves share the pixel loops
-    // (measured on MI355X, 21x21 patch: 56 / 41 / 32 us per call at 1 / 2 / 4 waves for <= 1024
-    // features).  Larger batches no longer fit the chip at 4 waves per feature (register-limited to
-    // 4 workgroups per CU), so they run 2 waves per feature, which keeps every workgroup resident.
+    // Wavefronts per feature (measured on MI355X; 4096 wave slots at 4 waves per SIMD):
+    //  * small batches are latency-bound: up to 4 waves share the pixel loops (21x21 patch, <= 1024
+    //    features: 56 / 41 / 32 us per call at 1 / 2 / 4 waves);
+    //  * beyond ~1024 features 4-wave workgroups no longer fit the chip at once: 2 waves;
+    //  * beyond ~2048 features the call is throughput-bound; patches of <= 256 pixels then run best
+    //    with ONE wave per feature (no barriers, no redundant uniform work: 25 000 features at 13x13
+    //    take 252 us instead of 346 us), larger patches keep 2 waves (the chain / sampling overlap
+    //    still pays), and so do the non-fast affine variants (24 chains per feature).
     int waves = (p.P + 63) / 64;
     if (waves > 4) {
         waves = 4;
     }
     if (n > 1024 && waves > 2) {
         waves = 2;
+    }
+    if (n > 2048 && p.P <= 256 && !(model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT))) {
+        waves = 1;
     }
     if (const char *env = getenv("FTK_KLT_WAVES")) {
         waves = atoi(env);  // experiment override
