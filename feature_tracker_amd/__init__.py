@@ -1,4 +1,4 @@
-"""feature_tracker_amd — MI355X-native pyramidal KLT trackers and BRIEF descriptor matcher.
+"""feature_tracker_amd — MI355X-native pyramidal KLT trackers and descriptor matchers (BRIEF Hamming, float cosine).
 
 Product layout: ``csrc/`` (hand-written HIP kernels + the C ABI of ``include/ftk.h``),
 ``host/`` (C++ classes with the reference's names on top of the ABI), ``tracker.py`` (the same
@@ -8,13 +8,13 @@ native library; the first compute call does, and fails loudly if it has not been
 """
 from . import synth  # noqa: F401
 from .tracker import (  # noqa: F401
-    BriefDescriptor, BriefMatcher, Context, FeaturePointHarrisDetector, DescriptorMatcherOptions, ImagePyramid, OpticalFlow, OpticalFlowAffineKlt, OpticalFlowBasicKlt,
+    BriefDescriptor, BriefMatcher, CosineMatcher, DiskMatcher, SuperpointMatcher, Context, FeaturePointHarrisDetector, DescriptorMatcherOptions, ImagePyramid, OpticalFlow, OpticalFlowAffineKlt, OpticalFlowBasicKlt,
     OpticalFlowLssdKlt, OpticalFlowOptions, default_context, pack_brief, unpack_brief,
     NOT_TRACKED, TRACKED, LARGE_RESIDUAL, OUTSIDE, NUMERIC_ERROR,
 )
 
 __all__ = [
-    "BriefDescriptor", "BriefMatcher", "Context", "FeaturePointHarrisDetector", "DescriptorMatcherOptions", "ImagePyramid", "OpticalFlow", "OpticalFlowAffineKlt", "OpticalFlowBasicKlt",
+    "BriefDescriptor", "BriefMatcher", "CosineMatcher", "DiskMatcher", "SuperpointMatcher", "Context", "FeaturePointHarrisDetector", "DescriptorMatcherOptions", "ImagePyramid", "OpticalFlow", "OpticalFlowAffineKlt", "OpticalFlowBasicKlt",
     "OpticalFlowLssdKlt", "OpticalFlowOptions", "default_context", "pack_brief", "unpack_brief", "synth",
     "NOT_TRACKED", "TRACKED", "LARGE_RESIDUAL", "OUTSIDE", "NUMERIC_ERROR",
 ]

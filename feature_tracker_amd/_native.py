@@ -27,7 +27,7 @@ EXPORTS = [
     "ftk_abi_version", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
     "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
-    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_fill_matched_pixels",
+    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_fill_matched_pixels",
     "ftk_brief_compute", "ftk_brief_compute_device", "ftk_harris_detect", "ftk_harris_response",
 ]
 
@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
     l.ftk_extract_extend_patch.argtypes = [vp, vp, i32, C.c_float, C.c_float, i32, i32, vp, vp, u32p]
     l.ftk_hamming_match.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
     l.ftk_hamming_match_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, vp]
+    l.ftk_cosine_match.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
+    l.ftk_cosine_match_device.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp]
     l.ftk_fill_matched_pixels.argtypes = [vp, i32, vp, i32, vp, vp]
     l.ftk_brief_compute.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp]
     l.ftk_brief_compute_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp]

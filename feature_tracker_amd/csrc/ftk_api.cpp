@@ -27,6 +27,9 @@ struct ftk_context {
     size_t scratch_bytes = 0;
     unsigned long long *match_keys = nullptr;
     size_t match_keys_count = 0;
+    // workspace of the float-descriptor matcher (fp16 copies, norms, candidate lists)
+    void *cosine_ws = nullptr;
+    size_t cosine_ws_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -111,6 +114,22 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     }
     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->match_keys), sizeof(unsigned long long) * count));
     ctx->match_keys_count = count;
+    return FTK_OK;
+}
+
+int ensure_cosine_ws(ftk_context *ctx, size_t bytes) {
+    if (bytes <= ctx->cosine_ws_bytes) {
+        return FTK_OK;
+    }
+    if (ctx->cosine_ws) {
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FTK_HIP(ctx, hipFree(ctx->cosine_ws));
+        ctx->cosine_ws = nullptr;
+        ctx->cosine_ws_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4, 4096);
+    FTK_HIP(ctx, hipMalloc(&ctx->cosine_ws, want));
+    ctx->cosine_ws_bytes = want;
     return FTK_OK;
 }
 
@@ -343,6 +362,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->match_keys) {
         (void)hipFree(ctx->match_keys);
+    }
+    if (ctx->cosine_ws) {
+        (void)hipFree(ctx->cosine_ws);
     }
     if (ctx->pinned) {
         (void)hipHostFree(ctx->pinned);
@@ -1028,6 +1050,142 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     FTK_HIP(ctx, hipMemcpyAsync(d_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
     rc = ftk_hamming_match_device(ctx, d_ref, n_ref, d_cur, n_cur, dev_words, n_bits, max_distance, d_pred, d_cuv, max_col_distance,
                                   max_row_distance, d_idx, nullptr);
+    if (rc != FTK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(index_pairs, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- float-descriptor matcher -------------------------------------------------------------- */
+
+int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n_ref, const float *d_cur_desc, int32_t n_cur, int32_t dim,
+                            float max_distance, const float *d_pred_uv, const float *d_cur_uv, int32_t max_col_distance,
+                            int32_t max_row_distance, int32_t *d_index_pairs) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "cosine_match_device: null context");
+    }
+    if (n_ref < 0 || n_cur < 0 || dim < 1) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "cosine_match_device: bad sizes (n_ref %d, n_cur %d, dim %d)", n_ref, n_cur, dim);
+    }
+    if (dim > 4096) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "cosine_match_device: dim %d > 4096", dim);
+    }
+    if (n_ref == 0 || n_cur == 0) {
+        return FTK_OK;
+    }
+    if (!d_ref_desc || !d_cur_desc || !d_index_pairs || (d_pred_uv && !d_cur_uv)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "cosine_match_device: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    ftk::CosineParams p;
+    p.ref = d_ref_desc;
+    p.cur = d_cur_desc;
+    p.pred_uv = d_pred_uv;
+    p.cur_uv = d_cur_uv;
+    p.index_pairs = d_index_pairs;
+    p.n_ref = n_ref;
+    p.n_cur = n_cur;
+    p.dim = dim;
+    p.n_ref_pad = (int32_t)align_up((size_t)n_ref, 128);
+    p.n_cur_pad = (int32_t)align_up((size_t)n_cur, 128);
+    p.dim_pad = (int32_t)align_up((size_t)dim, 64);
+    p.max_distance = max_distance;
+    p.max_col = (float)max_col_distance;
+    p.max_row = (float)max_row_distance;
+    // enough workgroups for ~3 per CU; each walks a contiguous run of cur tiles
+    const int row_tiles = p.n_ref_pad / 128, tiles_total = p.n_cur_pad / 128;
+    int splits = (768 + row_tiles - 1) / row_tiles;
+    splits = std::max(1, std::min(splits, tiles_total));
+    p.tiles_per_split = (tiles_total + splits - 1) / splits;
+    // workspace carve-up (every region 256-byte aligned)
+    size_t off = 0;
+    auto carve = [&off](size_t bytes) {
+        const size_t at = off;
+        off += align_up(bytes, 256);
+        return at;
+    };
+    const size_t o_ref_h = carve(sizeof(uint16_t) * (size_t)p.n_ref_pad * p.dim_pad);
+    const size_t o_cur_h = carve(sizeof(uint16_t) * (size_t)p.n_cur_pad * p.dim_pad);
+    const size_t o_ref_norm = carve(sizeof(float) * (size_t)p.n_ref_pad);
+    const size_t o_cur_norm = carve(sizeof(float) * (size_t)p.n_cur_pad);
+    const size_t o_cur_bias = carve(sizeof(float) * (size_t)p.n_cur_pad);
+    const size_t o_ref_irr = carve((size_t)p.n_ref_pad);
+    const size_t o_row_max = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
+    const size_t o_cnt = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
+    const size_t o_cand = carve(sizeof(int32_t) * (size_t)p.n_ref_pad * ftk::kCosineCandCap);
+    const size_t o_irr_cnt = carve(sizeof(uint32_t));
+    const size_t o_irr_list = carve(sizeof(int32_t) * ftk::kCosineIrregularCap);
+    const int rc = ensure_cosine_ws(ctx, off);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *ws = static_cast<uint8_t *>(ctx->cosine_ws);
+    p.ref_h = reinterpret_cast<_Float16 *>(ws + o_ref_h);
+    p.cur_h = reinterpret_cast<_Float16 *>(ws + o_cur_h);
+    p.ref_norm = reinterpret_cast<float *>(ws + o_ref_norm);
+    p.cur_norm = reinterpret_cast<float *>(ws + o_cur_norm);
+    p.cur_bias = reinterpret_cast<float *>(ws + o_cur_bias);
+    p.ref_irregular = ws + o_ref_irr;
+    p.row_max = reinterpret_cast<uint32_t *>(ws + o_row_max);
+    p.cand_count = reinterpret_cast<uint32_t *>(ws + o_cnt);
+    p.cand = reinterpret_cast<int32_t *>(ws + o_cand);
+    p.irregular_count = reinterpret_cast<uint32_t *>(ws + o_irr_cnt);
+    p.irregular_list = reinterpret_cast<int32_t *>(ws + o_irr_list);
+    FTK_HIP(ctx, ftk::cosine_match_launch(p, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, const float *cur_desc, int32_t n_cur, int32_t dim, float max_distance,
+                     const float *pred_uv, const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs,
+                     int *matched_ok) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "cosine_match: null context");
+    }
+    if (matched_ok) {
+        *matched_ok = 0;
+    }
+    if (n_ref < 0 || n_cur < 0 || dim < 1) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "cosine_match: bad sizes (n_ref %d, n_cur %d, dim %d)", n_ref, n_cur, dim);
+    }
+    if (n_cur == 0) {
+        return FTK_OK;  // descriptor_matcher.h:58,94 — `return false`
+    }
+    if (matched_ok) {
+        *matched_ok = 1;
+    }
+    if (n_ref == 0) {
+        return FTK_OK;
+    }
+    if (!ref_desc || !cur_desc || !index_pairs || (pred_uv && !cur_uv)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "cosine_match: null buffer");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ref_bytes = align_up(sizeof(float) * (size_t)n_ref * dim, 256);
+    const size_t cur_bytes = align_up(sizeof(float) * (size_t)n_cur * dim, 256);
+    const size_t pred_bytes = pred_uv ? align_up(sizeof(float) * 2 * (size_t)n_ref, 256) : 0;
+    const size_t cuv_bytes = pred_uv ? align_up(sizeof(float) * 2 * (size_t)n_cur, 256) : 0;
+    const size_t idx_bytes = align_up(sizeof(int32_t) * (size_t)n_ref, 256);
+    int rc = ensure_scratch(ctx, ref_bytes + cur_bytes + pred_bytes + cuv_bytes + idx_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_ref = reinterpret_cast<float *>(base);
+    float *d_cur = reinterpret_cast<float *>(base + ref_bytes);
+    float *d_pred = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes) : nullptr;
+    float *d_cuv = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes + pred_bytes) : nullptr;
+    int32_t *d_idx = reinterpret_cast<int32_t *>(base + ref_bytes + cur_bytes + pred_bytes + cuv_bytes);
+    FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_desc, sizeof(float) * (size_t)n_ref * dim, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_desc, sizeof(float) * (size_t)n_cur * dim, hipMemcpyHostToDevice, ctx->stream));
+    if (pred_uv) {
+        FTK_HIP(ctx, hipMemcpyAsync(d_pred, pred_uv, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpyAsync(d_cuv, cur_uv, sizeof(float) * 2 * (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FTK_HIP(ctx, hipMemcpyAsync(d_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    rc = ftk_cosine_match_device(ctx, d_ref, n_ref, d_cur, n_cur, dim, max_distance, d_pred, d_cuv, max_col_distance, max_row_distance, d_idx);
     if (rc != FTK_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;

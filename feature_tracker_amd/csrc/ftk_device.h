@@ -77,6 +77,28 @@ struct MatchParams {
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 
+// Float-descriptor (cosine distance) matcher: float_matcher_kernels.hip.
+constexpr int kCosineCandCap = 32;       // candidates kept per ref row before the row falls back to the exact scan
+constexpr int kCosineIrregularCap = 64;  // cur rows with a zero / non-finite / extreme norm kept in the side list
+struct CosineParams {
+    const float *ref, *cur;   // [n][dim] fp32 descriptors, row-major
+    const float *pred_uv;     // null => ForceMatch
+    const float *cur_uv;
+    int32_t *index_pairs;
+    // workspace (see ftk_cosine_workspace_bytes)
+    _Float16 *ref_h, *cur_h;  // unit-length fp16 copies, [n_pad][dim_pad], zero padded
+    float *ref_norm, *cur_norm, *cur_bias;
+    uint8_t *ref_irregular;
+    uint32_t *row_max, *cand_count;
+    int32_t *cand;            // [n_ref_pad][kCosineCandCap]
+    uint32_t *irregular_count;
+    int32_t *irregular_list;  // [kCosineIrregularCap]
+    int32_t n_ref, n_cur, dim, n_ref_pad, n_cur_pad, dim_pad;
+    int32_t tiles_per_split;  // 128-row cur tiles walked by one workgroup
+    float max_distance, max_col, max_row;
+};
+hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
+
 struct BriefParams {
     DevImage img;
     const float *uv;

@@ -107,6 +107,16 @@ def hamming_match_device(ctx: Context, ref_words, cur_words, n_bits: int, max_di
     N.check(rc, ctx.handle)
 
 
+def cosine_match_device(ctx: Context, ref_desc, cur_desc, max_distance: float, index_pairs, pred_uv=None, cur_uv=None, max_col: int = 40,
+                        max_row: int = 40):
+    """ForceMatch (pred_uv None) / NearbyMatch on float descriptors held in CUDA tensors ([n, dim] float32, contiguous)."""
+    rc = N.lib().ftk_cosine_match_device(
+        ctx.handle, C.c_void_p(ref_desc.data_ptr()), ref_desc.shape[0], C.c_void_p(cur_desc.data_ptr()), cur_desc.shape[0],
+        cur_desc.shape[1], float(max_distance), None if pred_uv is None else C.c_void_p(pred_uv.data_ptr()),
+        None if cur_uv is None else C.c_void_p(cur_uv.data_ptr()), int(max_col), int(max_row), C.c_void_p(index_pairs.data_ptr()))
+    N.check(rc, ctx.handle)
+
+
 def brief_compute_device(ctx: Context, image_pyr: ImagePyramid, uv, n_bits: int, half_patch: int, words_out, level: int = 0):
     """BRIEF descriptors of CUDA-resident features straight into packed CUDA words ([n, ceil(n_bits/32)] int32)."""
     rc = N.lib().ftk_brief_compute_device(ctx.handle, image_pyr.handle, int(level), C.c_void_p(uv.data_ptr()), uv.shape[0], int(n_bits),

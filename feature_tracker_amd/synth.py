@@ -130,6 +130,22 @@ def make_descriptors(n_ref: int, n_cur: int | None = None, n_bits: int = 256, fl
     return ref, cur, perm.astype(np.int32)
 
 
+def make_float_descriptors(n_ref: int, n_cur: int | None = None, dim: int = 256, noise: float = 0.25, seed: int = 11, normalize: bool = True):
+    """Float descriptors shaped like SuperPoint (dim 256) / DISK (dim 128) outputs: ref rows are random unit
+    vectors, cur[j] = ref[(7919 j) mod n_ref] + noise * gaussian (re-normalised), so the true match has cosine
+    distance ~ noise^2 / 4 and every other pair ~ 0.5.  Returns (ref, cur, perm)."""
+    n_cur = n_ref if n_cur is None else n_cur
+    rs = np.random.RandomState(seed)
+    ref = rs.standard_normal((n_ref, dim)).astype(np.float32)
+    perm = (7919 * np.arange(n_cur, dtype=np.int64)) % max(n_ref, 1)
+    cur = ref[perm] / np.sqrt(dim, dtype=np.float32) * np.float32(np.sqrt(dim)) if n_ref else np.zeros((n_cur, dim), np.float32)
+    cur = (cur + np.float32(noise) * rs.standard_normal((n_cur, dim)).astype(np.float32)).astype(np.float32)
+    if normalize:
+        ref = (ref / np.linalg.norm(ref, axis=1, keepdims=True)).astype(np.float32) if n_ref else ref
+        cur = (cur / np.linalg.norm(cur, axis=1, keepdims=True)).astype(np.float32) if n_cur else cur
+    return np.ascontiguousarray(ref), np.ascontiguousarray(cur), perm.astype(np.int32)
+
+
 def pack_bits(bits: np.ndarray) -> np.ndarray:
     """(n, n_bits) 0/1 bytes -> (n, ceil(n_bits/32)) uint32 words, bit i of the descriptor in bit (i % 32) of word i // 32."""
     n, n_bits = bits.shape

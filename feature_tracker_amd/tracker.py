@@ -453,3 +453,37 @@ class BriefMatcher:
             return False, None, status
         matched, st = self.FillMatchedPixelByPairIndices(idx, pixel_uv_cur, status)
         return True, matched, st
+
+
+class CosineMatcher(BriefMatcher):
+    """DescriptorMatcher<FloatDescriptor> with the cosine ComputeDistance of the reference's SuperPoint /
+    DISK callers (test/test_descriptor_matcher_superpoint.cpp:26-35, test_descriptor_matcher_disk.cpp:26-35):
+    0.5 - ref.dot(cur) / ref.norm() / cur.norm() * 0.5.  Descriptors are float arrays (n, dim).  Shares the
+    ForceMatch / NearbyMatch / FillMatchedPixelByPairIndices surface with BriefMatcher; only the device
+    entry point differs (ftk_cosine_match: fp16 MFMA shortlist + exact fp32 decision)."""
+
+    def _match(self, descriptors_ref, descriptors_cur, pred_uv, cur_uv, index_pairs):
+        ref = np.ascontiguousarray(descriptors_ref, dtype=np.float32)
+        cur = np.ascontiguousarray(descriptors_cur, dtype=np.float32)
+        n_ref, n_cur = ref.shape[0], cur.shape[0]
+        if n_cur == 0:
+            return False, index_pairs  # descriptor_matcher.h:58
+        dim = cur.shape[1]
+        if n_ref and ref.shape[1] != dim:
+            raise ValueError(f"descriptor sizes differ: ref {ref.shape[1]}, cur {dim}")
+        if index_pairs is None or np.asarray(index_pairs).size != n_ref:
+            idx = np.full(n_ref, -1, dtype=np.int32)
+        else:
+            idx = np.array(index_pairs, dtype=np.int32).copy()
+        ctx = self._ctx or default_context()
+        ok = C.c_int(0)
+        o = self._options
+        rc = N.lib().ftk_cosine_match(ctx.handle, _ptr(ref), n_ref, _ptr(cur), n_cur, dim, float(o.kMaxValidDescriptorDistance),
+                                      _ptr(pred_uv), _ptr(cur_uv), int(o.kMaxValidPredictColDistance), int(o.kMaxValidPredictRowDistance),
+                                      _ptr(idx), C.byref(ok))
+        N.check(rc, ctx.handle)
+        return bool(ok.value), idx
+
+
+SuperpointMatcher = CosineMatcher  # test/test_descriptor_matcher_superpoint.cpp:26
+DiskMatcher = CosineMatcher        # test/test_descriptor_matcher_disk.cpp:26

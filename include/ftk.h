@@ -202,6 +202,27 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
                              int32_t n_words, int32_t n_bits, float max_distance, const float *d_pred_uv, const float *d_cur_uv,
                              int32_t max_col_distance, int32_t max_row_distance, int32_t *d_index_pairs, uint64_t *d_workspace);
 
+/*
+ * Float descriptors.  Replaces DescriptorMatcher<T>::ForceMatch
+ * (descriptor_matcher.h:55-79) / ::NearbyMatch (:90-124) for the cosine distance the reference's
+ * SuperPoint / DISK callers define (test/test_descriptor_matcher_superpoint.cpp:32-34,
+ * test_descriptor_matcher_disk.cpp:32-34):
+ *     0.5f - ref.dot(cur) / ref.norm() / cur.norm() * 0.5f
+ * Descriptors are row-major float[n][dim] (256 for SuperPoint, 128 for DISK; any dim <= 4096).
+ * The all-pairs contraction runs on the matrix cores in fp16 only to shortlist the pairs that can
+ * decide a row; every deciding comparison is made on the distance evaluated in fp32 in Eigen's
+ * reduction order, so index_pairs is what the scalar loop returns (ties -> lowest index, strict
+ * threshold).  pred_uv == NULL selects ForceMatch.  index_pairs in/out and *matched_ok as in
+ * ftk_hamming_match.
+ */
+int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, const float *cur_desc, int32_t n_cur, int32_t dim, float max_distance,
+                     const float *pred_uv, const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs,
+                     int *matched_ok);
+/* Device-resident, asynchronous variant (workspace cached in the context). */
+int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n_ref, const float *d_cur_desc, int32_t n_cur, int32_t dim,
+                            float max_distance, const float *d_pred_uv, const float *d_cur_uv, int32_t max_col_distance,
+                            int32_t max_row_distance, int32_t *d_index_pairs);
+
 /* Replaces DescriptorMatcher::FillMatchedPixelByPairIndices (descriptor_matcher.h:135-157).
  * Pure index -> pixel gather on host buffers (O(n_ref), not worth a launch); status is in/out. */
 int ftk_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const float *cur_uv, int32_t n_cur, float *matched_uv, uint8_t *status);

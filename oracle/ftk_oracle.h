@@ -107,6 +107,19 @@ int orc_nearby_match_bits(const uint8_t *ref_bits, int32_t n_ref, const uint8_t 
 /* descriptor_matcher.h:135-157 */
 int orc_fill_matched_pixels(const int32_t *index_pairs, int32_t n_ref, const float *cur_uv, int32_t n_cur, float *matched_uv, uint8_t *status);
 
+/*
+ * descriptor_matcher.h:55-79 / :90-124 with the cosine distance of the float-descriptor callers
+ * (test/test_descriptor_matcher_superpoint.cpp:32-34, test_descriptor_matcher_disk.cpp:32-34);
+ * descriptors are row-major float[n][dim].  dot / norm follow Eigen 3.3.7's SSE2 reduction order
+ * (normative definition in oracle_float_matcher.c; unpinned — Eigen is un-vendored).
+ */
+float orc_eigen_dot(const float *x, const float *y, int32_t size);
+float orc_eigen_norm(const float *x, int32_t size);
+float orc_cosine_distance(const float *ref, const float *cur, int32_t size);
+int orc_force_match_float(const float *ref, int32_t n_ref, const float *cur, int32_t n_cur, int32_t dim, float max_distance, int32_t *index_pairs);
+int orc_nearby_match_float(const float *ref, int32_t n_ref, const float *cur, int32_t n_cur, int32_t dim, float max_distance, const float *pred_uv,
+                           const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs);
+
 /* BRIEF descriptor producer of the matcher (normative definition in oracle_brief.c). */
 void orc_brief_pattern(int32_t n_bits, int32_t half, int8_t *pattern);
 int orc_brief_compute(const orc_image *img, const float *uv, int32_t n, int32_t n_bits, int32_t half, uint8_t *bits);

@@ -145,6 +145,49 @@ def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, c
     }
 
 
+def float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, cpu_pairs):
+    """SuperPoint-256 / DISK-128 shaped cosine matcher."""
+    ref, cur, perm = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=0.2)
+    rs = np.random.RandomState(11)
+    cur_uv = np.stack([rs.uniform(0, 640, n_cur), rs.uniform(0, 480, n_cur)], axis=1).astype(np.float32)
+    pred_uv = np.stack([rs.uniform(0, 640, n_ref), rs.uniform(0, 480, n_ref)], axis=1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        d_ref, d_cur = torch.from_numpy(ref).to(dev), torch.from_numpy(cur).to(dev)
+        d_idx = torch.full((n_ref,), -1, dtype=torch.int32, device=dev)
+        d_pred = torch.from_numpy(pred_uv).to(dev) if nearby else None
+        d_cuv = torch.from_numpy(cur_uv).to(dev) if nearby else None
+        args = dict(pred_uv=d_pred, cur_uv=d_cuv, max_col=50, max_row=50)
+        D.cosine_match_device(ctx, d_ref, d_cur, 0.1, d_idx, **args)
+        stream.synchronize()
+        times = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            D.cosine_match_device(ctx, d_ref, d_cur, 0.1, d_idx, **args)
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        gpu_idx = d_idx.cpu().numpy()
+    rows = max(1, min(n_ref, cpu_pairs // n_cur))
+    t0 = time.perf_counter()
+    if nearby:
+        ok, cidx = oracle.match_float(ref[:rows], cur, 0.1, pred_uv[:rows], cur_uv, max_col=50, max_row=50)
+    else:
+        ok, cidx = oracle.match_float(ref[:rows], cur, 0.1)
+    cpu_s = time.perf_counter() - t0
+    gpu_ms = float(np.median(times))
+    flops = 2.0 * n_ref * n_cur * dim * 2  # two fp16 MFMA passes over all pairs
+    return {
+        "case": name, "mode": "nearby" if nearby else "force", "n_ref": n_ref, "n_cur": n_cur, "dim": dim, "gpu_call_ms": gpu_ms,
+        "gpu_pairs_per_s": n_ref * n_cur / gpu_ms * 1e3, "mfma_TFLOPs": flops / (gpu_ms * 1e-3) / 1e12, "cpu_sample_rows": rows,
+        "cpu_sample_s": cpu_s, "cpu_full_estimate_s": cpu_s * n_ref / rows, "speedup": (cpu_s * n_ref / rows) / (gpu_ms * 1e-3),
+        "indices_bit_exact_on_sample": bool(np.array_equal(gpu_idx[:rows], cidx)), "matched": int((gpu_idx >= 0).sum()),
+    }
+
+
 def producer_cases(torch, F, D, synth, oracle, reps):
     """Harris detection and BRIEF description on the reference's example-sized image."""
     from PIL import Image
@@ -184,6 +227,7 @@ def producer_cases(torch, F, D, synth, oracle, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="'cosine': just the float-descriptor matcher cases")
     args = ap.parse_args()
     import torch
 
@@ -194,6 +238,9 @@ def main():
 
     oracle.lib()
     reps = 10 if args.quick else 40
+    if args.only == "cosine":
+        float_matcher_cases(torch, F, D, synth, oracle, reps, args.quick)
+        return
     cases = []
     for key in ("config1", "config2", "config3", "config4", "config5_shard"):
         cases.append((key, dict(synth.CONFIGS[key])))
@@ -214,6 +261,16 @@ def main():
     for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True),
                                        ("match_300x300_nearby", 300, 300, True), ("match_2000_force", 2000, 2000, False)):
         out = matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000 if args.quick else 20_000_000)
+        print(json.dumps(out), flush=True)
+    float_matcher_cases(torch, F, D, synth, oracle, reps)
+
+
+def float_matcher_cases(torch, F, D, synth, oracle, reps, quick=False):
+    for name, n_ref, n_cur, dim, nearby in (("cosine_superpoint256_10000_force", 10000, 10000, 256, False),
+                                            ("cosine_superpoint256_10000_nearby", 10000, 10000, 256, True),
+                                            ("cosine_disk128_10000_force", 10000, 10000, 128, False),
+                                            ("cosine_superpoint256_300_nearby", 300, 300, 256, True)):
+        out = float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, 2_000_000 if quick else 8_000_000)
         print(json.dumps(out), flush=True)
 
 

@@ -42,7 +42,7 @@ def main(tag):
             for c in sorted(vals[k]):
                 v = vals[k][c]
                 w.writerow([k, meta[k][0], meta[k][1], c, len(v), statistics.median(v), min(v), max(v)])
-    klt = [k for k in vals if "klt_track_kernel" in k]
+    klt = [k for k in vals if "klt_basic_inverse_pipelined_kernel" in k] or [k for k in vals if "klt_track_kernel" in k]
     if klt:
         v = vals[klt[0]]
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:

@@ -45,6 +45,13 @@ def run_case(oracle, z):
         ok, idx = oracle.nearby_match(z["ref_bits"], z["cur_bits"], z["pred_uv"], z["cur_uv"], float(z["max_distance"]), int(z["max_col"]),
                                       int(z["max_row"]))
         return {"index": idx}
+    if kind == "float_force":
+        ok, idx = oracle.match_float(z["ref_desc"], z["cur_desc"], float(z["max_distance"]))
+        return {"index": idx}
+    if kind == "float_nearby":
+        ok, idx = oracle.match_float(z["ref_desc"], z["cur_desc"], float(z["max_distance"]), z["pred_uv"], z["cur_uv"], int(z["max_col"]),
+                                     int(z["max_row"]))
+        return {"index": idx}
     raise ValueError(kind)
 
 
@@ -61,7 +68,7 @@ def _klt_case(name, model, method, kind, ref_levels, cur_levels, ref_uv, half, h
     return name, d
 
 
-def generate():
+def generate(only=()):
     sys.path.insert(0, ROOT)
     from feature_tracker_amd import synth
     from tests import oracle_lib as oracle
@@ -95,7 +102,19 @@ def generate():
     cases.append(("match_nearby", dict(kind="nearby", ref_bits=bits_ref, cur_bits=bits_cur, pred_uv=puv, cur_uv=cuv,
                                        max_distance=np.float32(140.0), max_col=50, max_row=40)))
 
+    # float descriptors (cosine distance), stored as fp16-exact values to keep the fixtures small
+    fref, fcur, _ = synth.make_float_descriptors(96, 130, dim=128, noise=0.3)
+    fref, fcur = fref.astype(np.float16).astype(np.float32), fcur.astype(np.float16).astype(np.float32)
+    fcur[7] = fcur[3]  # a tie
+    fcur[11] = 0.0     # irregular candidate
+    cases.append(("match_float_force", dict(kind="float_force", ref_desc=fref.astype(np.float16), cur_desc=fcur.astype(np.float16),
+                                            max_distance=np.float32(0.2))))
+    cases.append(("match_float_nearby", dict(kind="float_nearby", ref_desc=fref.astype(np.float16), cur_desc=fcur.astype(np.float16), pred_uv=puv,
+                                             cur_uv=cuv, max_distance=np.float32(0.6), max_col=50, max_row=40)))
+
     for name, d in cases:
+        if only and name not in only:
+            continue
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)
         z = np.load(path)
@@ -105,4 +124,4 @@ def generate():
 
 
 if __name__ == "__main__":
-    generate()
+    generate(tuple(sys.argv[1:]))

@@ -50,6 +50,8 @@ def lib():
         _lib.orc_get_pixel_value_nocheck.restype = C.c_float
         _lib.orc_create_pyramid.restype = C.c_int64
         _lib.orc_extract_extend_patch.restype = C.c_uint32
+        for name in ("orc_eigen_dot", "orc_eigen_norm", "orc_cosine_distance"):
+            getattr(_lib, name).restype = C.c_float
     return _lib
 
 
@@ -196,6 +198,43 @@ def nearby_match(ref_bits, cur_bits, pred_uv, cur_uv, max_distance, max_col=40, 
     ok = lib().orc_nearby_match_bits(ref_bits.ctypes.data_as(C.c_void_p), n_ref, cur_bits.ctypes.data_as(C.c_void_p), n_cur, n_bits,
                                      C.c_float(max_distance), pred_uv.ctypes.data_as(C.c_void_p), cur_uv.ctypes.data_as(C.c_void_p),
                                      int(max_col), int(max_row), idx.ctypes.data_as(C.c_void_p))
+    return bool(ok), idx
+
+
+def eigen_dot(x, y):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    return np.float32(lib().orc_eigen_dot(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))
+
+
+def cosine_distance(ref, cur):
+    """SuperpointMatcher / DiskMatcher::ComputeDistance of one pair."""
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    cur = np.ascontiguousarray(cur, dtype=np.float32)
+    return np.float32(lib().orc_cosine_distance(ref.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), ref.size))
+
+
+def match_float(ref_desc, cur_desc, max_distance, pred_uv=None, cur_uv=None, max_col=40, max_row=40, index_pairs=None):
+    """ForceMatch (pred_uv is None) / NearbyMatch over float descriptors (n, dim) with the cosine distance."""
+    ref_desc = np.ascontiguousarray(ref_desc, dtype=np.float32)
+    cur_desc = np.ascontiguousarray(cur_desc, dtype=np.float32)
+    n_ref, n_cur = ref_desc.shape[0], cur_desc.shape[0]
+    dim = ref_desc.shape[1] if ref_desc.ndim == 2 else 0
+    if n_cur == 0:
+        return False, (np.zeros(0, np.int32) if index_pairs is None else np.array(index_pairs, np.int32))
+    if pred_uv is None:
+        idx = _prep_index(index_pairs, n_ref)
+        ok = lib().orc_force_match_float(ref_desc.ctypes.data_as(C.c_void_p), n_ref, cur_desc.ctypes.data_as(C.c_void_p), n_cur, dim,
+                                         C.c_float(max_distance), idx.ctypes.data_as(C.c_void_p))
+        return bool(ok), idx
+    pred_uv = np.ascontiguousarray(pred_uv, dtype=np.float32).reshape(-1, 2)
+    cur_uv = np.ascontiguousarray(cur_uv, dtype=np.float32).reshape(-1, 2)
+    if n_ref != pred_uv.shape[0] or n_cur != cur_uv.shape[0]:
+        return False, (np.zeros(0, np.int32) if index_pairs is None else np.array(index_pairs, np.int32))
+    idx = _prep_index(index_pairs, n_ref)
+    ok = lib().orc_nearby_match_float(ref_desc.ctypes.data_as(C.c_void_p), n_ref, cur_desc.ctypes.data_as(C.c_void_p), n_cur, dim,
+                                      C.c_float(max_distance), pred_uv.ctypes.data_as(C.c_void_p), cur_uv.ctypes.data_as(C.c_void_p),
+                                      int(max_col), int(max_row), idx.ctypes.data_as(C.c_void_p))
     return bool(ok), idx
 
 

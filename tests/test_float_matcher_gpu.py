@@ -1,0 +1,154 @@
+"""GPU parity tests: float-descriptor (cosine) ForceMatch / NearbyMatch against the CPU oracle — indices bit-exact.
+
+The device path shortlists pairs with an fp16 MFMA contraction and decides on the distance evaluated in fp32 in
+Eigen's reduction order (csrc/float_matcher_kernels.hip); these tests stress exactly the places where a shortlist
+could lose the deciding pair: near-ties, exact ties, thresholds at the minimum, irregular (zero / NaN / huge) rows,
+candidate-list overflow, ragged sizes and odd descriptor lengths."""
+import numpy as np
+import pytest
+
+from feature_tracker_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def matcher(ftk, max_dist, col=40, row=40):
+    m = ftk.CosineMatcher()
+    m.options().kMaxValidDescriptorDistance = max_dist
+    m.options().kMaxValidPredictColDistance = col
+    m.options().kMaxValidPredictRowDistance = row
+    return m
+
+
+@pytest.mark.parametrize("n_ref,n_cur,dim", [(1000, 1000, 256), (777, 1300, 128), (300, 257, 256), (100, 3000, 64), (129, 127, 96), (50, 70, 250), (33, 40, 7), (20, 20, 3)])
+def test_force_match(ftk, oracle, n_ref, n_cur, dim):
+    ref, cur, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim)
+    for thr in (0.1, 0.6):
+        ok_g, idx_g = matcher(ftk, thr).ForceMatch(ref, cur)
+        ok_c, idx_c = oracle.match_float(ref, cur, thr)
+        assert ok_g and ok_c
+        assert np.array_equal(idx_g, idx_c), (thr, np.flatnonzero(idx_g != idx_c)[:10])
+    assert (idx_c >= 0).sum() > 0
+
+
+def test_unnormalised_descriptors(ftk, oracle):
+    """The distance normalises by the norms, so raw (un-normalised, differently scaled) rows must match the same way."""
+    ref, cur, _ = synth.make_float_descriptors(400, 500, dim=128, normalize=False)
+    rs = np.random.RandomState(1)
+    ref *= rs.uniform(1e-3, 1e3, size=(400, 1)).astype(np.float32)
+    cur *= rs.uniform(1e-3, 1e3, size=(500, 1)).astype(np.float32)
+    ok_g, idx_g = matcher(ftk, 0.3).ForceMatch(ref, cur)
+    ok_c, idx_c = oracle.match_float(ref, cur, 0.3)
+    assert np.array_equal(idx_g, idx_c)
+
+
+def test_random_pairs_no_true_match(ftk, oracle):
+    """Independent random descriptors: all distances ~0.5, many near-ties inside the shortlist margin."""
+    rs = np.random.RandomState(5)
+    ref = rs.standard_normal((600, 256)).astype(np.float32)
+    cur = rs.standard_normal((2500, 256)).astype(np.float32)
+    ok_g, idx_g = matcher(ftk, 1.0).ForceMatch(ref, cur)
+    ok_c, idx_c = oracle.match_float(ref, cur, 1.0)
+    assert np.array_equal(idx_g, idx_c)
+    assert (idx_c >= 0).all()
+
+
+def test_exact_ties_lowest_index_and_strict_threshold(ftk, oracle):
+    """Duplicated candidates tie exactly: the lowest j wins; a threshold equal to the minimum never matches."""
+    ref, cur, _ = synth.make_float_descriptors(150, 150, dim=256, noise=0.3)
+    cur = np.concatenate([cur[::-1], cur, cur[::3]], axis=0).copy()
+    ok_g, idx_g = matcher(ftk, 0.5).ForceMatch(ref, cur)
+    ok_c, idx_c = oracle.match_float(ref, cur, 0.5)
+    assert np.array_equal(idx_g, idx_c)
+    d_min = np.array([oracle.cosine_distance(ref[i], cur[idx_c[i]]) for i in range(5)], dtype=np.float32)
+    for i in range(5):
+        for thr in (d_min[i], np.nextafter(d_min[i], np.float32(1.0))):
+            _, g = matcher(ftk, float(thr)).ForceMatch(ref[i:i + 1], cur)
+            _, c = oracle.match_float(ref[i:i + 1], cur, float(thr))
+            assert np.array_equal(g, c), (i, thr)
+    _, idx0 = ftk.CosineMatcher().ForceMatch(ref, cur)  # kMaxValidDescriptorDistance = 0: only a distance < 0 could match
+    _, idx0_c = oracle.match_float(ref, cur, 0.0)
+    assert np.array_equal(idx0, idx0_c)
+
+
+def test_candidate_overflow_falls_back_to_exact_scan(ftk, oracle):
+    """More near-minimal candidates than the per-row list holds (100 copies of every cur row)."""
+    ref, cur, _ = synth.make_float_descriptors(40, 12, dim=128)
+    cur = np.tile(cur, (100, 1))
+    ok_g, idx_g = matcher(ftk, 0.9).ForceMatch(ref, cur)
+    ok_c, idx_c = oracle.match_float(ref, cur, 0.9)
+    assert np.array_equal(idx_g, idx_c)
+    assert (idx_c < 12).all()  # lowest index of each group of copies
+
+
+def test_irregular_descriptors(ftk, oracle):
+    """Zero, NaN, inf, huge and tiny rows never enter the fp16 shortlist; the exact scan reproduces the scalar result."""
+    ref, cur, _ = synth.make_float_descriptors(200, 260, dim=256)
+    ref[3] = 0.0
+    ref[7, 5] = np.nan
+    ref[11] *= np.float32(1e25)   # squares overflow -> norm inf
+    ref[13] *= np.float32(1e-30)  # squares underflow -> norm 0
+    ref[17] *= np.float32(1e15)   # norm finite but outside the regular range
+    cur[2] = 0.0
+    cur[9, 100] = np.inf
+    cur[21] *= np.float32(1e-25)
+    cur[40] *= np.float32(3e14)
+    with np.errstate(all="ignore"):
+        ok_g, idx_g = matcher(ftk, 0.7).ForceMatch(ref, cur)
+        ok_c, idx_c = oracle.match_float(ref, cur, 0.7)
+    assert np.array_equal(idx_g, idx_c), np.flatnonzero(idx_g != idx_c)
+    # more irregular candidates than the side list holds: every row takes the exact scan
+    cur2 = cur.copy()
+    cur2[100:200] = 0.0
+    with np.errstate(all="ignore"):
+        _, g = matcher(ftk, 0.7).ForceMatch(ref, cur2)
+        _, c = oracle.match_float(ref, cur2, 0.7)
+    assert np.array_equal(g, c)
+
+
+@pytest.mark.parametrize("n_ref,n_cur,dim,window", [(1000, 1000, 256, 50), (500, 800, 128, 20), (300, 300, 256, 1000)])
+def test_nearby_match(ftk, oracle, n_ref, n_cur, dim, window):
+    ref, cur, perm = synth.make_float_descriptors(n_ref, n_cur, dim=dim)
+    rs = np.random.RandomState(9)
+    cur_uv = rs.uniform(0, 752, size=(n_cur, 2)).astype(np.float32)
+    pred_uv = rs.uniform(0, 752, size=(n_ref, 2)).astype(np.float32)
+    hit = rs.rand(n_cur) < 0.5  # half of the true matches lie inside the window
+    pred_uv[perm[hit]] = cur_uv[hit] + rs.uniform(-window, window, size=(int(hit.sum()), 2)).astype(np.float32) * np.float32(0.9)
+    m = matcher(ftk, 0.2, col=window, row=window // 2 + 1)
+    ok_g, idx_g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+    ok_c, idx_c = oracle.match_float(ref, cur, 0.2, pred_uv, cur_uv, max_col=window, max_row=window // 2 + 1)
+    assert ok_g and ok_c
+    assert np.array_equal(idx_g, idx_c)
+    ok, matched, st = m.NearbyMatchPixels(ref, cur, pred_uv, cur_uv)
+    m_c, st_c = oracle.fill_matched_pixels(idx_c, cur_uv)
+    assert ok and np.array_equal(st, st_c) and np.array_equal(matched[st == 1], m_c[st_c == 1])
+
+
+def test_stale_indices_and_empty_inputs(ftk, oracle):
+    ref, cur, _ = synth.make_float_descriptors(120, 90, dim=128)
+    stale = np.arange(120, dtype=np.int32) + 1000
+    _, idx_g = matcher(ftk, 0.02).ForceMatch(ref, cur, stale)
+    _, idx_c = oracle.match_float(ref, cur, 0.02, index_pairs=stale)
+    assert np.array_equal(idx_g, idx_c) and (idx_g >= 1000).any()
+    ok, _ = matcher(ftk, 0.5).ForceMatch(ref, cur[:0])
+    assert ok is False  # descriptor_matcher.h:58
+    ok, idx = matcher(ftk, 0.5).ForceMatch(ref[:0], cur)
+    assert ok is True and idx.size == 0
+    ok, _ = matcher(ftk, 0.5).NearbyMatch(ref, cur, np.zeros((5, 2), np.float32), np.zeros((90, 2), np.float32))
+    assert ok is False  # descriptor_matcher.h:95
+
+
+def test_full_size_properties(ftk):
+    """10 000 x 10 000 x 256 (BASELINE config 4's matcher shape, float variant): size-independent properties —
+    every row finds its planted partner, and the result is invariant under a permutation of the candidates."""
+    n = 10000
+    ref, cur, perm = synth.make_float_descriptors(n, n, dim=256, noise=0.2)
+    ok, idx = matcher(ftk, 0.1).ForceMatch(ref, cur)
+    assert ok
+    planted = np.full(n, -1, dtype=np.int64)
+    planted[perm[::-1]] = np.arange(n)[::-1]  # lowest j among duplicates of a ref row
+    assert np.array_equal(idx, planted.astype(np.int32))
+    rs = np.random.RandomState(2)
+    shuffle = rs.permutation(n)
+    ok, idx2 = matcher(ftk, 0.1).ForceMatch(ref, cur[shuffle])
+    assert np.array_equal(shuffle[idx2[idx2 >= 0]], idx[idx >= 0])

@@ -39,6 +39,16 @@ def test_hip_reproduces_golden(ftk, name):
         assert np.abs(c.astype(np.float64) - z["out_uv"].astype(np.float64))[np.isfinite(z["out_uv"])].max() <= 1e-3  # north_star tolerance
         assert np.array_equal(c.view(np.uint32), z["out_uv"].view(np.uint32))  # design goal: bit-identical
         assert np.array_equal(klt.last_iterations, z["out_iters"])
+    elif kind in ("float_force", "float_nearby"):
+        m = ftk.CosineMatcher()
+        m.options().kMaxValidDescriptorDistance = float(z["max_distance"])
+        if kind == "float_force":
+            ok, idx = m.ForceMatch(z["ref_desc"], z["cur_desc"])
+        else:
+            m.options().kMaxValidPredictColDistance = int(z["max_col"])
+            m.options().kMaxValidPredictRowDistance = int(z["max_row"])
+            ok, idx = m.NearbyMatch(z["ref_desc"], z["cur_desc"], z["pred_uv"], z["cur_uv"])
+        assert ok and np.array_equal(idx, z["out_index"])
     else:
         m = ftk.BriefMatcher()
         m.options().kMaxValidDescriptorDistance = float(z["max_distance"])

@@ -253,3 +253,98 @@ def test_brief_oracle_known_answers(oracle):
     assert np.array_equal(bits[0], (pattern[:, 1] < pattern[:, 3]).astype(np.uint8))
     # margin = half + 1 = 9: u = 8.4 rounds to column 8 (outside -> all zero), u = 8.5 rounds to column 9 (inside)
     assert not bits[1].any() and bits[2].any()
+
+
+# ---- float-descriptor matcher: Eigen reduction order + matcher semantics ----
+
+def _eigen_dot_numpy(x, y):
+    """Independent restatement of Eigen 3.3.7's SSE2 redux (two packet accumulators, predux (a0+a2)+(a1+a3), scalar tail)."""
+    f = np.float32
+    p = (x.astype(f) * y.astype(f)).astype(f)
+    n = p.size
+    aligned, end2 = (n // 4) * 4, (n // 8) * 8
+    if aligned == 0:
+        res = p[0]
+        for k in range(1, n):
+            res = f(res + p[k])
+        return res
+    p0 = p[0:4].copy()
+    if aligned > 4:
+        p1 = p[4:8].copy()
+        for i in range(8, end2, 8):
+            p0 = (p0 + p[i:i + 4]).astype(f)
+            p1 = (p1 + p[i + 4:i + 8]).astype(f)
+        p0 = (p0 + p1).astype(f)
+        if aligned > end2:
+            p0 = (p0 + p[end2:end2 + 4]).astype(f)
+    res = f(f(p0[0] + p0[2]) + f(p0[1] + p0[3]))
+    for k in range(aligned, n):
+        res = f(res + p[k])
+    return res
+
+
+def test_eigen_dot_order_known_answers(oracle):
+    one = np.ones(4, np.float32)
+    # packet order (a0 + a2) + (a1 + a3) = (1e8 - 1e8) + (1 + 1) = 2; a left-to-right sum would give 1
+    assert oracle.eigen_dot(np.array([1e8, 1, -1e8, 1], np.float32), one) == np.float32(2.0)
+    # size 8: the two packets are added lane-wise first: [1e8+(-1e8), 1+1, 0, 0] -> (0 + 0) + (2 + 0) = 2; sequential gives 1
+    x8 = np.array([1e8, 1, 0, 0, -1e8, 1, 0, 0], np.float32)
+    assert oracle.eigen_dot(x8, np.ones(8, np.float32)) == np.float32(2.0)
+    # sizes below one packet reduce left to right: (1e8 + 1) - 1e8 = 0
+    assert oracle.eigen_dot(np.array([1e8, 1, -1e8], np.float32), np.ones(3, np.float32)) == np.float32(0.0)
+    # scalar tail after the packets (size 6): predux of the first packet, then + x[4], + x[5]
+    x6 = np.array([1e8, 0, -1e8, 0, 1, 1], np.float32)
+    assert oracle.eigen_dot(x6, np.ones(6, np.float32)) == np.float32(2.0)
+
+
+def test_eigen_dot_matches_independent_restatement(oracle):
+    rs = np.random.RandomState(0)
+    for n in list(range(1, 41)) + [63, 64, 96, 100, 128, 250, 256, 257, 512]:
+        x = (rs.standard_normal(n) * 10 ** rs.uniform(-3, 3, n)).astype(np.float32)
+        y = rs.standard_normal(n).astype(np.float32)
+        assert oracle.eigen_dot(x, y).view(np.uint32) == _eigen_dot_numpy(x, y).view(np.uint32), n
+
+
+def test_cosine_distance_known_answers(oracle):
+    e0 = np.zeros(256, np.float32)
+    e0[0] = 3.0
+    e1 = np.zeros(256, np.float32)
+    e1[1] = 0.5
+    assert oracle.cosine_distance(e0, e0) == np.float32(0.0)       # 0.5 - 9 / 3 / 3 * 0.5
+    assert oracle.cosine_distance(e0, -e0) == np.float32(1.0)
+    assert oracle.cosine_distance(e0, e1) == np.float32(0.5)
+    with np.errstate(all="ignore"):
+        assert np.isnan(oracle.cosine_distance(e0, np.zeros(256, np.float32)))  # 0 / 3 / 0 -> NaN: never matches
+
+
+def test_float_matcher_semantics(oracle):
+    ref, cur, perm = synth.make_float_descriptors(40, 30, dim=128)
+    ok, idx = oracle.match_float(ref, cur, 0.1)
+    assert ok and (idx[perm] == np.arange(30)).all() and (idx >= 0).sum() == 30
+    # exact ties -> lowest index; strict threshold: distance == threshold does not match
+    cur2 = np.concatenate([cur, cur], axis=0)
+    _, idx2 = oracle.match_float(ref, cur2, 0.1)
+    assert np.array_equal(idx2, idx)
+    d = oracle.cosine_distance(ref[perm[0]], cur[0])
+    _, at = oracle.match_float(ref[perm[0]:perm[0] + 1], cur, float(d))
+    _, above = oracle.match_float(ref[perm[0]:perm[0] + 1], cur, float(np.nextafter(d, np.float32(1))))
+    assert at[0] == -1 and above[0] == 0
+    # default threshold 0 matches nothing (descriptor_matcher.h:19); stale entries survive
+    _, none = oracle.match_float(ref, cur, 0.0, index_pairs=np.full(40, 77, np.int32))
+    assert (none == 77).all()
+    # window test and size checks of NearbyMatch (:94-96, :108-111)
+    cur_uv = np.zeros((30, 2), np.float32)
+    pred = np.zeros((40, 2), np.float32)
+    pred[perm[3]] = (41.0, 0.0)
+    _, near = oracle.match_float(ref, cur, 0.1, pred, cur_uv, max_col=40, max_row=40)
+    assert near[perm[3]] == -1 and near[perm[4]] == 4
+    ok, _ = oracle.match_float(ref, cur, 0.1, pred[:5], cur_uv)
+    assert ok is False
+    ok, _ = oracle.match_float(ref, cur[:0], 0.1)
+    assert ok is False
+    # a zero descriptor has NaN distance to everything and is never matched, nor does it block others
+    cur3 = cur.copy()
+    cur3[0] = 0
+    with np.errstate(all="ignore"):
+        _, z = oracle.match_float(ref, cur3, 0.6)
+    assert (z != 0).all()
