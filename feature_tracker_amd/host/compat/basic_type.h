@@ -108,10 +108,36 @@ public:
             for (int c = 0; c < C; ++c) m(c, r) = (*this)(r, c);
         return m;
     }
+    // Small matrices: left-to-right.  Descriptor-sized vectors (SuperPoint 256, DISK 128): Eigen's
+    // reduction for the reference's SSE2 build once the expression cost passes EIGEN_UNROLLING_LIMIT
+    // (redux_impl<LinearVectorizedTraversal, NoUnrolling>, Core/Redux.h): two packet accumulators,
+    // their sum, a trailing packet, predux (a0 + a2) + (a1 + a3), scalar tail.  Same definition as
+    // oracle/oracle_float_matcher.c and the device's exact pass (csrc/float_matcher_kernels.hip).
     float dot(const FixedMat &o) const {
-        float s = 0.0f;
-        for (int i = 0; i < R * C; ++i) s += d_[i] * o.d_[i];
-        return s;
+        constexpr int n = R * C;
+        if constexpr (n * 3 + (n - 1) > 400) {
+            constexpr int aligned_size = (n / 4) * 4, aligned_end2 = (n / 8) * 8;
+            float p0[4], p1[4];
+            for (int q = 0; q < 4; ++q) p0[q] = d_[q] * o.d_[q];
+            for (int q = 0; q < 4; ++q) p1[q] = d_[4 + q] * o.d_[4 + q];
+            for (int index = 8; index < aligned_end2; index += 8) {
+                for (int q = 0; q < 4; ++q) {
+                    p0[q] = p0[q] + d_[index + q] * o.d_[index + q];
+                    p1[q] = p1[q] + d_[index + 4 + q] * o.d_[index + 4 + q];
+                }
+            }
+            for (int q = 0; q < 4; ++q) p0[q] = p0[q] + p1[q];
+            if (aligned_size > aligned_end2) {
+                for (int q = 0; q < 4; ++q) p0[q] = p0[q] + d_[aligned_end2 + q] * o.d_[aligned_end2 + q];
+            }
+            float res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
+            for (int index = aligned_size; index < n; ++index) res = res + d_[index] * o.d_[index];
+            return res;
+        } else {
+            float s = 0.0f;
+            for (int i = 0; i < n; ++i) s += d_[i] * o.d_[i];
+            return s;
+        }
     }
     float squaredNorm() const { return dot(*this); }
     float norm() const { return std::sqrt(squaredNorm()); }

@@ -1,4 +1,6 @@
-// descriptor_matcher.cpp — device side of DescriptorMatcher<std::vector<bool>>: packs the per-bit
+// descriptor_matcher.cpp — device side of DescriptorMatcher<T>.  Float descriptors go to
+// ftk_cosine_match as they are (a std::vector of packed float vectors is one n x dim array).
+// DescriptorMatcher<std::vector<bool>>: packs the per-bit
 // BRIEF containers into 32-bit words and runs the all-pairs Hamming scan on the MI355X
 // (replaces the double loops of descriptor_matcher.h:55-79 / :90-124 of the reference for the
 // distance of test/test_descriptor_matcher_brief.cpp:33-45).
@@ -66,6 +68,27 @@ bool HammingMatch(const std::vector<std::vector<bool>> &descriptors_ref, const s
                                      pixel_uv_pred_in_cur ? (*pixel_uv_pred_in_cur)[0].data() : nullptr,
                                      pixel_uv_cur ? (*pixel_uv_cur)[0].data() : nullptr, max_col_distance, max_row_distance,
                                      index_pairs_in_cur.data(), &ok);
+    if (rc != FTK_OK) {
+        ReportError("[DescriptorMatcher] " << ftk_last_error(ctx));
+        return false;
+    }
+    return ok != 0;
+}
+
+bool CosineMatch(const float *descriptors_ref, int32_t n_ref, const float *descriptors_cur, int32_t n_cur, int32_t dim,
+                 const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur, float max_distance,
+                 int32_t max_col_distance, int32_t max_row_distance, std::vector<int32_t> &index_pairs_in_cur) {
+    std::string error;
+    ftk_context *ctx = SharedContext(&error);
+    if (ctx == nullptr) {
+        ReportError("[DescriptorMatcher] " << error);
+        return false;
+    }
+    int ok = 0;
+    const int rc = ftk_cosine_match(ctx, descriptors_ref, n_ref, descriptors_cur, n_cur, dim, max_distance,
+                                    pixel_uv_pred_in_cur ? (*pixel_uv_pred_in_cur)[0].data() : nullptr,
+                                    pixel_uv_cur ? (*pixel_uv_cur)[0].data() : nullptr, max_col_distance, max_row_distance,
+                                    index_pairs_in_cur.data(), &ok);
     if (rc != FTK_OK) {
         ReportError("[DescriptorMatcher] " << ftk_last_error(ctx));
         return false;

@@ -8,14 +8,18 @@
 //     distance (probed on a few pairs at call time): the all-pairs loop runs on the MI355X
 //     (ftk_hamming_match: bit-packed descriptors, popcount kernel).  A device failure is reported
 //     and the call returns false; the host loop is NOT used as a fallback for this case.
+//   * DescriptorType is a fixed-size float vector (the SuperPoint-256 / DISK-128 descriptors of
+//     test/test_descriptor_matcher_{superpoint,disk}.cpp) and the caller's ComputeDistance IS the
+//     cosine distance 0.5f - a.dot(b) / a.norm() / b.norm() * 0.5f (probed bit for bit on a few
+//     pairs): ftk_cosine_match — fp16 MFMA shortlist, exact fp32 decision on the device.
 //   * any other descriptor type / distance: the distance is arbitrary caller code behind a virtual,
-//     so the double loop below runs on the host exactly as written in the reference.  That generic
-//     path is API compatibility (SuperPoint / DISK cosine matchers), not the accelerated hot path.
+//     so the double loop below runs on the host exactly as written in the reference.
 #ifndef _DESCRIPTOR_MATCHER_H_
 #define _DESCRIPTOR_MATCHER_H_
 
 #include <cmath>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "basic_type.h"
@@ -33,7 +37,22 @@ bool HammingMatch(const std::vector<std::vector<bool>> &descriptors_ref, const s
                   int32_t max_col_distance, int32_t max_row_distance, std::vector<int32_t> &index_pairs_in_cur);
 // Plain Hamming distance of two per-bit descriptors, used for the call-time probe.
 float HammingDistance(const std::vector<bool> &a, const std::vector<bool> &b);
+// Float descriptors stored back to back (n x dim floats).  pred_uv == nullptr selects ForceMatch.
+bool CosineMatch(const float *descriptors_ref, int32_t n_ref, const float *descriptors_cur, int32_t n_cur, int32_t dim,
+                 const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur, float max_distance,
+                 int32_t max_col_distance, int32_t max_row_distance, std::vector<int32_t> &index_pairs_in_cur);
 }  // namespace device
+
+namespace detail {
+// FixedMat<N, 1>-like: contiguous floats, nothing else in the object, dot() / norm() members.
+template <typename T, typename = void>
+struct IsFloatVector : std::false_type {};
+template <typename T>
+struct IsFloatVector<T, std::void_t<decltype(std::declval<const T &>().data()), decltype(std::declval<const T &>().dot(std::declval<const T &>())),
+                                    decltype(std::declval<const T &>().norm()), decltype(T::size())>>
+    : std::integral_constant<bool, std::is_same<decltype(std::declval<const T &>().data()), const float *>::value &&
+                                       sizeof(T) == sizeof(float) * static_cast<size_t>(T::size())> {};
+}  // namespace detail
 
 /* Class Descriptor Matcher Declaration. */
 template <typename DescriptorType>
@@ -78,6 +97,10 @@ private:
     // handful of pairs spread over the inputs.
     bool DistanceIsHamming(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur);
 
+    // True when DescriptorType is a packed float vector and ComputeDistance agrees bit for bit with
+    // the cosine distance of the reference's SuperPoint / DISK matchers on a handful of pairs.
+    bool DistanceIsCosine(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur);
+
     // Shared body of ForceMatch / NearbyMatch (pred == nullptr: no window test).
     bool MatchIndices(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,
                       const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur,
@@ -118,6 +141,31 @@ bool DescriptorMatcher<DescriptorType>::DistanceIsHamming(const std::vector<Desc
 }
 
 template <typename DescriptorType>
+bool DescriptorMatcher<DescriptorType>::DistanceIsCosine(const std::vector<DescriptorType> &descriptors_ref,
+                                                         const std::vector<DescriptorType> &descriptors_cur) {
+    if constexpr (detail::IsFloatVector<DescriptorType>::value) {
+        const size_t n_ref = descriptors_ref.size(), n_cur = descriptors_cur.size();
+        if (n_ref == 0 || n_cur == 0) {
+            return true;
+        }
+        const size_t probes = 6;
+        for (size_t k = 0; k < probes; ++k) {
+            const DescriptorType &a = descriptors_ref[(k * 7919u + 1u) % n_ref];
+            const DescriptorType &b = descriptors_cur[(k * 104729u + 3u) % n_cur];
+            const float expect = 0.5f - a.dot(b) / a.norm() / b.norm() * 0.5f;
+            const float got = ComputeDistance(a, b);
+            // bitwise equal, or both NaN (a zero descriptor)
+            RETURN_FALSE_IF(!(got == expect || (got != got && expect != expect)));
+        }
+        return true;
+    } else {
+        (void)descriptors_ref;
+        (void)descriptors_cur;
+        return false;
+    }
+}
+
+template <typename DescriptorType>
 bool DescriptorMatcher<DescriptorType>::MatchIndices(const std::vector<DescriptorType> &descriptors_ref,
                                                      const std::vector<DescriptorType> &descriptors_cur,
                                                      const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur,
@@ -132,6 +180,18 @@ bool DescriptorMatcher<DescriptorType>::MatchIndices(const std::vector<Descripto
         if (DistanceIsHamming(descriptors_ref, descriptors_cur)) {
             return device::HammingMatch(descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, options_.kMaxValidDescriptorDistance,
                                         options_.kMaxValidPredictColDistance, options_.kMaxValidPredictRowDistance, index_pairs_in_cur);
+        }
+    }
+
+    if constexpr (detail::IsFloatVector<DescriptorType>::value) {
+        if (DistanceIsCosine(descriptors_ref, descriptors_cur)) {
+            if (descriptors_ref.empty()) {
+                return true;
+            }
+            return device::CosineMatch(descriptors_ref[0].data(), static_cast<int32_t>(descriptors_ref.size()), descriptors_cur[0].data(),
+                                       static_cast<int32_t>(descriptors_cur.size()), static_cast<int32_t>(DescriptorType::size()),
+                                       pixel_uv_pred_in_cur, pixel_uv_cur, options_.kMaxValidDescriptorDistance,
+                                       options_.kMaxValidPredictColDistance, options_.kMaxValidPredictRowDistance, index_pairs_in_cur);
         }
     }
 

@@ -114,6 +114,62 @@ def test_cpp_brief_matcher_matches_oracle(tmp_path, oracle, mode):
     assert np.array_equal(got[ost == 1], omatched[ost == 1])
 
 
+@pytest.mark.parametrize("mode,dim", [("force", 256), ("nearby", 256), ("force", 128), ("nearby", 128)])
+def test_cpp_float_matcher_matches_oracle(tmp_path, oracle, mode, dim):
+    """DescriptorMatcher<SuperpointDescriptorType / DiskDescriptorType> with the reference's cosine ComputeDistance: the
+    probe must recognise it, the call must run on the device, and the indices must be the oracle's."""
+    ref, cur, perm = synth.make_float_descriptors(300, 420, dim=dim, noise=0.3)
+    rs = np.random.RandomState(4)
+    cur_uv = np.stack([rs.uniform(0, 640, 420), rs.uniform(0, 480, 420)], axis=1).astype(np.float32)
+    ref_uv = np.stack([rs.uniform(0, 640, 300), rs.uniform(0, 480, 300)], axis=1).astype(np.float32)
+    ref_uv[perm[:300] % 300] = cur_uv[:300] + 5.0
+    with open(tmp_path / "d.bin", "wb") as f:
+        f.write(struct.pack("<ii", 300, 420))
+        for a in (ref, cur, ref_uv, cur_uv):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    exe = os.path.join(BUILD, "match_float_cli")
+    res = subprocess.run([exe, mode, str(dim), "0.1", "50", "40", str(tmp_path / "d.bin")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0] == "ok 1" and lines[1] == "ok2 1" and lines[2] == "device 1", lines[:3]
+    rows = [l.split() for l in lines[3:]]
+    idx = np.array([int(r[0]) for r in rows], np.int32)
+    st = np.array([int(r[1]) for r in rows], np.uint8)
+    if mode == "force":
+        ok, oidx = oracle.match_float(ref, cur, 0.1)
+    else:
+        ok, oidx = oracle.match_float(ref, cur, 0.1, ref_uv, cur_uv, max_col=50, max_row=40)
+    assert np.array_equal(idx, oidx)
+    assert (oidx >= 0).sum() > 50
+    omatched, ost = oracle.fill_matched_pixels(oidx, cur_uv)
+    assert np.array_equal(st, ost)
+    got = np.array([[int(r[2], 16), int(r[3], 16)] for r in rows], dtype=np.uint32).view(np.float32)
+    assert np.array_equal(got[ost == 1], omatched[ost == 1])
+
+
+@pytest.mark.parametrize("prog,expect", [("test_optical_flow", r"tracked|cost time"), ("test_descriptor_matcher_brief", r"tracked features (\d+) / (\d+)"),
+                                         ("test_descriptor_matcher_superpoint", r"tracked features (\d+) / (\d+)"),
+                                         ("test_descriptor_matcher_disk", r"tracked features (\d+) / (\d+)")])
+def test_reference_callers_run_unchanged(tmp_path, prog, expect):
+    """The reference's own test programs, compiled UNCHANGED against this repo's headers / libraries by
+    scripts/check_dropin.sh (only possible where the reference is mounted; the binaries travel as build artefacts),
+    run headless on the GPU with the reference's example images at the relative path they hard-code."""
+    import re
+    exe = os.path.join(BUILD, "dropin", prog)
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (the reference is not mounted on this machine)")
+    os.makedirs(tmp_path / "example", exist_ok=True)
+    os.symlink(DATA, tmp_path / "example" / "optical_flow")
+    os.makedirs(tmp_path / "build", exist_ok=True)
+    res = subprocess.run([exe], cwd=tmp_path / "build", capture_output=True, text=True, timeout=180)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out[-2000:]
+    m = re.search(expect, out)
+    assert m, out[-2000:]
+    if m.groups():
+        assert int(m.group(2)) >= 50 and int(m.group(1)) >= 10, out[-1000:]  # matches found on the real image pair
+
+
 def test_demo_on_reference_example_images():
     """The reference's own example pair (752x480 PNGs): Harris corners -> pyramids -> 3 trackers; most corners must track."""
     exe = os.path.join(BUILD, "demo_optical_flow")
