@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) cosine_gemm_kernel(const CosineParams p) 
                     float v = acc[mt][nt][r] + info.x;  // bias: 0, or -inf for padding / irregular candidates
                     if (kNearby) {
                         // window test of descriptor_matcher.h:108-111, branch-free
-                        const bool out = (fabsf(pu[nt] - info.y) > p.max_col) | (fabsf(pv[nt] - info.z) > p.max_row);
+                        const bool out = (int)(fabsf(pu[nt] - info.y) > p.max_col) | (int)(fabsf(pv[nt] - info.z) > p.max_row);
                         v = out ? neg_inf : v;
                     }
                     if (!kCollect) {

@@ -38,6 +38,9 @@ namespace ftk {
 namespace {
 
 constexpr int kChunk = 64;  // pixels per chunk = one producer wave round
+// Ring rows are kChunk + 4 floats apart: the consumer's lanes read 16 bytes each from DIFFERENT rows
+// at the same column, and a row pitch of 256 B would put all of them on the same four banks.
+constexpr int kRingRow = kChunk + 4;
 constexpr int kTerms = 5;   // 0 H00, 1 H11, 2 H01, 3 -fx*ft, 4 -fy*ft (basic_klt.cpp:139-144)
 constexpr int kCurQuads = 4;  // 8-byte window loads a thread may hold in flight (current window)
 constexpr int kRefQuads = 3;  // ... (next level's reference window)
@@ -50,7 +53,7 @@ struct PbLds {
     float4 *rnodes, *cnodes;  // lattice nodes per axis: {window element offset, fraction, 1 - fraction, valid}
     uint4 *ridx, *cidx;       // per patch row / column: {centre node, minus node, plus node, all three valid}
     float4 *ctab;             // per producer wave: 2 float4 per patch row, then per patch column (see cur_tables)
-    float *ring;              // [2][producers][kTerms][kChunk]
+    float *ring;              // [2][producers][kTerms][kRingRow]
     float *lattice;           // [n_r][n_c] reference bilinear values
     float *sol;               // 4 floats: published solution
     uint32_t *slots;          // 16: node counts (0, 1), valid-pixel counts by iteration parity (4 + 4 * parity + wave)
@@ -64,7 +67,7 @@ __host__ __device__ inline size_t pb_lds_bytes(const KltParams &p, int waves) {
     size_t bytes = 16 * (size_t)(p.pb_cap_r + p.pb_cap_c);
     bytes += 16 * (size_t)(p.patch_rows + p.patch_cols);
     bytes += 16 * (size_t)np * 2 * (p.patch_rows + p.patch_cols);
-    bytes += 4 * (size_t)2 * np * kTerms * kChunk;
+    bytes += 4 * (size_t)2 * np * kTerms * kRingRow;
     bytes += 4 * (size_t)pb_pad4(p.pb_cap_r * p.pb_cap_c);
     bytes += 4 * 4 + 4 * 16;
     bytes += 2 * (size_t)2 * pb_pad4(p.pb_rwin_rows * p.pb_rwin_cols);
@@ -81,7 +84,7 @@ __device__ __forceinline__ PbLds pb_carve(float4 *base, const KltParams &p, int 
     c.cidx = c.ridx + p.patch_rows;
     c.ctab = reinterpret_cast<float4 *>(c.cidx + p.patch_cols);
     c.ring = reinterpret_cast<float *>(c.ctab + np * 2 * (p.patch_rows + p.patch_cols));
-    c.lattice = c.ring + 2 * np * kTerms * kChunk;
+    c.lattice = c.ring + 2 * np * kTerms * kRingRow;
     c.sol = c.lattice + pb_pad4(p.pb_cap_r * p.pb_cap_c);
     c.slots = reinterpret_cast<uint32_t *>(c.sol + 4);
     c.ref_win = reinterpret_cast<uint16_t *>(c.slots + 16);
@@ -281,11 +284,11 @@ __device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltPara
     const float fx = ok ? right - left : 0.0f;
     const float fy = ok ? bottom - top : 0.0f;
     const float ft = ok ? i_cur - i_ref : 0.0f;
-    slot[0 * kChunk + lane] = fx * fx;
-    slot[1 * kChunk + lane] = fy * fy;
-    slot[2 * kChunk + lane] = fx * fy;
-    slot[3 * kChunk + lane] = -(fx * ft);
-    slot[4 * kChunk + lane] = -(fy * ft);
+    slot[0 * kRingRow + lane] = fx * fx;
+    slot[1 * kRingRow + lane] = fy * fy;
+    slot[2 * kRingRow + lane] = fx * fy;
+    slot[3 * kRingRow + lane] = -(fx * ft);
+    slot[4 * kRingRow + lane] = -(fy * ft);
     return ok;
 }
 
@@ -485,7 +488,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (producer) {
                     const int chunk = s * np + pw;
                     if (chunk < n_chunks) {
-                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & 1) * np + pw) * kTerms * kChunk);
+                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & 1) * np + pw) * kTerms * kRingRow);
                         wave_valid += (uint32_t)__popcll(__ballot(ok));
                     }
                     if (s == n_steps - 1 && b.lane == 0) {
@@ -496,7 +499,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (consumer && b.lane < kTerms) {
                     for (int q = 0; q < np; ++q) {
                         if (s * np + q < n_chunks) {
-                            acc = chain_chunk(acc, c.ring + (((s & 1) * np + q) * kTerms + b.lane) * kChunk);
+                            acc = chain_chunk(acc, c.ring + (((s & 1) * np + q) * kTerms + b.lane) * kRingRow);
                         }
                     }
                 }
@@ -579,6 +582,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     }
 #endif
 }
+
 
 }  // namespace
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): marginal kernel time of one pyramid level and of one Gauss-Newton iteration
 on the config-2 workload, by timing the same launch with fewer levels / a lower kMaxIteration.
-    python scripts/marginal_costs.py [n_features]
+    python scripts/marginal_costs.py [n_features [levels max_iteration]]     (one combination only, for PMC runs)
 """
 import os, sys
 import numpy as np
@@ -19,10 +19,13 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
     ctx = D.context_on_stream(stream, 0)
+    only = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None
     for levels in (4, 3, 2, 1):
         rl, cl = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
         rp, cp = D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev)
-        for max_it in (15, 1):
+        for max_it in (15, 1) if only is None else (only[1],):
+            if only is not None and levels != only[0]:
+                continue
             opt = F.OpticalFlowOptions()
             opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber, opt.kMaxIteration = "inverse", half, half, n, max_it
             klt = D.DeviceKlt("basic", opt, rp, cp, ctx)
@@ -31,7 +34,7 @@ with torch.cuda.stream(stream):
             d_out = torch.empty_like(d_ref); d_sto = torch.empty_like(d_st); d_it = torch.zeros(n, dtype=torch.int32, device=dev)
             klt.track(d_ref, d_in, d_st, d_out, d_sto, d_it); stream.synchronize()
             ts = []
-            for _ in range(60):
+            for _ in range(60 if only is None else 8):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream); klt.track(d_ref, d_in, d_st, d_out, d_sto, None); e1.record(stream); e1.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3)
