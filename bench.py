@@ -218,9 +218,12 @@ def main():
         stream.synchronize()
 
         launches = [klt.bind(d_ref, d_cur_in, d_st_in, views2[slot][0], views2[slot][1], None) for slot in range(2)]
-        # kernel-only duration: HIP events on the launch stream around the tracker launches of the timed region
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        # kernel-only duration: HIP events on the launch stream around tracker launches INSIDE the timed region.
+        # Every launch of a short run is bracketed; from 32 steps on every 4th one is (an event pair costs about as
+        # much queue time as a tenth of this kernel, and the sampled launches are the same kernel on the same data).
+        ev_stride = 1 if args.steps < 32 else 4
+        ev0 = {k: torch.cuda.Event(enable_timing=True) for k in range(0, args.steps, ev_stride)}
+        ev1 = {k: torch.cuda.Event(enable_timing=True) for k in range(0, args.steps, ev_stride)}
 
         if use_dist:
             dist.barrier()
@@ -231,9 +234,12 @@ def main():
         # this Python loop — 95-100 us vs 81 us per step at world size 1 — so the plain order stays.)
         for k in range(args.steps):
             slot = k & 1
-            ev0[k].record(stream)
-            launches[slot]()
-            ev1[k].record(stream)
+            if k in ev0:
+                ev0[k].record(stream)
+                launches[slot]()
+                ev1[k].record(stream)
+            else:
+                launches[slot]()
             if use_dist:
                 FD.all_gather_results(packed2[slot], world, force_collective=True, out=gathered2[slot])
         torch.cuda.synchronize()
@@ -251,7 +257,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    kernel_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in ev0]))
     if rank == 0:
         total_features = n * world * args.steps
         value = total_features / elapsed
@@ -266,7 +272,9 @@ def main():
                        if use_dist else "single GPU",
                        "tracked_fraction": float((status == 1).mean()), "mean_iterations_per_feature": float(iters.mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(), "kernel": "klt_track_kernel", "kernel_ms": kernel_ms,
+                         "traffic": pmc_traffic_bytes(),
+                         "kernel": "klt_basic_inverse_pipelined_kernel" if (cfg["model"], cfg["method"]) == ("basic", "inverse") else "klt_track_kernel",
+                         "kernel_ms": kernel_ms, "kernel_launches_timed": len(ev0),
                          "algorithmic_bytes_per_launch": algo},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -74,6 +74,7 @@ struct MatchParams {
     float max_distance;
     float max_col, max_row;
     int32_t cur_per_block;  // candidates scanned by one workgroup
+    int32_t keys_clean;     // keys already hold "no match" (context-owned workspace: the epilogue leaves it that way)
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 

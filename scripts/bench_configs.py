@@ -114,7 +114,7 @@ def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, c
         d_ws = torch.zeros(n_ref, dtype=torch.int64, device=dev)
         d_pred = torch.from_numpy(pred_uv).to(dev) if nearby else None
         d_cuv = torch.from_numpy(cur_uv).to(dev) if nearby else None
-        args = dict(pred_uv=d_pred, cur_uv=d_cuv, max_col=50, max_row=50, workspace=d_ws)
+        args = dict(pred_uv=d_pred, cur_uv=d_cuv, max_col=50, max_row=50)  # context-owned key workspace
         D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx, **args)
         stream.synchronize()
         times = []
@@ -227,7 +227,7 @@ def producer_cases(torch, F, D, synth, oracle, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default="", help="'cosine': just the float-descriptor matcher cases")
+    ap.add_argument("--only", default="", help="'cosine': just the float-descriptor matcher cases; 'match': just the Hamming matcher at 10 000 x 10 000")
     args = ap.parse_args()
     import torch
 
@@ -240,6 +240,10 @@ def main():
     reps = 10 if args.quick else 40
     if args.only == "cosine":
         float_matcher_cases(torch, F, D, synth, oracle, reps, args.quick)
+        return
+    if args.only == "match":
+        for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True)):
+            print(json.dumps(matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000)), flush=True)
         return
     cases = []
     for key in ("config1", "config2", "config3", "config4", "config5_shard"):
