@@ -8,13 +8,13 @@ native library; the first compute call does, and fails loudly if it has not been
 """
 from . import synth  # noqa: F401
 from .tracker import (  # noqa: F401
-    BriefDescriptor, BriefMatcher, CosineMatcher, DiskMatcher, SuperpointMatcher, Context, FeaturePointHarrisDetector, DescriptorMatcherOptions, ImagePyramid, OpticalFlow, OpticalFlowAffineKlt, OpticalFlowBasicKlt,
+    BriefDescriptor, BriefMatcher, CosineMatcher, DirectMethod, DirectMethodOptions, DiskMatcher, SuperpointMatcher, Context, FeaturePointHarrisDetector, DescriptorMatcherOptions, ImagePyramid, OpticalFlow, OpticalFlowAffineKlt, OpticalFlowBasicKlt,
     OpticalFlowLssdKlt, OpticalFlowOptions, default_context, pack_brief, unpack_brief,
     NOT_TRACKED, TRACKED, LARGE_RESIDUAL, OUTSIDE, NUMERIC_ERROR,
 )
 
 __all__ = [
-    "BriefDescriptor", "BriefMatcher", "CosineMatcher", "DiskMatcher", "SuperpointMatcher", "Context", "FeaturePointHarrisDetector", "DescriptorMatcherOptions", "ImagePyramid", "OpticalFlow", "OpticalFlowAffineKlt", "OpticalFlowBasicKlt",
+    "BriefDescriptor", "BriefMatcher", "CosineMatcher", "DirectMethod", "DirectMethodOptions", "DiskMatcher", "SuperpointMatcher", "Context", "FeaturePointHarrisDetector", "DescriptorMatcherOptions", "ImagePyramid", "OpticalFlow", "OpticalFlowAffineKlt", "OpticalFlowBasicKlt",
     "OpticalFlowLssdKlt", "OpticalFlowOptions", "default_context", "pack_brief", "unpack_brief", "synth",
     "NOT_TRACKED", "TRACKED", "LARGE_RESIDUAL", "OUTSIDE", "NUMERIC_ERROR",
 ]

@@ -27,7 +27,7 @@ EXPORTS = [
     "ftk_abi_version", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
     "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
-    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_fill_matched_pixels",
+    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
     "ftk_brief_compute", "ftk_brief_compute_device", "ftk_harris_detect", "ftk_harris_response",
 ]
 
@@ -47,6 +47,23 @@ class KltOptions(C.Structure):
     _fields_ = [
         ("max_track_points", C.c_uint32), ("max_iteration", C.c_uint32), ("max_tolerance_large_step", C.c_uint32),
         ("half_rows", C.c_int32), ("half_cols", C.c_int32), ("max_converge_step", C.c_float), ("method", C.c_int32),
+    ]
+
+
+class DirectOptions(C.Structure):
+    """DirectMethodOptions (direct_method_tracker.h:20-28)."""
+    _fields_ = [
+        ("max_track_points", C.c_uint32), ("max_iteration", C.c_uint32), ("half_rows", C.c_int32), ("half_cols", C.c_int32),
+        ("max_converge_step", C.c_float), ("max_converge_residual", C.c_float), ("method", C.c_int32),
+    ]
+
+
+class DirectProblem(C.Structure):
+    """ftk_direct_problem: one pose problem of a batched launch (device pointers)."""
+    _fields_ = [
+        ("ref", C.c_void_p), ("cur", C.c_void_p), ("K", C.c_float * 4), ("d_p_c_in_ref", C.c_void_p), ("d_ref_uv", C.c_void_p),
+        ("d_cur_uv", C.c_void_p), ("n", C.c_int32), ("d_pose", C.c_void_p), ("d_status", C.c_void_p), ("status_valid", C.c_int32),
+        ("d_iterations", C.c_void_p),
     ]
 
 
@@ -114,6 +131,10 @@ def lib() -> C.CDLL:
     l.ftk_hamming_match_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, vp]
     l.ftk_cosine_match.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
     l.ftk_cosine_match_device.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp]
+    l.ftk_default_direct_options.argtypes = [C.POINTER(DirectOptions)]
+    l.ftk_default_direct_options.restype = None
+    l.ftk_direct_track.argtypes = [vp, C.POINTER(DirectOptions), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, C.c_int, u32p]
+    l.ftk_direct_track_batch_device.argtypes = [vp, C.POINTER(DirectOptions), C.POINTER(DirectProblem), i32]
     l.ftk_fill_matched_pixels.argtypes = [vp, i32, vp, i32, vp, vp]
     l.ftk_brief_compute.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp]
     l.ftk_brief_compute_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp]

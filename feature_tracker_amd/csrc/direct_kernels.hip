@@ -1,0 +1,328 @@
+// direct_kernels.hip — DirectMethod (photometric 6-DoF pose alignment) on gfx950: SURVEY.md
+// section 8(f) rank 4.  Replaces DirectMethod::TrackFeatures (camera-frame overload,
+// src/direct_method_tracker/direct_method_tracker.cpp:35-86) with TrackAllFeaturesDirect (:115-192).
+//
+// The problem is ONE pose for all features: every Gauss-Newton iteration sums 21 + 6 normal-equation
+// entries over features x patch pixels (50 700 terms for the reference's 300 features at 13 x 13),
+// solves a 6 x 6 system and moves the pose.  Results must be those of the scalar loop, whose sums
+// run feature by feature, pixel by pixel with one rounding per addition — and the convergence test
+// (|dx|^2 < 1e-6) turns any reordering into a different iteration count.  So the kernel keeps the
+// order and parallelises what the order leaves free:
+//
+//   * one workgroup of 8 wavefronts per pose problem (problems are independent: blockIdx.x);
+//   * waves 1..7 are PRODUCERS: chunk c = 64 consecutive terms of the (feature, pixel) stream; a
+//     lane projects its feature with the current pose, takes the six bounds-checked bilinear taps
+//     (five in the current image, one in the reference image) straight from global memory, forms
+//     the 1 x 6 Jacobian row and writes the 27 products of its pixel into a ring slot in LDS;
+//   * wave 0 is the CONSUMER: lane k < 27 adds row k of every chunk in stream order (the exact-order
+//     chain of the KLT kernels, klt_basic_kernels.hip);
+//   * one barrier per round of 7 chunks; after the last round every thread solves the same 6 x 6
+//     system (Eigen-compatible LDLT, klt_common.h) and applies the same pose update, so the pose
+//     lives in registers and needs no further exchange.
+//
+// Projection of the features (cur_pixel_uv, :141-142) happens once per iteration in a prologue pass
+// and is kept in LDS for the producers; the Jacobian of the pixel w.r.t. the pose (:145-148) depends
+// on the reference-frame point only and is recomputed per lane (12 products).
+// fp32 throughout, no contraction; quaternion arithmetic as defined in oracle/oracle_direct_method.c.
+#define FTK_CHAIN_ROUND 4
+#include "klt_common.h"
+
+namespace ftk {
+namespace {
+
+constexpr int kDmWaves = 8;
+constexpr int kDmProducers = kDmWaves - 1;
+constexpr int kDmChunk = 64;
+constexpr int kDmRow = kDmChunk + 4;  // row pitch in floats: keeps the consumer's b128 reads on distinct banks
+constexpr int kDmTerms = 27;          // 21 upper-triangle H entries (row-major) + 6 b entries
+constexpr float kZeroFloat = 1e-6f;
+
+struct Quat {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ Quat q_mul(const Quat &a, const Quat &b) {
+    Quat r;
+    r.x = (a.x * b.w - a.z * b.y) + (a.y * b.z + a.w * b.x);
+    r.y = (a.y * b.w - a.x * b.z) + (a.z * b.x + a.w * b.y);
+    r.z = (a.z * b.w - a.y * b.x) + (a.x * b.y + a.w * b.z);
+    r.w = (a.w * b.w - a.x * b.x) - (a.z * b.z + a.y * b.y);
+    return r;
+}
+__device__ __forceinline__ float q_squared_norm(const Quat &q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
+__device__ __forceinline__ Quat q_inverse(const Quat &q) {
+    const float n2 = q_squared_norm(q);
+    Quat r = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n2 > 0.0f) {
+        r.x = -q.x / n2;
+        r.y = -q.y / n2;
+        r.z = -q.z / n2;
+        r.w = q.w / n2;
+    }
+    return r;
+}
+__device__ __forceinline__ Quat q_normalized(Quat q) {
+    const float z = q_squared_norm(q);
+    if (z > 0.0f) {
+        const float n = sqrtf(z);
+        q.x /= n;
+        q.y /= n;
+        q.z /= n;
+        q.w /= n;
+    }
+    return q;
+}
+__device__ __forceinline__ void q_rotate(const Quat &q, float vx, float vy, float vz, float &ox, float &oy, float &oz) {
+    float ux = q.y * vz - q.z * vy, uy = q.z * vx - q.x * vz, uz = q.x * vy - q.y * vx;
+    ux += ux;
+    uy += uy;
+    uz += uz;
+    const float cx = q.y * uz - q.z * uy, cy = q.z * ux - q.x * uz, cz = q.x * uy - q.y * ux;
+    ox = (vx + q.w * ux) + cx;
+    oy = (vy + q.w * uy) + cy;
+    oz = (vz + q.w * uz) + cz;
+}
+
+// GrayImage::GetPixelValue straight from global memory (no LDS window: every tap of a problem is
+// touched once per iteration, and the images stay in L2).
+__device__ __forceinline__ bool tap_global(const DevImage &im, float row, float col, float &value) {
+    Win none;
+    none.data = nullptr;
+    none.r_lo = none.c_lo = 0;
+    none.rows = none.cols = 0;
+    return sample(im, none, row, col, value);
+}
+
+__device__ __forceinline__ float dm_chain_chunk(float acc, const float *row) {
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    float4 qa[kChainRound], qb[kChainRound];
+    chain_load(qa, t);
+#pragma unroll
+    for (int i = 0; i < kDmChunk / 4; i += 2 * kChainRound) {
+        chain_load(qb, t + i + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        if (i + 2 * kChainRound < kDmChunk / 4) {
+            chain_load(qa, t + i + 2 * kChainRound);
+        }
+        acc = chain_consume_all(acc, qb);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const DirectParams pp) {
+    extern __shared__ float4 dm_lds[];
+    const DirectProblem pr = pp.problems[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const bool consumer = wave == 0;
+    float *const ring = reinterpret_cast<float *>(dm_lds);                   // [2][kDmProducers][kDmTerms][kDmRow]
+    float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;         // [32]
+    float *const feat = sums + 32;                                           // [n_track][4]: cur u, cur v, usable, -
+    const int n = pr.n;
+    const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
+    const int P = pp.patch_rows * pp.patch_cols;
+    const long long total_terms = (long long)n_track * P;
+    const int n_chunks = (int)((total_terms + kDmChunk - 1) / kDmChunk);
+    const int n_rounds = (n_chunks + kDmProducers - 1) / kDmProducers;
+
+    // pose in registers, identical in every thread
+    Quat q = {pr.pose[1], pr.pose[2], pr.pose[3], pr.pose[0]};
+    float px = pr.pose[4], py = pr.pose[5], pz = pr.pose[6];
+    uint32_t iterations = 0;
+
+    const float scale = (float)(1 << (pp.n_levels - 1));
+    if (pp.method == FTK_METHOD_DIRECT && n_track > 0) {
+        for (int level = pp.n_levels - 1; level > -1; --level) {
+            const DevImage ref = pr.ref[level];
+            const DevImage cur = pr.cur[level];
+            // scaled_K / scaled_ref_points_: value / scale, then doubled once per finer level (exact), :47-52,64-69
+            const float up = (float)(1 << (pp.n_levels - 1 - level));
+            const float fx = (pr.K[0] / scale) * up, fy = (pr.K[1] / scale) * up, cx = (pr.K[2] / scale) * up, cy = (pr.K[3] / scale) * up;
+            bool stop = false;
+            for (uint32_t iter = 0; iter < pp.max_iteration && !stop; ++iter) {
+                ++iterations;
+                // ---- projection of every feature with the current pose (:128-142) ----
+                const Quat q_inv = q_inverse(q);
+                for (int i = tid; i < n_track; i += kDmWaves * kWave) {
+                    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+                    float cu = 0.0f, cv = 0.0f;
+                    bool usable = !(prz < kZeroFloat);
+                    if (usable) {
+                        float cxp, cyp, czp;
+                        q_rotate(q_inv, prx - px, pry - py, prz - pz, cxp, cyp, czp);
+                        usable = !(czp < kZeroFloat);
+                        if (usable) {
+                            const float nx = cxp / czp, ny = cyp / czp;
+                            cu = fx * nx + cx;
+                            cv = fy * ny + cy;
+                            pr.cur_uv[2 * i] = cu;
+                            pr.cur_uv[2 * i + 1] = cv;
+                        }
+                    }
+                    reinterpret_cast<float4 *>(feat)[i] = make_float4(cu, cv, usable ? 1.0f : 0.0f, 0.0f);
+                }
+                __syncthreads();
+
+                // ---- the (feature, pixel) stream in rounds of kDmProducers chunks ----
+                float acc = 0.0f;
+                for (int round = 0; round < n_rounds; ++round) {
+                    if (!consumer) {
+                        const int chunk = round * kDmProducers + (wave - 1);
+                        float *slot = ring + (((round & 1) * kDmProducers + (wave - 1)) * kDmTerms) * kDmRow;
+                        const long long g = (long long)chunk * kDmChunk + lane;
+                        float jac[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        float residual = 0.0f;
+                        if (chunk < n_chunks && g < total_terms) {
+                            const int i = (int)(g / P);
+                            const int pix = (int)(g - (long long)i * P);
+                            const int prow = pix / pp.patch_cols, pcol = pix - prow * pp.patch_cols;
+                            const float4 f = reinterpret_cast<const float4 *>(feat)[i];
+                            if (f.z != 0.0f) {
+                                const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
+                                const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
+                                const float row_i = drow + scaled_rv, col_i = dcol + scaled_ru;
+                                const float row_j = drow + f.y, col_j = dcol + f.x;
+                                float t0, t1, t2, t3, t4, t5;
+                                // all six must be valid (:160-162); evaluation order does not matter for the result
+                                bool ok = tap_global(cur, row_j, col_j - 1.0f, t0);
+                                ok = tap_global(cur, row_j, col_j + 1.0f, t1) && ok;
+                                ok = tap_global(cur, row_j - 1.0f, col_j, t2) && ok;
+                                ok = tap_global(cur, row_j + 1.0f, col_j, t3) && ok;
+                                ok = tap_global(ref, row_i, col_i, t4) && ok;
+                                ok = tap_global(cur, row_j, col_j, t5) && ok;
+                                if (ok) {
+                                    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+                                    const float zi = 1.0f / prz;
+                                    const float z2i = zi * zi;
+                                    // jacobian_pixel_xi, :145-148 — operator precedence as written
+                                    const float j00 = fx * zi, j01 = 0.0f, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i,
+                                                j05 = -fx * pry * zi;
+                                    const float j10 = 0.0f, j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i,
+                                                j15 = fy * prx * zi;
+                                    const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
+                                    residual = t5 - t4;
+                                    jac[0] = gx * j00 + gy * j10;
+                                    jac[1] = gx * j01 + gy * j11;
+                                    jac[2] = gx * j02 + gy * j12;
+                                    jac[3] = gx * j03 + gy * j13;
+                                    jac[4] = gx * j04 + gy * j14;
+                                    jac[5] = gx * j05 + gy * j15;
+                                }
+                            }
+                        }
+                        // an unused pixel contributes exact zeros (x + (+-0) == x, and the sums start at +0)
+                        int k = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                            for (int c = r; c < 6; ++c) {
+                                slot[k * kDmRow + lane] = jac[r] * jac[c];
+                                ++k;
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            slot[(21 + r) * kDmRow + lane] = residual * jac[r];
+                        }
+                    }
+                    __syncthreads();
+                    if (consumer && lane < kDmTerms) {
+                        for (int w = 0; w < kDmProducers; ++w) {
+                            if (round * kDmProducers + w < n_chunks) {
+                                acc = dm_chain_chunk(acc, ring + ((((round & 1) * kDmProducers + w) * kDmTerms) + lane) * kDmRow);
+                            }
+                        }
+                    }
+                }
+                if (consumer && lane < kDmTerms) {
+                    sums[lane] = acc;
+                }
+                __syncthreads();
+
+                // ---- solve and update, redundantly in every thread (:170-181) ----
+                float H[6][6], b[6], dx[6];
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                        for (int c = r; c < 6; ++c) {
+                            H[r][c] = sums[k];
+                            H[c][r] = sums[k];
+                            ++k;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        b[r] = sums[21 + r];
+                    }
+                }
+                ldlt_solve<6>(H, b, dx);
+                bool has_nan = false;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    has_nan = has_nan || isnan(dx[k]);
+                }
+                if (has_nan) {
+                    stop = true;  // :173
+                } else {
+                    px += dx[0];
+                    py += dx[1];
+                    pz += dx[2];
+                    Quat dq = {dx[3] * 0.5f, dx[4] * 0.5f, dx[5] * 0.5f, 1.0f};
+                    q = q_normalized(q_mul(q_normalized(dq), q));
+                    const float sq = (((dx[0] * dx[0] + dx[2] * dx[2]) + (dx[1] * dx[1] + dx[3] * dx[3])) + dx[4] * dx[4]) + dx[5] * dx[5];
+                    if (sq < pp.converge) {
+                        stop = true;  // :181
+                    }
+                }
+                __syncthreads();  // everyone has read `sums` and `feat` before the next iteration rewrites them
+            }
+        }
+    }
+    // ---- status and pose write-back (:72-83) ----
+    const DevImage bottom = pr.ref[0];
+    for (int i = tid; i < n; i += kDmWaves * kWave) {
+        uint8_t s = pr.status_valid ? pr.status[i] : (uint8_t)FTK_TRACKED;
+        const float u = pr.cur_uv[2 * i], v = pr.cur_uv[2 * i + 1];
+        if (u < 0.0f || u > (float)(bottom.cols - 1) || v < 0.0f || v > (float)(bottom.rows - 1)) {
+            s = FTK_OUTSIDE;
+        }
+        pr.status[i] = s;
+    }
+    if (tid == 0) {
+        pr.pose[0] = q.w;
+        pr.pose[1] = q.x;
+        pr.pose[2] = q.y;
+        pr.pose[3] = q.z;
+        pr.pose[4] = px;
+        pr.pose[5] = py;
+        pr.pose[6] = pz;
+        if (pr.iterations) {
+            *pr.iterations = iterations;
+        }
+    }
+}
+
+}  // namespace
+
+size_t direct_lds_bytes(uint32_t max_features) {
+    return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 32 + 4 * (size_t)max_features);
+}
+
+hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream) {
+    if (n_problems <= 0) {
+        return hipSuccess;
+    }
+    const size_t lds = direct_lds_bytes(max_features);
+    auto kernel = direct_track_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_problems), dim3(kDmWaves * kWave), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ftk

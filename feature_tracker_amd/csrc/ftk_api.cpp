@@ -30,6 +30,9 @@ struct ftk_context {
     // workspace of the float-descriptor matcher (fp16 copies, norms, candidate lists)
     void *cosine_ws = nullptr;
     size_t cosine_ws_bytes = 0;
+    // problem table of the direct-method launches
+    void *direct_table = nullptr;
+    size_t direct_table_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -367,6 +370,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->cosine_ws) {
         (void)hipFree(ctx->cosine_ws);
+    }
+    if (ctx->direct_table) {
+        (void)hipFree(ctx->direct_table);
     }
     if (ctx->pinned) {
         (void)hipHostFree(ctx->pinned);
@@ -1067,6 +1073,185 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     }
     FTK_HIP(ctx, hipMemcpyAsync(index_pairs, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+/* ---- direct method ------------------------------------------------------------------------ */
+
+void ftk_default_direct_options(ftk_direct_options *opt) {
+    if (!opt) {
+        return;
+    }
+    opt->max_track_points = 500;
+    opt->max_iteration = 15;
+    opt->half_rows = 6;
+    opt->half_cols = 6;
+    opt->max_converge_step = 1e-6f;
+    opt->max_converge_residual = 2.0f;
+    opt->method = FTK_METHOD_DIRECT;
+}
+
+int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *opt, const ftk_direct_problem *problems, int32_t n_problems) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "direct_track: null context");
+    }
+    if (!opt || n_problems < 0 || (n_problems > 0 && !problems)) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: null options / problems");
+    }
+    if (n_problems == 0) {
+        return FTK_OK;
+    }
+    if (opt->half_rows < 0 || opt->half_cols < 0 || opt->half_rows > 63 || opt->half_cols > 63) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: half patch size (%d, %d) outside [0, 63]", opt->half_rows, opt->half_cols);
+    }
+    std::vector<ftk::DirectProblem> host((size_t)n_problems);
+    uint32_t max_features = 0;
+    int32_t n_levels = 0;
+    for (int32_t k = 0; k < n_problems; ++k) {
+        const ftk_direct_problem &in = problems[k];
+        if (!in.ref || !in.cur || in.n < 0 || (in.n > 0 && (!in.d_p_c_in_ref || !in.d_ref_uv || !in.d_cur_uv || !in.d_status)) || !in.d_pose) {
+            return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: problem %d has a null buffer", k);
+        }
+        if (in.ref->n_levels != in.cur->n_levels || in.ref->n_levels < 1) {
+            return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: problem %d pyramid level mismatch (%d vs %d)", k, in.ref->n_levels, in.cur->n_levels);
+        }
+        if (k == 0) {
+            n_levels = in.ref->n_levels;
+        } else if (in.ref->n_levels != n_levels) {
+            return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: all problems of a batch must share the pyramid depth");
+        }
+        if (in.ref->device != ctx->device || in.cur->device != ctx->device) {
+            return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: pyramid lives on another device");
+        }
+        ftk::DirectProblem &out = host[(size_t)k];
+        memset(&out, 0, sizeof(out));
+        for (int i = 0; i < n_levels; ++i) {
+            out.ref[i] = in.ref->levels[i];
+            out.cur[i] = in.cur->levels[i];
+            if (out.ref[i].rows < 2 || out.ref[i].cols < 2 || out.cur[i].rows < 2 || out.cur[i].cols < 2) {
+                return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: pyramid level %d smaller than 2x2", i);
+            }
+        }
+        for (int i = 0; i < 4; ++i) {
+            out.K[i] = in.K[i];
+        }
+        out.p_ref = in.d_p_c_in_ref;
+        out.ref_uv = in.d_ref_uv;
+        out.cur_uv = in.d_cur_uv;
+        out.pose = in.d_pose;
+        out.status = in.d_status;
+        out.iterations = in.d_iterations;
+        out.n = in.n;
+        out.status_valid = in.status_valid ? 1 : 0;
+        const uint32_t tracked = ((uint32_t)in.n < opt->max_track_points) ? (uint32_t)in.n : opt->max_track_points;
+        max_features = std::max(max_features, tracked);
+    }
+    if (max_features > 3072) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: %u tracked features in one problem (limit 3072); lower kMaxTrackPointsNumber", max_features);
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    // the problem table travels through a context-owned device buffer (separate from the scratch the host-buffer wrapper uses)
+    const size_t table_bytes = sizeof(ftk::DirectProblem) * (size_t)n_problems;
+    if (table_bytes > ctx->direct_table_bytes) {
+        if (ctx->direct_table) {
+            FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            FTK_HIP(ctx, hipFree(ctx->direct_table));
+            ctx->direct_table = nullptr;
+            ctx->direct_table_bytes = 0;
+        }
+        FTK_HIP(ctx, hipMalloc(&ctx->direct_table, align_up(table_bytes, 4096)));
+        ctx->direct_table_bytes = align_up(table_bytes, 4096);
+    }
+    // pageable host -> device copy: synchronous with respect to the host buffer, so `host` may go out of scope
+    FTK_HIP(ctx, hipMemcpyAsync(ctx->direct_table, host.data(), table_bytes, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ftk::DirectParams p;
+    p.problems = static_cast<const ftk::DirectProblem *>(ctx->direct_table);
+    p.n_levels = n_levels;
+    p.max_track_points = opt->max_track_points;
+    p.max_iteration = opt->max_iteration;
+    p.half_rows = opt->half_rows;
+    p.half_cols = opt->half_cols;
+    p.patch_rows = 2 * opt->half_rows + 1;
+    p.patch_cols = 2 * opt->half_cols + 1;
+    p.converge = opt->max_converge_step;
+    p.method = opt->method;
+    FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, max_features, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *K,
+                     const float *p_c_in_ref, const float *ref_uv, float *cur_uv, int32_t n, float *q_rc_wxyz, float *p_rc, uint8_t *status,
+                     int status_valid, uint32_t *iterations) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "direct_track: null context");
+    }
+    if (n < 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: negative feature count");
+    }
+    if (n == 0) {
+        return FTK_OK;  // the class returns false for an empty ref_pixel_uv (:38); nothing to compute here
+    }
+    if (!opt || !ref || !cur || !K || !p_c_in_ref || !ref_uv || !cur_uv || !q_rc_wxyz || !p_rc || !status) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: null argument");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pts_bytes = align_up(sizeof(float) * 3 * (size_t)n, 256);
+    const size_t uv_bytes = align_up(sizeof(float) * 2 * (size_t)n, 256);
+    const size_t st_bytes = align_up((size_t)n, 256);
+    const size_t total = pts_bytes + 2 * uv_bytes + st_bytes + 256 + 256;
+    int rc = ensure_scratch(ctx, total);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_pts = reinterpret_cast<float *>(base);
+    float *d_ref = reinterpret_cast<float *>(base + pts_bytes);
+    float *d_cur = reinterpret_cast<float *>(base + pts_bytes + uv_bytes);
+    uint8_t *d_st = base + pts_bytes + 2 * uv_bytes;
+    float *d_pose = reinterpret_cast<float *>(base + pts_bytes + 2 * uv_bytes + st_bytes);
+    uint32_t *d_it = reinterpret_cast<uint32_t *>(base + pts_bytes + 2 * uv_bytes + st_bytes + 256);
+    float pose[7] = {q_rc_wxyz[0], q_rc_wxyz[1], q_rc_wxyz[2], q_rc_wxyz[3], p_rc[0], p_rc[1], p_rc[2]};
+    FTK_HIP(ctx, hipMemcpyAsync(d_pts, p_c_in_ref, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_st, status, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_pose, pose, sizeof(pose), hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `pose` is a stack buffer
+    ftk_direct_problem prob;
+    prob.ref = ref;
+    prob.cur = cur;
+    for (int i = 0; i < 4; ++i) {
+        prob.K[i] = K[i];
+    }
+    prob.d_p_c_in_ref = d_pts;
+    prob.d_ref_uv = d_ref;
+    prob.d_cur_uv = d_cur;
+    prob.n = n;
+    prob.d_pose = d_pose;
+    prob.d_status = d_st;
+    prob.status_valid = status_valid;
+    prob.d_iterations = d_it;
+    rc = ftk_direct_track_batch_device(ctx, opt, &prob, 1);
+    if (rc != FTK_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    uint32_t it = 0;
+    FTK_HIP(ctx, hipMemcpyAsync(cur_uv, d_cur, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(pose, d_pose, sizeof(pose), hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(&it, d_it, sizeof(it), hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) {
+        q_rc_wxyz[i] = pose[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        p_rc[i] = pose[4 + i];
+    }
+    if (iterations) {
+        *iterations = it;
+    }
     return FTK_OK;
 }
 

@@ -100,6 +100,32 @@ struct CosineParams {
 };
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
 
+// DirectMethod (direct_kernels.hip): one workgroup per pose problem; all problems of a launch share
+// the pyramid depth and the options.
+struct DirectProblem {
+    DevImage ref[FTK_MAX_LEVELS];
+    DevImage cur[FTK_MAX_LEVELS];
+    float K[4];             // fx, fy, cx, cy at full resolution
+    const float *p_ref;     // n x 3: points in the reference camera frame
+    const float *ref_uv;    // n x 2
+    float *cur_uv;          // n x 2, in/out
+    float *pose;            // 7: q_rc (w, x, y, z), p_rc — in/out
+    uint8_t *status;        // n, in/out
+    uint32_t *iterations;   // optional: Gauss-Newton iterations over all levels
+    int32_t n;
+    int32_t status_valid;   // 0: reset every status to kTracked first (direct_method_tracker.cpp:73-75)
+};
+struct DirectParams {
+    const DirectProblem *problems;  // device memory, one per workgroup
+    int32_t n_levels;
+    uint32_t max_track_points, max_iteration;
+    int32_t half_rows, half_cols, patch_rows, patch_cols;
+    float converge;
+    int32_t method;
+};
+size_t direct_lds_bytes(uint32_t max_features);
+hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream);
+
 struct BriefParams {
     DevImage img;
     const float *uv;

@@ -487,3 +487,128 @@ class CosineMatcher(BriefMatcher):
 
 SuperpointMatcher = CosineMatcher  # test/test_descriptor_matcher_superpoint.cpp:26
 DiskMatcher = CosineMatcher        # test/test_descriptor_matcher_disk.cpp:26
+
+
+class DirectMethodOptions:
+    """direct_method_tracker.h:20-28 — same field names and defaults."""
+
+    def __init__(self):
+        self.kMaxTrackPointsNumber = 500
+        self.kMaxIteration = 15
+        self.kPatchRowHalfSize = 6
+        self.kPatchColHalfSize = 6
+        self.kMaxConvergeStep = 1e-6
+        self.kMaxConvergeResidual = 2.0
+        self.kMethod = "direct"  # DirectMethodMethod::kDirect (kInverse / kFast are empty stubs in the reference)
+
+    def to_native(self) -> N.DirectOptions:
+        o = N.DirectOptions()
+        o.max_track_points = int(self.kMaxTrackPointsNumber)
+        o.max_iteration = int(self.kMaxIteration)
+        o.half_rows = int(self.kPatchRowHalfSize)
+        o.half_cols = int(self.kPatchColHalfSize)
+        o.max_converge_step = float(self.kMaxConvergeStep)
+        o.max_converge_residual = float(self.kMaxConvergeResidual)
+        o.method = N.METHODS[self.kMethod] if isinstance(self.kMethod, str) else int(self.kMethod)
+        return o
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def _quat_mul(a, b):
+    """Eigen::Quaternionf product for the reference's SSE2 build, (w, x, y, z) fp32 (oracle/oracle_direct_method.c)."""
+    aw, ax, ay, az = (_f32(v) for v in a)
+    bw, bx, by, bz = (_f32(v) for v in b)
+    x = _f32(_f32(_f32(ax * bw) - _f32(az * by)) + _f32(_f32(ay * bz) + _f32(aw * bx)))
+    y = _f32(_f32(_f32(ay * bw) - _f32(ax * bz)) + _f32(_f32(az * bx) + _f32(aw * by)))
+    z = _f32(_f32(_f32(az * bw) - _f32(ay * bx)) + _f32(_f32(ax * by) + _f32(aw * bz)))
+    w = _f32(_f32(_f32(aw * bw) - _f32(ax * bx)) - _f32(_f32(az * bz) + _f32(ay * by)))
+    return np.array([w, x, y, z], dtype=np.float32)
+
+
+def _quat_inverse(q):
+    w, x, y, z = (_f32(v) for v in q)
+    n2 = _f32(_f32(_f32(x * x) + _f32(z * z)) + _f32(_f32(y * y) + _f32(w * w)))
+    if not n2 > 0:
+        return np.zeros(4, dtype=np.float32)
+    return np.array([_f32(w / n2), _f32(-x / n2), _f32(-y / n2), _f32(-z / n2)], dtype=np.float32)
+
+
+def _quat_rotate(q, v):
+    w, x, y, z = (_f32(c) for c in q)
+    v = np.asarray(v, dtype=np.float32)
+    qv = (x, y, z)
+
+    def cross(a, b):
+        return [_f32(_f32(a[1] * b[2]) - _f32(a[2] * b[1])), _f32(_f32(a[2] * b[0]) - _f32(a[0] * b[2])), _f32(_f32(a[0] * b[1]) - _f32(a[1] * b[0]))]
+
+    uv = cross(qv, v)
+    uv = [_f32(c + c) for c in uv]
+    c2 = cross(qv, uv)
+    return np.array([_f32(_f32(v[k] + _f32(w * uv[k])) + c2[k]) for k in range(3)], dtype=np.float32)
+
+
+class DirectMethod:
+    """feature_tracker::DirectMethod (direct_method_tracker.h:30-78): photometric 6-DoF pose alignment of one
+    frame against a reference frame over all features jointly.  The camera-frame overload runs on the device
+    (ftk_direct_track); the world-frame overload (direct_method_tracker.cpp:8-33) is the same quaternion algebra
+    around it, evaluated in fp32 on the host.  Quaternions are (w, x, y, z)."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self._ctx = ctx
+        self._options = DirectMethodOptions()
+        self.last_iterations = 0
+
+    def options(self) -> DirectMethodOptions:
+        return self._options
+
+    def TrackFeatures(self, ref_pyramid: ImagePyramid, cur_pyramid: ImagePyramid, K, p_c_in_ref, ref_pixel_uv, cur_pixel_uv=None,
+                      q_rc=(1.0, 0.0, 0.0, 0.0), p_rc=(0.0, 0.0, 0.0), status=None):
+        """Camera-frame overload (direct_method_tracker.cpp:35-86).  Returns (ok, cur_pixel_uv, q_rc, p_rc, status)."""
+        ref_uv = np.ascontiguousarray(ref_pixel_uv, dtype=np.float32).reshape(-1, 2)
+        n = ref_uv.shape[0]
+        q = np.array(q_rc, dtype=np.float32).reshape(4).copy()
+        p = np.array(p_rc, dtype=np.float32).reshape(3).copy()
+        cur_uv = None if cur_pixel_uv is None else np.asarray(cur_pixel_uv, dtype=np.float32).reshape(-1, 2)
+        st = None if status is None else np.asarray(status, dtype=np.uint8).reshape(-1)
+        # RETURN_FALSE_IF(ref_pixel_uv.empty()) / level mismatch (:38-39)
+        if n == 0 or cur_pyramid.level() != ref_pyramid.level():
+            return False, (np.zeros((0, 2), np.float32) if cur_uv is None else cur_uv), q, p, (np.zeros(0, np.uint8) if st is None else st)
+        pts = np.ascontiguousarray(p_c_in_ref, dtype=np.float32).reshape(-1, 3)
+        if pts.shape[0] < min(n, int(self._options.kMaxTrackPointsNumber)):
+            raise ValueError("p_c_in_ref has fewer points than features to track")
+        if pts.shape[0] < n:
+            pts = np.concatenate([pts, np.zeros((n - pts.shape[0], 3), np.float32)], axis=0)
+        cur_uv = ref_uv.copy() if (cur_uv is None or cur_uv.shape[0] != n) else np.ascontiguousarray(cur_uv).copy()  # :42-44
+        valid = st is not None and st.shape[0] == n
+        st = np.ascontiguousarray(st).copy() if valid else np.zeros(n, dtype=np.uint8)
+        ctx = self._ctx or default_context()
+        opt = self._options.to_native()
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        it = C.c_uint32(0)
+        rc = N.lib().ftk_direct_track(ctx.handle, C.byref(opt), ref_pyramid.handle, cur_pyramid.handle, _ptr(Kf), _ptr(pts), _ptr(ref_uv), _ptr(cur_uv),
+                                      n, _ptr(q), _ptr(p), _ptr(st), int(valid), C.byref(it))
+        N.check(rc, ctx.handle)
+        self.last_iterations = int(it.value)
+        return True, cur_uv, q, p, st
+
+    def TrackFeaturesWorld(self, ref_pyramid: ImagePyramid, cur_pyramid: ImagePyramid, K, ref_q_wc, ref_p_wc, p_w, ref_pixel_uv, cur_pixel_uv=None,
+                           cur_q_wc=(1.0, 0.0, 0.0, 0.0), cur_p_wc=(0.0, 0.0, 0.0), status=None):
+        """World-frame overload (direct_method_tracker.cpp:8-33).  Returns (ok, cur_pixel_uv, cur_q_wc, cur_p_wc, status)."""
+        ref_q_wc = np.asarray(ref_q_wc, dtype=np.float32)
+        ref_p_wc = np.asarray(ref_p_wc, dtype=np.float32)
+        cur_q_wc = np.asarray(cur_q_wc, dtype=np.float32)
+        cur_p_wc = np.asarray(cur_p_wc, dtype=np.float32)
+        ref_q_cw = _quat_inverse(ref_q_wc)
+        p_w = np.asarray(p_w, dtype=np.float32).reshape(-1, 3)
+        p_c_in_ref = np.stack([_quat_rotate(ref_q_cw, (pw - ref_p_wc).astype(np.float32)) for pw in p_w], axis=0) if len(p_w) else np.zeros((0, 3), np.float32)
+        q_rc = _quat_mul(ref_q_cw, cur_q_wc)
+        p_rc = _quat_rotate(ref_q_cw, (cur_p_wc - ref_p_wc).astype(np.float32))
+        ok, cur_uv, q_rc, p_rc, st = self.TrackFeatures(ref_pyramid, cur_pyramid, K, p_c_in_ref, ref_pixel_uv, cur_pixel_uv, q_rc, p_rc, status)
+        if not ok:
+            return False, cur_uv, cur_q_wc, cur_p_wc, st
+        out_q = _quat_mul(ref_q_wc, q_rc)
+        out_p = (_quat_rotate(ref_q_wc, p_rc) + ref_p_wc).astype(np.float32)
+        return True, cur_uv, out_q, out_p, st

@@ -177,6 +177,53 @@ int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
 /* The response map alone (rows*cols floats, host memory; 0 outside the 11-pixel border). */
 int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t level, float *response);
 
+/* ---- direct method ---------------------------------------------- */
+
+/* DirectMethodOptions, src/direct_method_tracker/direct_method_tracker.h:20-28 */
+typedef struct ftk_direct_options {
+    uint32_t max_track_points;   /* kMaxTrackPointsNumber (500)  */
+    uint32_t max_iteration;      /* kMaxIteration         (15)   */
+    int32_t half_rows;           /* kPatchRowHalfSize     (6)    */
+    int32_t half_cols;           /* kPatchColHalfSize     (6)    */
+    float max_converge_step;     /* kMaxConvergeStep      (1e-6) */
+    float max_converge_residual; /* kMaxConvergeResidual  (2.0; the reference never reads it) */
+    int32_t method;              /* kMethod (FTK_METHOD_DIRECT); kInverse / kFast are empty stubs in the reference and no-ops here */
+} ftk_direct_options;
+void ftk_default_direct_options(ftk_direct_options *opt);
+
+/*
+ * Replaces DirectMethod::TrackFeatures, camera-frame overload (direct_method_tracker.cpp:35-86) with
+ * TrackSingleLevel -> TrackAllFeaturesDirect (:88-106, :115-192): photometric Gauss-Newton on ONE pose
+ * (q_rc, p_rc) over all features jointly, coarse to fine.  K = {fx, fy, cx, cy}; p_c_in_ref = n x 3 points in
+ * the reference camera frame; cur_uv in/out (the caller applies ":42-44 sizes differ -> cur = ref");
+ * q_rc = (w, x, y, z) and p_rc in/out; status in/out with status_valid = 0 meaning "was not sized n"
+ * (reset to kTracked, :73-75).  iterations (optional) = Gauss-Newton iterations over all levels.
+ * The sums of the normal equations keep the scalar loop's order (feature by feature, pixel by pixel),
+ * so pose, pixels and iteration counts are those of the scalar code.  The world-frame overload
+ * (:8-33) is host-side quaternion algebra around this call and lives in the C++ class.
+ * At most 3072 tracked features per problem (the per-feature projections live in LDS).
+ */
+int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *K,
+                     const float *p_c_in_ref, const float *ref_uv, float *cur_uv, int32_t n, float *q_rc_wxyz, float *p_rc, uint8_t *status,
+                     int status_valid, uint32_t *iterations);
+
+/* A batch of independent pose problems in ONE launch (one workgroup each), buffers device-resident.
+ * d_pose = 7 floats: q_rc (w, x, y, z) then p_rc.  All problems share the options and the pyramid depth. */
+typedef struct ftk_direct_problem {
+    const ftk_pyramid *ref;
+    const ftk_pyramid *cur;
+    float K[4];
+    const float *d_p_c_in_ref;
+    const float *d_ref_uv;
+    float *d_cur_uv;
+    int32_t n;
+    float *d_pose;
+    uint8_t *d_status;
+    int32_t status_valid;
+    uint32_t *d_iterations; /* may be NULL */
+} ftk_direct_problem;
+int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *opt, const ftk_direct_problem *problems, int32_t n_problems);
+
 /* ---- descriptor matcher ------------------------------------------------------------------ */
 
 /*

@@ -120,6 +120,26 @@ int orc_force_match_float(const float *ref, int32_t n_ref, const float *cur, int
 int orc_nearby_match_float(const float *ref, int32_t n_ref, const float *cur, int32_t n_cur, int32_t dim, float max_distance, const float *pred_uv,
                            const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs);
 
+/* src/direct_method_tracker/direct_method_tracker.h:20-28 */
+typedef struct {
+    uint32_t max_track_points;   /* kMaxTrackPointsNumber (500)  */
+    uint32_t max_iteration;      /* kMaxIteration         (15)   */
+    int32_t half_rows;           /* kPatchRowHalfSize     (6)    */
+    int32_t half_cols;           /* kPatchColHalfSize     (6)    */
+    float max_converge_step;     /* kMaxConvergeStep      (1e-6) */
+    float max_converge_residual; /* kMaxConvergeResidual  (2.0, unused by the reference) */
+    int32_t method;              /* kMethod               (kDirect) */
+} orc_direct_options;
+
+/* DirectMethod (direct_method_tracker.cpp:35-86, :115-192); normative substrate in oracle_direct_method.c.
+ * Quaternions are (w, x, y, z). */
+int orc_direct_track(const orc_direct_options *opt, const orc_image *ref_levels, const orc_image *cur_levels, int32_t n_levels, const float *K,
+                     const float *p_c_in_ref, const float *ref_uv, float *cur_uv, int32_t n, float *q_rc_wxyz, float *p_rc, uint8_t *status,
+                     int status_valid, uint32_t *iterations);
+void orc_quat_mul(const float *a, const float *b, float *out);
+void orc_quat_rotate(const float *q, const float *v, float *out);
+void orc_quat_inverse(const float *q, float *out);
+
 /* BRIEF descriptor producer of the matcher (normative definition in oracle_brief.c). */
 void orc_brief_pattern(int32_t n_bits, int32_t half, int8_t *pattern);
 int orc_brief_compute(const orc_image *img, const float *uv, int32_t n, int32_t n_bits, int32_t half, uint8_t *bits);

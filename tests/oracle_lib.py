@@ -24,6 +24,13 @@ class _Image(C.Structure):
     _fields_ = [("data", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class _DirectOptions(C.Structure):
+    _fields_ = [
+        ("max_track_points", C.c_uint32), ("max_iteration", C.c_uint32), ("half_rows", C.c_int32), ("half_cols", C.c_int32),
+        ("max_converge_step", C.c_float), ("max_converge_residual", C.c_float), ("method", C.c_int32),
+    ]
+
+
 class _Options(C.Structure):
     _fields_ = [
         ("max_track_points", C.c_uint32), ("max_iteration", C.c_uint32), ("max_tolerance_large_step", C.c_uint32),
@@ -250,6 +257,52 @@ def fill_matched_pixels(index_pairs, cur_uv, status=None):
     lib().orc_fill_matched_pixels(index_pairs.ctypes.data_as(C.c_void_p), n_ref, cur_uv.ctypes.data_as(C.c_void_p), cur_uv.shape[0],
                                   matched.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
     return matched, st
+
+
+def direct_track(ref_levels, cur_levels, K, p_c_in_ref, ref_uv, cur_uv=None, q_rc=(1, 0, 0, 0), p_rc=(0, 0, 0), status=None, method="direct",
+                 half=6, half_cols=None, max_points=500, max_iteration=15, converge=1e-6):
+    """DirectMethod::TrackFeatures, camera-frame overload (direct_method_tracker.cpp:35-86).
+    Returns (ok, cur_uv, q_rc (w, x, y, z), p_rc, status, iterations)."""
+    ref_uv = np.ascontiguousarray(ref_uv, dtype=np.float32).reshape(-1, 2)
+    n = ref_uv.shape[0]
+    pts = np.ascontiguousarray(p_c_in_ref, dtype=np.float32).reshape(-1, 3)
+    # :42-44 — sizes differ: no prediction
+    cur = ref_uv.copy() if (cur_uv is None or np.asarray(cur_uv).reshape(-1, 2).shape[0] != n) else np.array(cur_uv, np.float32).reshape(-1, 2).copy()
+    q = np.array(q_rc, dtype=np.float32).copy()
+    p = np.array(p_rc, dtype=np.float32).copy()
+    valid = status is not None and np.asarray(status).size == n
+    st = np.array(status, dtype=np.uint8).copy() if valid else np.zeros(n, np.uint8)
+    if n == 0 or len(ref_levels) != len(cur_levels):
+        return False, cur, q, p, st, 0
+    ra, k1 = _images(ref_levels)
+    ca, k2 = _images(cur_levels)
+    o = _DirectOptions()
+    o.max_track_points, o.max_iteration, o.half_rows, o.half_cols = max_points, max_iteration, half, half if half_cols is None else half_cols
+    o.max_converge_step, o.max_converge_residual, o.method = converge, 2.0, METHODS[method] if isinstance(method, str) else int(method)
+    Kf = np.ascontiguousarray(K, dtype=np.float32)
+    it = C.c_uint32(0)
+    ok = lib().orc_direct_track(C.byref(o), ra, ca, len(ref_levels), Kf.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p),
+                                ref_uv.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), n, q.ctypes.data_as(C.c_void_p),
+                                p.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), int(valid), C.byref(it))
+    return bool(ok), cur, q, p, st, int(it.value)
+
+
+def quat_mul(a, b):
+    a, b, out = np.asarray(a, np.float32).copy(), np.asarray(b, np.float32).copy(), np.zeros(4, np.float32)
+    lib().orc_quat_mul(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def quat_rotate(q, v):
+    q, v, out = np.asarray(q, np.float32).copy(), np.asarray(v, np.float32).copy(), np.zeros(3, np.float32)
+    lib().orc_quat_rotate(q.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def quat_inverse(q):
+    q, out = np.asarray(q, np.float32).copy(), np.zeros(4, np.float32)
+    lib().orc_quat_inverse(q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 def brief_compute(image, uv, n_bits=256, half=8):
