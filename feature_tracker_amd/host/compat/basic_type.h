@@ -162,9 +162,66 @@ using Mat1x2 = FixedMat<1, 2>;
 using Mat1x3 = FixedMat<1, 3>;
 using Mat2x3 = FixedMat<2, 3>;
 
+using Mat2x6 = FixedMat<2, 6>;
+
 static_assert(sizeof(Vec2) == 2 * sizeof(float), "Vec2 must be a packed (u, v) pair");
+static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 must be a packed (x, y, z) triple");
+
+// Quat — stand-in for Eigen::Quaternionf as the direct-method callers use it: constructor order
+// (w, x, y, z), Identity(), inverse(), normalized() / normalize(), q * q, q * v.  Arithmetic follows
+// Eigen 3.3.7 for the reference's SSE2 build (oracle/oracle_direct_method.c states it operation by
+// operation); the device kernel and the oracle use the same definitions.
+class Quat {
+public:
+    Quat() : x_(0.0f), y_(0.0f), z_(0.0f), w_(1.0f) {}
+    Quat(float w, float x, float y, float z) : x_(x), y_(y), z_(z), w_(w) {}
+    static Quat Identity() { return Quat(1.0f, 0.0f, 0.0f, 0.0f); }
+    float w() const { return w_; }
+    float x() const { return x_; }
+    float y() const { return y_; }
+    float z() const { return z_; }
+    float &w() { return w_; }
+    float &x() { return x_; }
+    float &y() { return y_; }
+    float &z() { return z_; }
+    float squaredNorm() const { return (x_ * x_ + z_ * z_) + (y_ * y_ + w_ * w_); }
+    float norm() const { return std::sqrt(squaredNorm()); }
+    Quat inverse() const {
+        const float n2 = squaredNorm();
+        if (n2 > 0.0f) {
+            return Quat(w_ / n2, -x_ / n2, -y_ / n2, -z_ / n2);
+        }
+        return Quat(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    Quat normalized() const {
+        const float z = squaredNorm();
+        if (z > 0.0f) {
+            const float n = std::sqrt(z);
+            return Quat(w_ / n, x_ / n, y_ / n, z_ / n);
+        }
+        return *this;
+    }
+    void normalize() { *this = normalized(); }
+    Quat operator*(const Quat &b) const {
+        const Quat &a = *this;
+        return Quat((a.w_ * b.w_ - a.x_ * b.x_) - (a.z_ * b.z_ + a.y_ * b.y_), (a.x_ * b.w_ - a.z_ * b.y_) + (a.y_ * b.z_ + a.w_ * b.x_),
+                    (a.y_ * b.w_ - a.x_ * b.z_) + (a.z_ * b.x_ + a.w_ * b.y_), (a.z_ * b.w_ - a.y_ * b.x_) + (a.x_ * b.y_ + a.w_ * b.z_));
+    }
+    Vec3 operator*(const Vec3 &v) const {
+        float ux = y_ * v.z() - z_ * v.y(), uy = z_ * v.x() - x_ * v.z(), uz = x_ * v.y() - y_ * v.x();
+        ux += ux;
+        uy += uy;
+        uz += uz;
+        const float cx = y_ * uz - z_ * uy, cy = z_ * ux - x_ * uz, cz = x_ * uy - y_ * ux;
+        return Vec3((v.x() + w_ * ux) + cx, (v.y() + w_ * uy) + cy, (v.z() + w_ * uz) + cz);
+    }
+
+private:
+    float x_, y_, z_, w_;  // Eigen's coefficient order
+};
 
 constexpr int32_t kMaxInt32 = std::numeric_limits<int32_t>::max();
 constexpr float kPai = 3.14159265358979323846f;
+constexpr float kZeroFloat = 1e-6f;  // Slam_Utility slam_basic_math.h (un-vendored): this repo's normative value
 
 #endif  // _SLAM_UTILITY_BASIC_TYPE_H_

@@ -2,6 +2,10 @@
 #ifndef _SLAM_UTILITY_LOG_REPORTER_H_
 #define _SLAM_UTILITY_LOG_REPORTER_H_
 #include <iostream>
+#include <sstream>
+#include <string>
+
+#include "basic_type.h"
 
 #define RESET_COLOR "\033[0m"
 #define BLACK "\033[30m"
@@ -18,4 +22,20 @@
 #define ReportDebug(...) std::cout << CYAN "[Debug] " RESET_COLOR << __VA_ARGS__ << std::endl
 #define ReportWarn(...) std::cout << YELLOW "[Warn] " RESET_COLOR << __VA_ARGS__ << std::endl
 #define ReportError(...) std::cerr << RED "[Error] " RESET_COLOR << __VA_ARGS__ << std::endl
+// LogVec / LogQuat (test_direct_method.cpp:96): printable forms of small vectors and quaternions
+template <int R, int C>
+inline std::string LogVec(const FixedMat<R, C> &v) {
+    std::ostringstream os;
+    os << "[";
+    for (int i = 0; i < R * C; ++i) {
+        os << (i ? ", " : "") << v(i);
+    }
+    os << "]";
+    return os.str();
+}
+inline std::string LogQuat(const Quat &q) {
+    std::ostringstream os;
+    os << "[wxyz][" << q.w() << ", " << q.x() << ", " << q.y() << ", " << q.z() << "]";
+    return os.str();
+}
 #endif

@@ -6,6 +6,7 @@
 
 #include <string>
 
+#include "datatype_image_pyramid.h"
 #include "ftk.h"
 
 namespace feature_tracker {
@@ -16,6 +17,9 @@ namespace device {
 ftk_context *SharedContext(std::string *error);
 // Text of the last failure on the shared context.
 std::string LastError();
+// Device twin of a host ImagePyramid: uploaded once per generation of the host object, then reused by
+// every tracker that is handed the same pyramid (owned by the pyramid, released with it).
+ftk_pyramid *PyramidTwin(ftk_context *ctx, const ImagePyramid &pyramid, std::string *error);
 
 }  // namespace device
 }  // namespace feature_tracker

@@ -28,34 +28,6 @@ struct PyramidDeleter {
     void operator()(void *p) const { ftk_pyramid_destroy(static_cast<ftk_pyramid *>(p)); }
 };
 
-// Device twin of a host ImagePyramid: uploaded once per generation of the host object.
-ftk_pyramid *DeviceTwin(ftk_context *ctx, const ImagePyramid &pyramid, std::string *error) {
-    std::shared_ptr<void> &twin = pyramid.device_twin();
-    if (twin && pyramid.device_twin_generation() == pyramid.generation()) {
-        return static_cast<ftk_pyramid *>(twin.get());
-    }
-    ftk_image levels[FTK_MAX_LEVELS];
-    const int32_t n = static_cast<int32_t>(pyramid.level());
-    if (n < 1 || n > FTK_MAX_LEVELS) {
-        *error = "image pyramid has no levels (CreateImagePyramid was not called)";
-        return nullptr;
-    }
-    for (int32_t i = 0; i < n; ++i) {
-        const GrayImage &im = pyramid.GetImageConst(i);
-        levels[i].data = im.data();
-        levels[i].rows = im.rows();
-        levels[i].cols = im.cols();
-    }
-    ftk_pyramid *dev = nullptr;
-    if (ftk_pyramid_upload(ctx, levels, n, &dev) != FTK_OK) {
-        *error = ftk_last_error(ctx);
-        return nullptr;
-    }
-    twin = std::shared_ptr<void>(dev, PyramidDeleter());
-    pyramid.device_twin_generation() = pyramid.generation();
-    return dev;
-}
-
 ftk_pyramid *UploadSingle(ftk_context *ctx, const GrayImage &image, std::string *error) {
     ftk_image level;
     level.data = image.data();
@@ -119,8 +91,8 @@ bool OpticalFlow::TrackOnDevice(int model, const ImagePyramid *ref_pyramid, cons
         cur_dev = ref_dev ? UploadSingle(ctx, *cur_image, &last_error_) : nullptr;
         cur_guard.reset(cur_dev);
     } else {
-        ref_dev = DeviceTwin(ctx, *ref_pyramid, &last_error_);
-        cur_dev = ref_dev ? DeviceTwin(ctx, *cur_pyramid, &last_error_) : nullptr;
+        ref_dev = device::PyramidTwin(ctx, *ref_pyramid, &last_error_);
+        cur_dev = ref_dev ? device::PyramidTwin(ctx, *cur_pyramid, &last_error_) : nullptr;
     }
     if (ref_dev == nullptr || cur_dev == nullptr) {
         ReportError("[OpticalFlow] " << OpticalFlowMethodName() << ": " << last_error_);

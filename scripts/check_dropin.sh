@@ -11,10 +11,10 @@ HOST=$HERE/feature_tracker_amd/host
 make -s -C "$HOST" -j4
 mkdir -p "$HOST/build/dropin"
 INC="-I$HERE/include -I$HOST/compat -I$HOST/src -I$HOST/src/optical_flow_tracker -I$HOST/src/optical_flow_tracker/basic_klt \
-     -I$HOST/src/optical_flow_tracker/affine_klt -I$HOST/src/optical_flow_tracker/lssd_klt -I$HOST/src/descriptor_matcher"
-LIBS="$HOST/build/liblib_optical_flow_tracker.a $HOST/build/liblib_descriptor_matcher.a $HOST/build/liblib_substrate.a \
+     -I$HOST/src/optical_flow_tracker/affine_klt -I$HOST/src/optical_flow_tracker/lssd_klt -I$HOST/src/descriptor_matcher -I$HOST/src/direct_method_tracker"
+LIBS="$HOST/build/liblib_optical_flow_tracker.a $HOST/build/liblib_descriptor_matcher.a $HOST/build/liblib_direct_method_tracker.a $HOST/build/liblib_substrate.a \
       -L$HERE/feature_tracker_amd/csrc -lftk_hip -Wl,-rpath,$HERE/feature_tracker_amd/csrc -Wl,-rpath,/opt/rocm/lib -lz -lpthread"
-for t in test_optical_flow test_descriptor_matcher_brief test_descriptor_matcher_superpoint test_descriptor_matcher_disk; do
+for t in test_optical_flow test_descriptor_matcher_brief test_descriptor_matcher_superpoint test_descriptor_matcher_disk test_direct_method; do
   g++ -std=c++17 -O3 -Wall -Wno-unused-parameter $INC -o "$HOST/build/dropin/$t" "$REF/test/$t.cpp" $LIBS
   echo "linked unchanged: $t"
 done

@@ -170,6 +170,57 @@ def test_reference_callers_run_unchanged(tmp_path, prog, expect):
         assert int(m.group(2)) >= 50 and int(m.group(1)) >= 10, out[-1000:]  # matches found on the real image pair
 
 
+def test_reference_direct_method_program_matches_oracle(tmp_path, oracle):
+    """The reference's own test_direct_method.cpp, compiled unchanged (scripts/check_dropin.sh), on its own example
+    frames: 300 std::rand() points with stereo depth, 5 frames, 5-level pyramids.  The poses it prints must be the
+    oracle's for the same inputs (the program prints ~6 significant digits; the ABI-level tests compare bit for bit)."""
+    import ctypes
+    import re
+    from PIL import Image
+    exe = os.path.join(BUILD, "dropin", "test_direct_method")
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binaries not built (the reference is not mounted on this machine)")
+    data = os.path.join(ROOT, "tests", "data", "direct_method")
+    os.makedirs(tmp_path / "example", exist_ok=True)
+    os.symlink(data, tmp_path / "example" / "direct_method")
+    os.makedirs(tmp_path / "build", exist_ok=True)
+    res = subprocess.run([exe], cwd=tmp_path / "build", capture_output=True, text=True, timeout=300)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out[-2000:]
+    got = re.findall(r"q_rc \[wxyz\]\[([^\]]+)\], p_rc \[([^\]]+)\]", out)
+    assert len(got) == 5, out[-2000:]
+    # the same inputs, rebuilt here: glibc rand() from its default seed (test_direct_method.cpp:45-49)
+    fx = fy = np.float32(718.856)
+    cx, cy, baseline = np.float32(607.1928), np.float32(185.2157), np.float32(0.573)
+    left = np.array(Image.open(os.path.join(data, "left.png")).convert("L"))
+    disp = np.array(Image.open(os.path.join(data, "disparity.png")).convert("L"))
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    uv = np.zeros((300, 2), np.float32)
+    depth = np.zeros(300, np.float32)
+    with np.errstate(all="ignore"):
+        for i in range(300):
+            # Vec2(std::rand() % cols, std::rand() % rows): g++ evaluates constructor arguments right to left
+            v = libc.rand() % left.shape[0]
+            u = libc.rand() % left.shape[1]
+            uv[i] = (u, v)
+            depth[i] = np.float32(fx * baseline) / np.float32(int(disp[v, u]))
+        p_w = np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth, np.float32(1.0) * depth], axis=1).astype(np.float32)
+    ref_levels = synth.build_pyramid(left, 5)
+    q, p, cur_uv, status = np.float32([1, 0, 0, 0]), np.zeros(3, np.float32), None, None
+    with np.errstate(all="ignore"):
+        for k in range(5):
+            cur = np.array(Image.open(os.path.join(data, f"00000{k + 1}.png")).convert("L"))
+            # world frame == reference camera frame here (q_ref = I, p_ref = 0), so the world overload reduces to the camera one
+            ok, cur_uv, q, p, status, _ = oracle.direct_track(ref_levels, synth.build_pyramid(cur, 5), [fx, fy, cx, cy], p_w, uv, cur_uv, q, p, None,
+                                                              max_points=500)
+            gq = np.array([float(x) for x in got[k][0].split(",")])
+            gp = np.array([float(x) for x in got[k][1].split(",")])
+            assert np.allclose(gq, q, rtol=2e-4, atol=2e-6), (k, gq, q)
+            assert np.allclose(gp, p, rtol=2e-4, atol=2e-6), (k, gp, p)
+    assert abs(p[2]) > 0.5  # the car drove forward over the five frames
+
+
 def test_demo_on_reference_example_images():
     """The reference's own example pair (752x480 PNGs): Harris corners -> pyramids -> 3 trackers; most corners must track."""
     exe = os.path.join(BUILD, "demo_optical_flow")

@@ -348,3 +348,46 @@ def test_float_matcher_semantics(oracle):
     with np.errstate(all="ignore"):
         _, z = oracle.match_float(ref, cur3, 0.6)
     assert (z != 0).all()
+
+
+# ---- DirectMethod: quaternion substrate + pose recovery --------------------
+
+def test_quaternion_substrate_known_answers(oracle):
+    ident = np.float32([1, 0, 0, 0])
+    qz90 = np.float32([np.sqrt(0.5), 0, 0, np.sqrt(0.5)])  # 90 degrees about z
+    assert np.array_equal(oracle.quat_mul(ident, qz90), qz90) and np.array_equal(oracle.quat_mul(qz90, ident), qz90)
+    assert np.allclose(oracle.quat_rotate(qz90, [1, 0, 0]), [0, 1, 0], atol=1e-6)
+    assert np.allclose(oracle.quat_mul(qz90, qz90), [0, 0, 0, 1], atol=1e-6)
+    inv = oracle.quat_inverse(np.float32([2, 0, 0, 0]))  # conjugate / squaredNorm: not assumed unit
+    assert np.array_equal(inv, np.float32([0.5, 0, 0, 0]))
+    assert np.array_equal(oracle.quat_inverse(np.zeros(4, np.float32)), np.zeros(4, np.float32))
+    # i * j = k, j * i = -k (Hamilton convention, coefficients (w, x, y, z))
+    assert np.array_equal(oracle.quat_mul([0, 1, 0, 0], [0, 0, 1, 0]), np.float32([0, 0, 0, 1]))
+    assert np.array_equal(oracle.quat_mul([0, 0, 1, 0], [0, 1, 0, 0]), np.float32([0, 0, 0, -1]))
+
+
+def test_direct_method_recovers_a_known_translation(oracle):
+    """Fronto-parallel plane at depth Z, image shifted by (du, dv): the camera moved by (-du Z / fx, -dv Z / fy, 0)."""
+    w, h, Z, fx, fy, cx, cy = 640, 480, 5.0, 400.0, 400.0, 320.0, 240.0
+    ref, cur = synth.make_image_pair(w, h, (3.3, -2.1))
+    rl, cl = synth.build_pyramid(ref, 4), synth.build_pyramid(cur, 4)
+    uv = synth.make_features(200, w, h, half=6)
+    pts = np.stack([(uv[:, 0] - cx) / fx * Z, (uv[:, 1] - cy) / fy * Z, np.full(len(uv), Z)], axis=1).astype(np.float32)
+    ok, c, q, p, st, it = oracle.direct_track(rl, cl, [fx, fy, cx, cy], pts, uv, max_points=200)
+    assert ok and 4 <= it <= 60
+    assert abs(p[0] + 3.3 * Z / fx) < 1e-3 and abs(p[1] - 2.1 * Z / fy) < 1e-3 and abs(p[2]) < 1e-2
+    assert abs(q[0] - 1) < 1e-4 and np.abs(q[1:]).max() < 1e-3
+    assert np.abs(c - (uv + np.float32([3.3, -2.1]))).max() < 0.2 and (st == 1).all()
+    # the stub methods leave everything alone but still produce statuses (direct_method_tracker.cpp:108-113,194-199)
+    ok, c2, q2, p2, st2, it2 = oracle.direct_track(rl, cl, [fx, fy, cx, cy], pts, uv, method="fast")
+    assert ok and it2 == 0 and np.array_equal(c2, uv) and np.array_equal(q2, np.float32([1, 0, 0, 0])) and (st2 == 1).all()
+    # status of the right size is kept, and only overwritten by kOutside
+    pred = uv.copy()
+    pred[0] = (-3.0, 5.0)
+    pts2 = pts.copy()
+    pts2[0, 2] = -1.0  # skipped feature keeps its (outside) prediction
+    st_in = np.full(len(uv), 2, np.uint8)
+    ok, c3, _, _, st3, _ = oracle.direct_track(rl, cl, [fx, fy, cx, cy], pts2, uv, pred, status=st_in, max_points=200)
+    assert st3[0] == 3 and (st3[1:] == 2).all()
+    ok, *_ = oracle.direct_track(rl, cl[:3], [fx, fy, cx, cy], pts, uv)
+    assert ok is False
