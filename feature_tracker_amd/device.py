@@ -122,3 +122,34 @@ def brief_compute_device(ctx: Context, image_pyr: ImagePyramid, uv, n_bits: int,
     rc = N.lib().ftk_brief_compute_device(ctx.handle, image_pyr.handle, int(level), C.c_void_p(uv.data_ptr()), uv.shape[0], int(n_bits),
                                           int(half_patch), C.c_void_p(words_out.data_ptr()))
     N.check(rc, ctx.handle)
+
+
+class DeviceDirectBatch:
+    """A batch of DirectMethod pose problems (ftk_direct_track_batch_device): one workgroup per problem, ONE launch.
+    Every tensor stays in HBM; ``problems`` is a list of dicts with keys ref, cur (ImagePyramid), K (4 floats),
+    p_c_in_ref [n, 3], ref_uv [n, 2], cur_uv [n, 2] (in/out), pose [7] (q w,x,y,z then p; in/out), status [n] uint8,
+    status_valid (bool) and optionally iterations (int32 [1])."""
+
+    def __init__(self, options, problems, ctx: Context):
+        self.ctx = ctx
+        self.opt = options.to_native()
+        self._keep = problems
+        self.n = len(problems)
+        self.table = (N.DirectProblem * self.n)()
+        for k, pr in enumerate(problems):
+            t = self.table[k]
+            t.ref, t.cur = pr["ref"].handle, pr["cur"].handle
+            for i in range(4):
+                t.K[i] = float(pr["K"][i])
+            t.d_p_c_in_ref = pr["p_c_in_ref"].data_ptr()
+            t.d_ref_uv = pr["ref_uv"].data_ptr()
+            t.d_cur_uv = pr["cur_uv"].data_ptr()
+            t.n = int(pr["ref_uv"].shape[0])
+            t.d_pose = pr["pose"].data_ptr()
+            t.d_status = pr["status"].data_ptr()
+            t.status_valid = int(bool(pr.get("status_valid", False)))
+            it = pr.get("iterations")
+            t.d_iterations = None if it is None else it.data_ptr()
+
+    def track(self):
+        N.check(N.lib().ftk_direct_track_batch_device(self.ctx.handle, C.byref(self.opt), self.table, self.n), self.ctx.handle)

@@ -188,6 +188,64 @@ def float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, orac
     }
 
 
+def direct_method_cases(torch, F, D, synth, oracle, quick=False):
+    """DirectMethod: the reference's shape (300 points, 13 x 13, 5 levels, 1241 x 376) as one problem and as
+    a batch of independent problems in one launch; CPU = the oracle, single thread."""
+    w, h, levels, n, half = 1241, 376, 5, 300, 6
+    fx = fy = 718.856
+    cx, cy = 607.1928, 185.2157
+    ref_img, cur_img = synth.make_image_pair(w, h, (2.6, -1.2))
+    rl, cl = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    out = []
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        rp, cp = D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev)
+        for batch in (1, 64, 256):
+            problems, host = [], []
+            for b in range(batch):
+                uv = synth.make_features(n, w, h, seed=100 + b, half=half)
+                z = np.full(n, 8.0, np.float32)
+                pts = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], axis=1).astype(np.float32)
+                host.append((uv, pts))
+                problems.append(dict(ref=rp, cur=cp, K=[fx, fy, cx, cy], p_c_in_ref=torch.from_numpy(pts).to(dev), ref_uv=torch.from_numpy(uv).to(dev),
+                                     cur_uv=torch.from_numpy(uv).to(dev), pose=torch.zeros(7, dtype=torch.float32, device=dev),
+                                     status=torch.zeros(n, dtype=torch.uint8, device=dev), status_valid=False,
+                                     iterations=torch.zeros(1, dtype=torch.int32, device=dev)))
+            opt = F.DirectMethodOptions()
+            opt.kMaxTrackPointsNumber = n
+            runner = D.DeviceDirectBatch(opt, problems, ctx)
+
+            def reset():
+                for pr, (uv, _) in zip(problems, host):
+                    pr["cur_uv"].copy_(torch.from_numpy(uv))
+                    pr["pose"].copy_(torch.tensor([1, 0, 0, 0, 0, 0, 0], dtype=torch.float32))
+            times = []
+            for _ in range(3 if quick else 6):
+                reset()
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                runner.track()
+                e1.record(stream)
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1))
+            gpu_ms = float(np.median(times))
+            pose0 = problems[0]["pose"].cpu().numpy()
+            it0 = int(problems[0]["iterations"].cpu().numpy()[0])
+            uv, pts = host[0]
+            t0 = time.perf_counter()
+            ok, c, q, p, st, it = oracle.direct_track(rl, cl, [fx, fy, cx, cy], pts, uv, max_points=n)
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+            out.append({"case": f"direct_method_{n}pts_{w}x{h}_{levels}lvl_batch{batch}", "problems": batch, "gpu_launch_ms": gpu_ms,
+                        "gpu_ms_per_problem": gpu_ms / batch, "cpu_ms_per_problem": cpu_ms, "speedup": cpu_ms * batch / gpu_ms, "iterations": it0,
+                        "bit_identical_pose": bool(np.array_equal(pose0[:4].view(np.uint32), q.view(np.uint32)) and
+                                                   np.array_equal(pose0[4:].view(np.uint32), p.view(np.uint32))),
+                        "iterations_equal": it0 == it})
+    return out
+
+
 def producer_cases(torch, F, D, synth, oracle, reps):
     """Harris detection and BRIEF description on the reference's example-sized image."""
     from PIL import Image
@@ -241,6 +299,10 @@ def main():
     if args.only == "cosine":
         float_matcher_cases(torch, F, D, synth, oracle, reps, args.quick)
         return
+    if args.only == "direct":
+        for out in direct_method_cases(torch, F, D, synth, oracle, args.quick):
+            print(json.dumps(out), flush=True)
+        return
     if args.only == "match":
         for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True)):
             print(json.dumps(matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000)), flush=True)
@@ -267,6 +329,8 @@ def main():
         out = matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000 if args.quick else 20_000_000)
         print(json.dumps(out), flush=True)
     float_matcher_cases(torch, F, D, synth, oracle, reps)
+    for out in direct_method_cases(torch, F, D, synth, oracle, args.quick):
+        print(json.dumps(out), flush=True)
 
 
 def float_matcher_cases(torch, F, D, synth, oracle, reps, quick=False):

@@ -45,6 +45,12 @@ def run_case(oracle, z):
         ok, idx = oracle.nearby_match(z["ref_bits"], z["cur_bits"], z["pred_uv"], z["cur_uv"], float(z["max_distance"]), int(z["max_col"]),
                                       int(z["max_row"]))
         return {"index": idx}
+    if kind == "direct":
+        levels = int(z["levels"])
+        ok, c, q, p, st, it = oracle.direct_track([z[f"ref{i}"] for i in range(levels)], [z[f"cur{i}"] for i in range(levels)], z["K"], z["p_c_in_ref"],
+                                                  z["ref_uv"], z["cur_uv"] if z["cur_uv"].size else None, z["q_rc"], z["p_rc"],
+                                                  z["status"] if z["status"].size else None, half=int(z["half"]), max_points=int(z["max_points"]))
+        return {"uv": c, "q": q, "p": p, "status": st, "iters": np.array([it], np.uint32)}
     if kind == "float_force":
         ok, idx = oracle.match_float(z["ref_desc"], z["cur_desc"], float(z["max_distance"]))
         return {"index": idx}
@@ -111,6 +117,20 @@ def generate(only=()):
                                             max_distance=np.float32(0.2))))
     cases.append(("match_float_nearby", dict(kind="float_nearby", ref_desc=fref.astype(np.float16), cur_desc=fcur.astype(np.float16), pred_uv=puv,
                                              cur_uv=cuv, max_distance=np.float32(0.6), max_col=50, max_row=40)))
+
+    # DirectMethod: small scene, prediction + initial pose + status, a point behind the camera, a cap
+    from tests import scenes as _scenes
+    rl, cl = _scenes.scene(160, 120, 3, "easy", "similarity")
+    duv = _scenes.features(60, 160, 120, half=4)
+    dz = (3.0 + 0.02 * np.arange(60)).astype(np.float32)
+    dK = np.float32([150.0, 152.0, 80.5, 60.25])
+    dpts = np.stack([(duv[:, 0] - dK[2]) / dK[0] * dz, (duv[:, 1] - dK[3]) / dK[1] * dz, dz], axis=1).astype(np.float32)
+    dpts[5, 2] = -1.0
+    dcase = dict(kind="direct", levels=3, half=4, max_points=50, K=dK, p_c_in_ref=dpts, ref_uv=duv, cur_uv=(duv + np.float32([0.5, -0.25])).astype(np.float32),
+                 q_rc=np.float32([0.9999, 0.002, -0.003, 0.001]), p_rc=np.float32([0.01, -0.02, 0.005]), status=(np.arange(60) % 4).astype(np.uint8))
+    for i in range(3):
+        dcase[f"ref{i}"], dcase[f"cur{i}"] = rl[i], cl[i]
+    cases.append(("direct_method", dcase))
 
     for name, d in cases:
         if only and name not in only:

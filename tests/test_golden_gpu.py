@@ -39,6 +39,19 @@ def test_hip_reproduces_golden(ftk, name):
         assert np.abs(c.astype(np.float64) - z["out_uv"].astype(np.float64))[np.isfinite(z["out_uv"])].max() <= 1e-3  # north_star tolerance
         assert np.array_equal(c.view(np.uint32), z["out_uv"].view(np.uint32))  # design goal: bit-identical
         assert np.array_equal(klt.last_iterations, z["out_iters"])
+    elif kind == "direct":
+        levels = int(z["levels"])
+        dm = ftk.DirectMethod()
+        dm.options().kPatchRowHalfSize = dm.options().kPatchColHalfSize = int(z["half"])
+        dm.options().kMaxTrackPointsNumber = int(z["max_points"])
+        ok, c, q, p, st = dm.TrackFeatures(ftk.ImagePyramid.from_host_levels([z[f"ref{i}"] for i in range(levels)]),
+                                           ftk.ImagePyramid.from_host_levels([z[f"cur{i}"] for i in range(levels)]), z["K"], z["p_c_in_ref"], z["ref_uv"],
+                                           z["cur_uv"], z["q_rc"], z["p_rc"], z["status"])
+        assert ok and dm.last_iterations == int(z["out_iters"][0])
+        assert np.array_equal(st, z["out_status"])
+        assert np.abs(c.astype(np.float64) - z["out_uv"].astype(np.float64)).max() <= 1e-3  # north_star tolerance
+        assert np.array_equal(c.view(np.uint32), z["out_uv"].view(np.uint32))
+        assert np.array_equal(q.view(np.uint32), z["out_q"].view(np.uint32)) and np.array_equal(p.view(np.uint32), z["out_p"].view(np.uint32))
     elif kind in ("float_force", "float_nearby"):
         m = ftk.CosineMatcher()
         m.options().kMaxValidDescriptorDistance = float(z["max_distance"])
