@@ -91,8 +91,9 @@ __device__ __forceinline__ float eigen_dot_octet(const float *__restrict__ x, co
 }
 
 // ---- 1. norms + unit-length fp16 copies ------------------------------------------------------
-// One octet per (padded) row of one operand.  which == 0: ref, 1: cur.
-__global__ void __launch_bounds__(256) cosine_prep_kernel(const CosineParams p, int which) {
+// One octet per (padded) row of one operand; blockIdx.y == 0: ref, 1: cur.
+__global__ void __launch_bounds__(256) cosine_prep_kernel(const CosineParams p) {
+    const int which = (int)blockIdx.y;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = tid >> 3, c = tid & 7, base = (threadIdx.x & 63) & ~7;
     const int n = which ? p.n_cur : p.n_ref;
@@ -295,6 +296,238 @@ __global__ void __launch_bounds__(256) cosine_gemm_kernel(const CosineParams p) 
 
 #undef FTK_LOAD_CHUNK
 
+// ---- 2 / 3 (dim_pad <= 256): ref-stationary contraction ----------------------------------------
+// rocprofv3 on the kernel above (10 000^2 x 256): MFMA busy 25 %, 41 % of the wave time waiting on
+// memory, a third of the L2 lookups missing — each workgroup re-fetches its ref chunk for every cur
+// tile and has a prefetch distance of one 64-wide chunk (~500 cycles) against L2-miss latency.
+// Here a workgroup of 8 waves keeps its 128 ref rows for the WHOLE K in LDS (loaded once), streams
+// cur chunks of 256 rows x 64 K through a double-buffered LDS tile with the global loads issued
+// TWO chunks ahead (two named register sets), and pays one barrier per chunk.  Wave (wm, wn) of
+// the 4 x 2 grid computes 64 cur x 64 ref = 2 x 2 MFMA tiles; the epilogue is unchanged.
+constexpr int kCurTile = 256;
+
+template <bool kCollect, bool kNearby>
+__global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    const int pitch_y = p.dim_pad + 8;                                         // halfs
+    _Float16 *const sY = reinterpret_cast<_Float16 *>(rs_lds);                 // [128][pitch_y]
+    _Float16 *const sX = sY + kTile * pitch_y;                                 // [2][256][kPitch]
+    float4 *const sInfo = reinterpret_cast<float4 *>(sX + 2 * kCurTile * kPitch);  // [2][256]: {bias, u, v, -}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.x * kTile;
+    const int tiles_total = p.n_cur_pad / kCurTile;
+    const int jt_begin = blockIdx.y * p.tiles_per_split;
+    const int jt_end = min(jt_begin + p.tiles_per_split, tiles_total);
+    if (jt_begin >= jt_end) {
+        return;
+    }
+    const int n_chunks = p.dim_pad / kChunkK;
+    const int total_chunks = (jt_end - jt_begin) * n_chunks;
+    const float pos_inf = __uint_as_float(0x7F800000u), neg_inf = __uint_as_float(0xFF800000u);
+
+    int row_i[2];
+    bool live[2];
+    float pu[2], pv[2], thr[2], best[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int i = i0 + wn * 64 + nt * 32 + (lane & 31);
+        row_i[nt] = i;
+        live[nt] = i < p.n_ref && p.ref_irregular[i] == 0;
+        pu[nt] = (kNearby && i < p.n_ref) ? p.pred_uv[2 * i] : 0.0f;
+        pv[nt] = (kNearby && i < p.n_ref) ? p.pred_uv[2 * i + 1] : 0.0f;
+        best[nt] = neg_inf;
+        thr[nt] = pos_inf;
+        if (kCollect && live[nt]) {
+            const uint32_t key = p.row_max[i];
+            thr[nt] = (key == 0u) ? pos_inf : order_value(key) - 2.0f * kMargin;
+        }
+    }
+
+    // ref rows, whole K, once: thread t copies dim_pad / 4 halfs of row t / 4
+    {
+        const int r = tid >> 2, part = tid & 3, span = p.dim_pad / 4;  // span is a multiple of 16 halfs (dim_pad % 64 == 0)
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.ref_h + (size_t)(i0 + r) * p.dim_pad + part * span);
+        uint4 *dst = reinterpret_cast<uint4 *>(sY + r * pitch_y + part * span);
+        for (int k = 0; k < span / 8; ++k) {
+            dst[k] = src[k];
+        }
+    }
+
+    // cur chunk staging: thread t carries 64 B (32 halfs) of row t / 2
+    const int srow = tid >> 1, scol = (tid & 1) * 32;
+    const _Float16 *const gx_base = p.cur_h + (size_t)srow * p.dim_pad + scol;
+    auto chunk_src = [&](int c) {
+        const int jt = jt_begin + c / n_chunks, kc = c - (c / n_chunks) * n_chunks;
+        return reinterpret_cast<const uint4 *>(gx_base + (size_t)jt * kCurTile * p.dim_pad + kc * kChunkK);
+    };
+    // two named register sets (an aggregate passed by reference into a lambda ends up in scratch memory)
+    uint4 s0a, s0b, s0c, s0d, s1a, s1b, s1c, s1d;
+#define FTK_RS_LOAD(A, B, C, D, c_)          \
+    do {                                     \
+        const uint4 *g_ = chunk_src(c_);     \
+        A = g_[0];                           \
+        B = g_[1];                           \
+        C = g_[2];                           \
+        D = g_[3];                           \
+    } while (0)
+#define FTK_RS_STORE(A, B, C, D, buf_)                                                                       \
+    do {                                                                                                     \
+        uint4 *d_ = reinterpret_cast<uint4 *>(sX + ((buf_) * kCurTile + srow) * kPitch + scol);              \
+        d_[0] = A;                                                                                           \
+        d_[1] = B;                                                                                           \
+        d_[2] = C;                                                                                           \
+        d_[3] = D;                                                                                           \
+    } while (0)
+    auto write_info = [&](int tile_index) {  // per-candidate data of cur tile jt_begin + tile_index
+        if (tid < kCurTile) {
+            const int j = (jt_begin + tile_index) * kCurTile + tid;
+            float4 info = make_float4(p.cur_bias[j], 0.0f, 0.0f, 0.0f);
+            if (kNearby && j < p.n_cur) {
+                info.y = p.cur_uv[2 * j];
+                info.z = p.cur_uv[2 * j + 1];
+            }
+            sInfo[(tile_index & 1) * kCurTile + tid] = info;
+        }
+    };
+
+    // set (c & 1) carries chunk c between its load and its LDS store
+    FTK_RS_LOAD(s0a, s0b, s0c, s0d, 0);
+    FTK_RS_STORE(s0a, s0b, s0c, s0d, 0);
+    write_info(0);
+    if (total_chunks > 1) {
+        FTK_RS_LOAD(s1a, s1b, s1c, s1d, 1);
+    }
+    if (total_chunks > 2) {
+        FTK_RS_LOAD(s0a, s0b, s0c, s0d, 2);
+    }
+
+    float16v acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[mt][nt][r] = 0.0f;
+                }
+            }
+        }
+    };
+    zero_acc();
+
+    // one pipeline step: chunk c is in LDS buffer c & 1; the set named at the call site holds chunk c + 1 and is
+    // refilled with chunk c + 3 (FTK_RS_STEP below); `compute` is the part that touches no staging register
+    auto compute = [&](int c) {
+        const int tile_index = c / n_chunks, kc = c - tile_index * n_chunks;
+        if (kc == 0 && jt_begin + tile_index + 1 < jt_end) {
+            write_info(tile_index + 1);
+        }
+        const _Float16 *bx = sX + ((c & 1) * kCurTile) * kPitch;
+#pragma unroll
+        for (int kk = 0; kk < kChunkK / 16; ++kk) {
+            half8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const half8 *>(&bx[(wm * 64 + t * 32 + (lane & 31)) * kPitch + kk * 16 + 8 * (lane >> 5)]);
+                b[t] = *reinterpret_cast<const half8 *>(&sY[(wn * 64 + t * 32 + (lane & 31)) * pitch_y + kc * kChunkK + kk * 16 + 8 * (lane >> 5)]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (kc == n_chunks - 1) {
+            // epilogue of this cur tile: C/D map of the 32x32 MFMA — col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            const int j0 = (jt_begin + tile_index) * kCurTile;
+            const float4 *info_tile = sInfo + (tile_index & 1) * kCurTile;
+            // straight-line pass: bias, window, running maximum (per tile in collect mode, per launch otherwise)
+            float tile_best[2] = {neg_inf, neg_inf};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float4 info = info_tile[jl];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        float v = acc[mt][nt][r] + info.x;
+                        if (kNearby) {
+                            const bool out = (int)(fabsf(pu[nt] - info.y) > p.max_col) | (int)(fabsf(pv[nt] - info.z) > p.max_row);
+                            v = out ? neg_inf : v;
+                        }
+                        if (kCollect) {
+                            acc[mt][nt][r] = v;  // kept for the (rare) second look below
+                        }
+                        tile_best[nt] = fmaxf(tile_best[nt], v);
+                    }
+                }
+            }
+            if (!kCollect) {
+                best[0] = fmaxf(best[0], tile_best[0]);
+                best[1] = fmaxf(best[1], tile_best[1]);
+            } else {
+                // a tile holds a candidate for very few rows: one test per (lane, nt) instead of one branch per element
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (tile_best[nt] >= thr[nt]) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if (acc[mt][nt][r] >= thr[nt]) {
+                                    const int jl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                    const uint32_t slot = atomicAdd(&p.cand_count[row_i[nt]], 1u);
+                                    if (slot < (uint32_t)kCosineCandCap) {
+                                        p.cand[(size_t)row_i[nt] * kCosineCandCap + slot] = j0 + jl;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            zero_acc();
+        }
+    };
+
+#define FTK_RS_STEP(c_, A, B, C, D)                                                                                       \
+    do {                                                                                                                  \
+        __syncthreads(); /* chunk c visible; everyone is done with chunk c - 1 (its buffer, the older sInfo half) */      \
+        if ((c_) + 1 < total_chunks) {                                                                                    \
+            FTK_RS_STORE(A, B, C, D, ((c_) + 1) & 1);                                                                     \
+        }                                                                                                                 \
+        if ((c_) + 3 < total_chunks) {                                                                                    \
+            FTK_RS_LOAD(A, B, C, D, (c_) + 3);                                                                            \
+        }                                                                                                                 \
+        compute(c_);                                                                                                      \
+    } while (0)
+    for (int c = 0; c < total_chunks; c += 2) {
+        FTK_RS_STEP(c, s1a, s1b, s1c, s1d);  // chunk c + 1 lives in set 1 (odd), refilled with chunk c + 3
+        if (c + 1 < total_chunks) {
+            FTK_RS_STEP(c + 1, s0a, s0b, s0c, s0d);  // chunk c + 2 lives in set 0 (even), refilled with chunk c + 4
+        }
+    }
+#undef FTK_RS_STEP
+#undef FTK_RS_LOAD
+#undef FTK_RS_STORE
+    if (!kCollect) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float other = __shfl_xor(best[nt], 32);
+            const float m = fmaxf(best[nt], other);
+            if (lane < 32 && live[nt] && m > neg_inf) {
+                atomicMax(&p.row_max[row_i[nt]], order_key(m));
+            }
+        }
+    }
+}
+
 // ---- 4. exact decision -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams p) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,34 +572,57 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
 
 }  // namespace
 
+size_t cosine_rs_lds_bytes(int dim_pad) {
+    return sizeof(_Float16) * ((size_t)kTile * (dim_pad + 8) + (size_t)2 * kCurTile * kPitch) + sizeof(float4) * 2 * kCurTile;
+}
+
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     if (p.n_ref <= 0 || p.n_cur <= 0) {
         return hipSuccess;
     }
-    hipError_t e = hipMemsetAsync(p.row_max, 0, sizeof(uint32_t) * (size_t)p.n_ref_pad, stream);  // key 0 = "no candidate yet"
+    hipError_t e = hipMemsetAsync(p.clear_begin, 0, p.clear_bytes, stream);  // key 0 = "no candidate yet", counts 0
     if (e != hipSuccess) {
         return e;
     }
-    e = hipMemsetAsync(p.cand_count, 0, sizeof(uint32_t) * (size_t)p.n_ref_pad, stream);
-    if (e != hipSuccess) {
-        return e;
+    // both operands in one launch: blockIdx.y selects ref / cur
+    {
+        const int rows = p.n_ref_pad > p.n_cur_pad ? p.n_ref_pad : p.n_cur_pad;
+        hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((rows * 8 + 255) / 256), 2u), dim3(256), 0, stream, p);
     }
-    e = hipMemsetAsync(p.irregular_count, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) {
-        return e;
-    }
-    hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((p.n_ref_pad * 8 + 255) / 256)), dim3(256), 0, stream, p, 0);
-    hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((p.n_cur_pad * 8 + 255) / 256)), dim3(256), 0, stream, p, 1);
     const int row_tiles = p.n_ref_pad / kTile;
-    const int tiles_total = p.n_cur_pad / kTile;
-    const int splits = (tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
-    const dim3 grid((unsigned)row_tiles, (unsigned)splits);
-    if (p.pred_uv) {
-        hipLaunchKernelGGL((cosine_gemm_kernel<false, true>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((cosine_gemm_kernel<true, true>), grid, dim3(256), 0, stream, p);
+    if (p.ref_stationary) {
+        const int tiles_total = p.n_cur_pad / kCurTile;
+        const int splits = (tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
+        const dim3 grid((unsigned)row_tiles, (unsigned)splits);
+        const size_t lds = cosine_rs_lds_bytes(p.dim_pad);
+#define FTK_RS_LAUNCH(COLLECT, NEARBY)                                                                                            \
+    do {                                                                                                                            \
+        auto kern = cosine_gemm_rs_kernel<COLLECT, NEARBY>;                                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        if (e != hipSuccess) {                                                                                                      \
+            return e;                                                                                                               \
+        }                                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);                                                                  \
+    } while (0)
+        if (p.pred_uv) {
+            FTK_RS_LAUNCH(false, true);
+            FTK_RS_LAUNCH(true, true);
+        } else {
+            FTK_RS_LAUNCH(false, false);
+            FTK_RS_LAUNCH(true, false);
+        }
+#undef FTK_RS_LAUNCH
     } else {
-        hipLaunchKernelGGL((cosine_gemm_kernel<false, false>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((cosine_gemm_kernel<true, false>), grid, dim3(256), 0, stream, p);
+        const int tiles_total = p.n_cur_pad / kTile;
+        const int splits = (tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
+        const dim3 grid((unsigned)row_tiles, (unsigned)splits);
+        if (p.pred_uv) {
+            hipLaunchKernelGGL((cosine_gemm_kernel<false, true>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((cosine_gemm_kernel<true, true>), grid, dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((cosine_gemm_kernel<false, false>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((cosine_gemm_kernel<true, false>), grid, dim3(256), 0, stream, p);
+        }
     }
     hipLaunchKernelGGL(cosine_recheck_kernel, dim3((unsigned)((p.n_ref * 8 + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();

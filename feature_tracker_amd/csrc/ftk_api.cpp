@@ -1285,15 +1285,24 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.n_ref = n_ref;
     p.n_cur = n_cur;
     p.dim = dim;
-    p.n_ref_pad = (int32_t)align_up((size_t)n_ref, 128);
-    p.n_cur_pad = (int32_t)align_up((size_t)n_cur, 128);
     p.dim_pad = (int32_t)align_up((size_t)dim, 64);
+    // dim <= 256 (SuperPoint, DISK): the ref-stationary contraction — 128 ref rows for the whole K resident in LDS,
+    // cur streamed in 256-row tiles, one 8-wave workgroup per CU.  Longer descriptors use the chunked kernel.
+    p.ref_stationary = (p.dim_pad <= 256 && !(getenv("FTK_COSINE_CHUNKED") && atoi(getenv("FTK_COSINE_CHUNKED")) == 1)) ? 1 : 0;
+    const int cur_tile = p.ref_stationary ? 256 : 128;
+    p.n_ref_pad = (int32_t)align_up((size_t)n_ref, 128);
+    p.n_cur_pad = (int32_t)align_up((size_t)n_cur, (size_t)cur_tile);
     p.max_distance = max_distance;
     p.max_col = (float)max_col_distance;
     p.max_row = (float)max_row_distance;
-    // enough workgroups for ~3 per CU; each walks a contiguous run of cur tiles
-    const int row_tiles = p.n_ref_pad / 128, tiles_total = p.n_cur_pad / 128;
-    int splits = (768 + row_tiles - 1) / row_tiles;
+    // Keep the whole grid co-resident in ONE round (ref-stationary: one workgroup per CU -> <= 256; chunked: two per
+    // CU -> <= 512), each workgroup walking a contiguous run of cur tiles: a second, partly filled round costs more
+    // than slightly longer runs.
+    const int row_tiles = p.n_ref_pad / 128, tiles_total = p.n_cur_pad / cur_tile;
+    int splits = (p.ref_stationary ? 256 : 512) / row_tiles;
+    if (const char *env = getenv("FTK_COSINE_SPLITS")) {
+        splits = atoi(env);  // experiment override
+    }
     splits = std::max(1, std::min(splits, tiles_total));
     p.tiles_per_split = (tiles_total + splits - 1) / splits;
     // workspace carve-up (every region 256-byte aligned)
@@ -1309,10 +1318,12 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     const size_t o_cur_norm = carve(sizeof(float) * (size_t)p.n_cur_pad);
     const size_t o_cur_bias = carve(sizeof(float) * (size_t)p.n_cur_pad);
     const size_t o_ref_irr = carve((size_t)p.n_ref_pad);
+    // row_max | cand_count | irregular_count are adjacent: ONE memset clears them (key 0 = "no candidate yet")
     const size_t o_row_max = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
     const size_t o_cnt = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
-    const size_t o_cand = carve(sizeof(int32_t) * (size_t)p.n_ref_pad * ftk::kCosineCandCap);
     const size_t o_irr_cnt = carve(sizeof(uint32_t));
+    const size_t o_clear_end = off;
+    const size_t o_cand = carve(sizeof(int32_t) * (size_t)p.n_ref_pad * ftk::kCosineCandCap);
     const size_t o_irr_list = carve(sizeof(int32_t) * ftk::kCosineIrregularCap);
     const int rc = ensure_cosine_ws(ctx, off);
     if (rc != FTK_OK) {
@@ -1330,6 +1341,8 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.cand = reinterpret_cast<int32_t *>(ws + o_cand);
     p.irregular_count = reinterpret_cast<uint32_t *>(ws + o_irr_cnt);
     p.irregular_list = reinterpret_cast<int32_t *>(ws + o_irr_list);
+    p.clear_begin = ws + o_row_max;
+    p.clear_bytes = o_clear_end - o_row_max;
     FTK_HIP(ctx, ftk::cosine_match_launch(p, ctx->stream));
     return FTK_OK;
 }

@@ -94,10 +94,14 @@ struct CosineParams {
     int32_t *cand;            // [n_ref_pad][kCosineCandCap]
     uint32_t *irregular_count;
     int32_t *irregular_list;  // [kCosineIrregularCap]
+    void *clear_begin;        // row_max | cand_count | irregular_count, contiguous: zeroed by one memset per call
+    size_t clear_bytes;
     int32_t n_ref, n_cur, dim, n_ref_pad, n_cur_pad, dim_pad;
-    int32_t tiles_per_split;  // 128-row cur tiles walked by one workgroup
+    int32_t tiles_per_split;  // cur tiles (128 rows; 256 in ref-stationary mode) walked by one workgroup
+    int32_t ref_stationary;   // dim_pad <= 256: cosine_gemm_rs_kernel (n_cur_pad is then a multiple of 256)
     float max_distance, max_col, max_row;
 };
+size_t cosine_rs_lds_bytes(int dim_pad);
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
 
 // DirectMethod (direct_kernels.hip): one workgroup per pose problem; all problems of a launch share
