@@ -1,4 +1,4 @@
-"""Feature sharding across the GPUs of one node.
+"""Feature / descriptor-row sharding across the GPUs of one node.
 
 Features are independent units (basic_klt.cpp:13-54 keeps no cross-feature state), so the path
 shards by block-partitioning the feature list over ranks, replicating both pyramids, and joining
@@ -109,3 +109,54 @@ class ShardedKlt:
     def track(self, ref_uv, cur_uv_in, status_in, iters=None):
         """Returns (cur_uv [n, 2], status [n]) for ALL features, in order."""
         return unpack_gathered(self.launch(ref_uv, cur_uv_in, status_in, iters), self.n, self.world)
+
+
+class ShardedMatcher:
+    """ForceMatch / NearbyMatch over the GPUs of one node ("shard ref rows, replicate cur").
+
+    Rows of the reference set are independent (descriptor_matcher.h:67-76), so rank r matches the contiguous
+    block ``shard_bounds(n_ref, world, r)`` of ref descriptors against ALL candidates and one all-gather of the
+    int32 index shards gives every rank the complete ``index_pairs_in_cur`` — identical to the single-GPU result.
+
+    ``match`` is any callable ``match(ref_rows, cur_rows, pred_rows_or_None, cur_uv_or_None, index_inout)`` on torch
+    tensors that writes the shard's indices in place (``feature_tracker_amd.device.hamming_match_device`` /
+    ``cosine_match_device`` behind a lambda on GPUs)."""
+
+    def __init__(self, match, n_ref: int, device, world_size: int = 1, rank: int = 0, group=None):
+        import torch
+
+        self.match, self.n, self.world, self.rank, self.group = match, int(n_ref), int(world_size), int(rank), group
+        self.begin, self.end = shard_bounds(self.n, self.world, self.rank)
+        self.cap = shard_capacity(self.n, self.world)
+        self.local = torch.full((self.cap,), -1, dtype=torch.int32, device=device)
+        self.gathered = torch.empty(self.cap * self.world, dtype=torch.int32, device=device)
+
+    def launch(self, ref_desc, cur_desc, pred_uv=None, cur_uv=None, index_pairs=None):
+        """Enqueue the shard's match and the all-gather; returns the gathered [world * cap] int32 buffer."""
+        import torch
+        import torch.distributed as dist
+
+        m = self.end - self.begin
+        # index_pairs is in/out in the reference (stale entries survive, descriptor_matcher.h:60-62): seed the shard
+        if index_pairs is not None:
+            self.local[:m].copy_(index_pairs[self.begin:self.end])
+        else:
+            self.local.fill_(-1)
+        if m > 0:
+            self.match(ref_desc[self.begin:self.end], cur_desc, None if pred_uv is None else pred_uv[self.begin:self.end], cur_uv, self.local[:m])
+        if self.world == 1:
+            self.gathered.copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        return self.gathered
+
+    def match_all(self, ref_desc, cur_desc, pred_uv=None, cur_uv=None, index_pairs=None):
+        """Returns index_pairs_in_cur [n_ref] for ALL reference descriptors, in order."""
+        import torch
+
+        g = self.launch(ref_desc, cur_desc, pred_uv, cur_uv, index_pairs)
+        parts = []
+        for r in range(self.world):
+            b, e = shard_bounds(self.n, self.world, r)
+            parts.append(g[r * self.cap: r * self.cap + (e - b)])
+        return torch.cat(parts, dim=0)

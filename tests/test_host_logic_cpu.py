@@ -97,6 +97,33 @@ guv, gst = sharded.track(t_uv, t_uv.clone(), torch.zeros(n, dtype=torch.uint8))
 ok, c_all, st_all, _ = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="fast", half=4, max_points=n)
 assert np.array_equal(guv.numpy().view(np.uint32), c_all.view(np.uint32)), "gathered uv differs from the unsharded run"
 assert np.array_equal(gst.numpy(), st_all)
+# descriptor matcher: ref rows sharded, candidates replicated, one all-gather of the index shards
+ref_bits, cur_bits, _ = synth.make_descriptors(53, 40, n_bits=64, flips=5)
+fref, fcur, _ = synth.make_float_descriptors(53, 40, dim=32)
+rs = np.random.RandomState(3)
+cur_uv = rs.uniform(0, 100, (40, 2)).astype(np.float32); pred_uv = rs.uniform(0, 100, (53, 2)).astype(np.float32)
+def hamming(ref_rows, cur_rows, pred, cuv, idx):
+    if pred is None:
+        ok, out = oracle_lib.force_match(ref_rows.numpy(), cur_rows.numpy(), 20.0, idx.numpy())
+    else:
+        ok, out = oracle_lib.nearby_match(ref_rows.numpy(), cur_rows.numpy(), pred.numpy(), cuv.numpy(), 20.0, 60, 60, idx.numpy())
+    idx.copy_(torch.from_numpy(out))
+def cosine(ref_rows, cur_rows, pred, cuv, idx):
+    ok, out = oracle_lib.match_float(ref_rows.numpy(), cur_rows.numpy(), 0.3, None if pred is None else pred.numpy(), None if cuv is None else cuv.numpy(),
+                                     60, 60, idx.numpy())
+    idx.copy_(torch.from_numpy(out))
+stale = torch.arange(53, dtype=torch.int32) + 500
+sm = FD.ShardedMatcher(hamming, 53, "cpu", world, rank)
+got = sm.match_all(torch.from_numpy(ref_bits), torch.from_numpy(cur_bits), index_pairs=stale)
+ok, want = oracle_lib.force_match(ref_bits, cur_bits, 20.0, stale.numpy())
+assert np.array_equal(got.numpy(), want), "sharded ForceMatch differs from the unsharded run"
+got = sm.match_all(torch.from_numpy(ref_bits), torch.from_numpy(cur_bits), torch.from_numpy(pred_uv), torch.from_numpy(cur_uv))
+ok, want = oracle_lib.nearby_match(ref_bits, cur_bits, pred_uv, cur_uv, 20.0, 60, 60)
+assert np.array_equal(got.numpy(), want), "sharded NearbyMatch differs from the unsharded run"
+sc = FD.ShardedMatcher(cosine, 53, "cpu", world, rank)
+got = sc.match_all(torch.from_numpy(fref), torch.from_numpy(fcur))
+ok, want = oracle_lib.match_float(fref, fcur, 0.3)
+assert np.array_equal(got.numpy(), want) and (want >= 0).sum() > 10, "sharded cosine ForceMatch differs from the unsharded run"
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -104,8 +131,8 @@ print("rank", rank, "ok")
 
 
 def test_two_rank_gloo_exchange(tmp_path):
-    """N > 1 path on CPU: features sharded over 2 ranks, one all-gather of the packed shards, result
-    identical to the unsharded run."""
+    """N > 1 path on CPU: features (tracker) and reference rows (matchers) sharded over 2 ranks, one all-gather
+    of the result shards, results identical to the unsharded runs."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

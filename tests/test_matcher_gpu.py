@@ -105,3 +105,25 @@ def test_config4_brute_force_property(ftk):
     inv = np.empty(n, np.int32)
     inv[perm] = np.arange(n, dtype=np.int32)
     assert np.array_equal(idx, inv)
+
+
+def test_sharded_matcher_on_device_world_size_1(ftk, oracle):
+    """dist.ShardedMatcher driving the device entry points (world size 1: the shard is everything, no collective)."""
+    import torch
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import dist as FD
+    ref, cur, _ = synth.make_descriptors(700, 900, flips=20)
+    fref, fcur, _ = synth.make_float_descriptors(700, 900, dim=128)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        d_ref = torch.from_numpy(ftk.pack_brief(ref).view(np.int32)).to(dev)
+        d_cur = torch.from_numpy(ftk.pack_brief(cur).view(np.int32)).to(dev)
+        sm = FD.ShardedMatcher(lambda r, c, p, u, idx: D.hamming_match_device(ctx, r, c, 256, 60.0, idx, p, u), 700, dev)
+        got = sm.match_all(d_ref, d_cur).cpu().numpy()
+        d_fr, d_fc = torch.from_numpy(fref).to(dev), torch.from_numpy(fcur).to(dev)
+        sc = FD.ShardedMatcher(lambda r, c, p, u, idx: D.cosine_match_device(ctx, r, c, 0.1, idx, p, u), 700, dev)
+        gotf = sc.match_all(d_fr, d_fc).cpu().numpy()
+    assert np.array_equal(got, oracle.force_match(ref, cur, 60.0)[1])
+    assert np.array_equal(gotf, oracle.match_float(fref, fcur, 0.1)[1])
