@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): the HIP path against the CPU oracle on randomly drawn problems for a fixed
+time budget — every tracker variant, both descriptor matchers, the direct method — comparing bit for bit.
+
+    python scripts/soak_parity.py [seconds] [seed]        prints one summary line per family, exits 1 on any mismatch
+
+Random axes: image size (odd sizes included), motion (translation / rotation / scale, up to ~15 px), pyramid depth,
+patch size (rectangular too), feature count, border features, predictions, incoming status, kMaxTrackPointsNumber,
+descriptor lengths / set sizes / thresholds / windows, duplicated and zero descriptors, pose priors and depths.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import feature_tracker_amd as F  # noqa: E402
+from feature_tracker_amd import synth  # noqa: E402
+from tests import oracle_lib as O  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+CLASSES = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}
+stats = {}
+
+
+def note(family, ok, detail=""):
+    s = stats.setdefault(family, [0, 0, ""])
+    s[0] += 1
+    if not ok:
+        s[1] += 1
+        s[2] = s[2] or detail
+
+
+def random_scene():
+    w, h = int(rs.choice([160, 199, 320, 333, 640])), int(rs.choice([120, 151, 240, 255, 480]))
+    t = (float(rs.uniform(-15, 15)), float(rs.uniform(-12, 12)))
+    rot, sc = (0.0, 1.0) if rs.rand() < 0.4 else (float(rs.uniform(-3, 3)), float(rs.uniform(0.97, 1.03)))
+    ref, cur = synth.make_image_pair(w, h, t, rotation_deg=rot, scale=sc)
+    if rs.rand() < 0.1:
+        cur[:, : w // 3] = 128  # a textureless band
+    levels = int(rs.randint(1, 6))
+    while (min(w, h) >> (levels - 1)) < 8:
+        levels -= 1
+    return w, h, levels, synth.build_pyramid(ref, levels), synth.build_pyramid(cur, levels), t
+
+
+def klt_round():
+    w, h, levels, rl, cl, t = random_scene()
+    n = int(rs.choice([1, 7, 64, 300, 1000, 2500]))
+    half, half_c = int(rs.randint(1, 11)), None
+    if rs.rand() < 0.2:
+        half_c = int(rs.randint(1, 11))
+    uv = synth.make_features(n, w, h, seed=int(rs.randint(1 << 30)), margin=min(40.0, w / 8.0), border_fraction=float(rs.choice([0.0, 0.05, 0.3])), half=half)
+    pred = status = None
+    if rs.rand() < 0.4:
+        pred = (uv + np.float32(t) * np.float32(rs.uniform(0.5, 1.2)) + rs.uniform(-1, 1, uv.shape)).astype(np.float32)
+    if rs.rand() < 0.3:
+        status = rs.randint(0, 5, n).astype(np.uint8)
+    max_points = int(rs.choice([n, max(1, n // 2), 500]))
+    rp, cp = F.ImagePyramid.from_host_levels(rl), F.ImagePyramid.from_host_levels(cl)
+    for model in ("basic", "affine", "lssd"):
+        for method in ("inverse", "direct", "fast"):
+            klt = CLASSES[model]()
+            o = klt.options()
+            o.kMethod, o.kPatchRowHalfSize, o.kPatchColHalfSize, o.kMaxTrackPointsNumber = method, half, half if half_c is None else half_c, max_points
+            lum = model == "lssd" and rs.rand() < 0.5
+            prior = None
+            if model == "lssd":
+                klt.consider_patch_luminance = lum
+                if rs.rand() < 0.3:
+                    a = float(rs.uniform(-0.05, 0.05))
+                    prior = np.float32([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+                    klt.predict_R_cr = prior
+            ok, c, s = klt.TrackFeatures(rp, cp, uv, pred, status)
+            ok2, oc, os_, oit = O.klt_track_pyramid(model, rl, cl, uv, pred, status, prior=prior, consider_luminance=lum, method=method, half=half,
+                                                    half_cols=half_c, max_points=max_points)
+            same = ok == ok2 and np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and np.array_equal(klt.last_iterations, oit)
+            note(f"klt/{model}/{method}", same, f"{w}x{h} L{levels} h{half}/{half_c} n{n} cap{max_points}")
+
+
+def matcher_round():
+    n_ref, n_cur = int(rs.choice([1, 33, 300, 1500])), int(rs.choice([1, 40, 257, 2000]))
+    n_bits = int(rs.choice([32, 64, 200, 256, 512]))
+    ref, cur, _ = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=max(1, n_bits // int(rs.choice([8, 13, 30]))), seed=int(rs.randint(1 << 30)))
+    if n_cur > 4:
+        cur[rs.randint(n_cur)] = cur[rs.randint(n_cur)]
+    thr = float(rs.choice([0.0, 5.0, 30.0, 60.0, 1000.0]))
+    cuv = rs.uniform(0, 500, (n_cur, 2)).astype(np.float32)
+    puv = rs.uniform(0, 500, (n_ref, 2)).astype(np.float32)
+    win = int(rs.choice([5, 50, 600]))
+    m = F.BriefMatcher()
+    m.options().kMaxValidDescriptorDistance, m.options().kMaxValidPredictColDistance, m.options().kMaxValidPredictRowDistance = thr, win, win // 2 + 1
+    ok, idx = m.ForceMatch(ref, cur)
+    note("match/hamming/force", np.array_equal(idx, O.force_match(ref, cur, thr)[1]), f"{n_ref}x{n_cur}x{n_bits} thr{thr}")
+    ok, idx = m.NearbyMatch(ref, cur, puv, cuv)
+    note("match/hamming/nearby", np.array_equal(idx, O.nearby_match(ref, cur, puv, cuv, thr, win, win // 2 + 1)[1]), f"{n_ref}x{n_cur}x{n_bits} thr{thr} w{win}")
+    dim = int(rs.choice([3, 32, 100, 128, 256, 320]))
+    fr, fc, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=float(rs.choice([0.1, 0.3, 1.0])), seed=int(rs.randint(1 << 30)), normalize=bool(rs.rand() < 0.5))
+    if n_cur > 4:
+        fc[rs.randint(n_cur)] = fc[rs.randint(n_cur)]
+        if rs.rand() < 0.3:
+            fc[rs.randint(n_cur)] = 0
+    fthr = float(rs.choice([0.0, 0.05, 0.3, 0.6, 2.0]))
+    c = F.CosineMatcher()
+    c.options().kMaxValidDescriptorDistance, c.options().kMaxValidPredictColDistance, c.options().kMaxValidPredictRowDistance = fthr, win, win // 2 + 1
+    with np.errstate(all="ignore"):
+        ok, idx = c.ForceMatch(fr, fc)
+        note("match/cosine/force", np.array_equal(idx, O.match_float(fr, fc, fthr)[1]), f"{n_ref}x{n_cur}x{dim} thr{fthr}")
+        ok, idx = c.NearbyMatch(fr, fc, puv, cuv)
+        note("match/cosine/nearby", np.array_equal(idx, O.match_float(fr, fc, fthr, puv, cuv, win, win // 2 + 1)[1]), f"{n_ref}x{n_cur}x{dim} thr{fthr} w{win}")
+
+
+def direct_round():
+    w, h, levels, rl, cl, t = random_scene()
+    n = int(rs.choice([1, 20, 150, 400]))
+    half = int(rs.randint(1, 8))
+    uv = synth.make_features(n, w, h, seed=int(rs.randint(1 << 30)), margin=min(40.0, w / 8.0), border_fraction=0.05, half=half)
+    fx, fy, cx, cy = float(rs.uniform(200, 700)), float(rs.uniform(200, 700)), w / 2 + float(rs.uniform(-9, 9)), h / 2 + float(rs.uniform(-9, 9))
+    z = rs.uniform(2, 30, n).astype(np.float32)
+    if n > 3:
+        z[rs.randint(n)] = -1.0
+    pts = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], axis=1).astype(np.float32)
+    q0 = np.float32([1, 0, 0, 0]) if rs.rand() < 0.5 else (np.float32([1, *rs.uniform(-0.01, 0.01, 3)]))
+    p0 = np.zeros(3, np.float32) if rs.rand() < 0.5 else rs.uniform(-0.05, 0.05, 3).astype(np.float32)
+    cap = int(rs.choice([n, max(1, n // 2), 500]))
+    dm = F.DirectMethod()
+    o = dm.options()
+    o.kMaxTrackPointsNumber, o.kPatchRowHalfSize, o.kPatchColHalfSize = cap, half, half
+    K = [fx, fy, cx, cy]
+    with np.errstate(all="ignore"):
+        ok, c, q, p, s = dm.TrackFeatures(F.ImagePyramid.from_host_levels(rl), F.ImagePyramid.from_host_levels(cl), K, pts, uv, None, q0, p0)
+        ok2, oc, oq, op, os_, oit = O.direct_track(rl, cl, K, pts, uv, None, q0, p0, half=half, max_points=cap)
+    same = (ok == ok2 and dm.last_iterations == oit and np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and
+            np.array_equal(q.view(np.uint32), oq.view(np.uint32)) and np.array_equal(p.view(np.uint32), op.view(np.uint32)))
+    note("direct", same, f"{w}x{h} L{levels} h{half} n{n} cap{cap}")
+
+
+t_end = time.time() + budget
+rounds = 0
+while time.time() < t_end:
+    klt_round()
+    matcher_round()
+    direct_round()
+    rounds += 1
+bad = 0
+for fam in sorted(stats):
+    n, f, d = stats[fam]
+    bad += f
+    print(f"{fam:24s} cases {n:5d}  mismatches {f}" + (f"   first: {d}" if f else ""))
+print(f"soak: {rounds} rounds in {budget:.0f} s budget, {sum(v[0] for v in stats.values())} comparisons, {bad} mismatches")
+sys.exit(1 if bad else 0)
