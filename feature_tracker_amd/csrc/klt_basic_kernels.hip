@@ -47,6 +47,10 @@ constexpr int kRefQuads = 3;  // ... (next level's reference window)
 
 __host__ __device__ inline int pb_pad4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int pb_producers(int waves) { return waves > 1 ? waves - 1 : 1; }
+// Ring slots: with separate producer and consumer waves the chunk being chained and the chunk being produced
+// coexist (2 slots); a single wave produces and then chains each chunk itself (1 slot, 1.4 KB of LDS saved —
+// LDS, not registers, is what caps the resident features per CU for the one-wave configuration).
+__host__ __device__ inline int pb_ring_slots(int waves) { return waves > 1 ? 2 : 1; }
 
 // LDS carve-up (float4 regions first so that every region keeps its natural alignment).
 struct PbLds {
@@ -67,7 +71,7 @@ __host__ __device__ inline size_t pb_lds_bytes(const KltParams &p, int waves) {
     size_t bytes = 16 * (size_t)(p.pb_cap_r + p.pb_cap_c);
     bytes += 16 * (size_t)(p.patch_rows + p.patch_cols);
     bytes += 16 * (size_t)np * 2 * (p.patch_rows + p.patch_cols);
-    bytes += 4 * (size_t)2 * np * kTerms * kRingRow;
+    bytes += 4 * (size_t)pb_ring_slots(waves) * np * kTerms * kRingRow;
     bytes += 4 * (size_t)pb_pad4(p.pb_cap_r * p.pb_cap_c);
     bytes += 4 * 4 + 4 * 16;
     bytes += 2 * (size_t)2 * pb_pad4(p.pb_rwin_rows * p.pb_rwin_cols);
@@ -84,7 +88,7 @@ __device__ __forceinline__ PbLds pb_carve(float4 *base, const KltParams &p, int 
     c.cidx = c.ridx + p.patch_rows;
     c.ctab = reinterpret_cast<float4 *>(c.cidx + p.patch_cols);
     c.ring = reinterpret_cast<float *>(c.ctab + np * 2 * (p.patch_rows + p.patch_cols));
-    c.lattice = c.ring + 2 * np * kTerms * kRingRow;
+    c.lattice = c.ring + pb_ring_slots(waves) * np * kTerms * kRingRow;
     c.sol = c.lattice + pb_pad4(p.pb_cap_r * p.pb_cap_c);
     c.slots = reinterpret_cast<uint32_t *>(c.sol + 4);
     c.ref_win = reinterpret_cast<uint16_t *>(c.slots + 16);
@@ -292,20 +296,29 @@ __device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltPara
     return ok;
 }
 
-// 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave).
+// 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave), 16 terms per batch in two
+// ping-pong register sets.  The compiler hoists every ds_read of the unrolled chunk to its top if it may (64 VGPRs
+// of terms live at once — the difference between 4 and 5-6 waves per SIMD for this kernel); sched_barrier does not
+// stop that, a data dependency does: the address of batch k + 2 is tied to the accumulator after batch k, so its
+// reads issue exactly when their registers are free, one batch (16 dependent adds) ahead of their use.
+__device__ __forceinline__ int chain_tie(float acc) {
+    int zero = 0;
+    asm volatile("" : "+v"(zero) : "v"(acc));
+    return zero;
+}
+
 __device__ __forceinline__ float chain_chunk(float acc, const float *row) {
+    static_assert(kChainRound == 4 && kChunk == 64, "chain_chunk is written for 4 batches of 16 terms");
     const float4 *t = reinterpret_cast<const float4 *>(row);
     float4 qa[kChainRound], qb[kChainRound];
     chain_load(qa, t);
-#pragma unroll
-    for (int i = 0; i < kChunk / 4; i += 2 * kChainRound) {
-        chain_load(qb, t + i + kChainRound);
-        acc = chain_consume_all(acc, qa);
-        if (i + 2 * kChainRound < kChunk / 4) {
-            chain_load(qa, t + i + 2 * kChainRound);
-        }
-        acc = chain_consume_all(acc, qb);
-    }
+    chain_load(qb, t + kChainRound);
+    acc = chain_consume_all(acc, qa);
+    chain_load(qa, t + 2 * kChainRound + chain_tie(acc));
+    acc = chain_consume_all(acc, qb);
+    chain_load(qb, t + 3 * kChainRound + chain_tie(acc));
+    acc = chain_consume_all(acc, qa);
+    acc = chain_consume_all(acc, qb);
     return acc;
 }
 
@@ -361,6 +374,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     float4 *const my_tab = c.ctab + pw * 2 * (p.patch_rows + p.patch_cols);
     const int n_chunks = (p.P + kChunk - 1) / kChunk;
     const int n_steps = (n_chunks + np - 1) / np;
+    const int ring_mask = pb_ring_slots(b.nwaves) - 1;
 
     // basic_klt.cpp:10,18-19 (pyramid) / :59-86 (single level)
     const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
@@ -408,6 +422,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         }
         const bool cur_async = cur_fits && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols);
         const bool next_async = level > 0 && ref_fits && window_inside(p.ref[level > 0 ? level - 1 : 0], nr_lo, nc_lo, rrows, rcols);
+        // the window loads are issued FIRST (they depend on the footprints only) and fly while the node tables and
+        // the lattice are built: at one wave per feature the level entry is a chain of dependent latencies
+        RawQuads<kCurQuads> qc;
+        RawQuads<kRefQuads> qn;
+        if (cur_async) {
+            issue_quads(qc, b, cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwq);
+        }
+        if (next_async) {
+            issue_quads(qn, b, p.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
+        }
         if (b.wave == 0) {
             // both axes' node tables in one pass of wave 0 (two passes when the patch has more than 64 rows + columns)
             AxisSpec ar = {p.patch_rows, p.half_rows, ref.rows - 1, rw.r_lo, rw.rows - 1, rw.cols, p.pb_cap_r, ref_v, c.rnodes, c.ridx, &c.slots[0]};
@@ -424,15 +448,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         }
         __syncthreads();  // B1: node tables (and this level's reference window) visible
         FTK_STAMP_END(b, 0);
-        // the window loads fly while the lattice is built
-        RawQuads<kCurQuads> qc;
-        RawQuads<kRefQuads> qn;
-        if (cur_async) {
-            issue_quads(qc, b, cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwq);
-        }
-        if (next_async) {
-            issue_quads(qn, b, p.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
-        }
         // ---- lattice: one bilinear per node pair ----
         const int n_r = (int)c.slots[0], n_c = (int)c.slots[1];
         {
@@ -488,7 +503,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (producer) {
                     const int chunk = s * np + pw;
                     if (chunk < n_chunks) {
-                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & 1) * np + pw) * kTerms * kRingRow);
+                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & ring_mask) * np + pw) * kTerms * kRingRow);
                         wave_valid += (uint32_t)__popcll(__ballot(ok));
                     }
                     if (s == n_steps - 1 && b.lane == 0) {
@@ -499,7 +514,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (consumer && b.lane < kTerms) {
                     for (int q = 0; q < np; ++q) {
                         if (s * np + q < n_chunks) {
-                            acc = chain_chunk(acc, c.ring + (((s & 1) * np + q) * kTerms + b.lane) * kRingRow);
+                            acc = chain_chunk(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + b.lane) * kRingRow);
                         }
                     }
                 }
