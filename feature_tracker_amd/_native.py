@@ -27,7 +27,7 @@ EXPORTS = [
     "ftk_abi_version", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
     "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
-    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
+    "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_ldlt6_solve", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
     "ftk_brief_compute", "ftk_brief_compute_device", "ftk_harris_detect", "ftk_harris_response",
 ]
 
@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
     l.ftk_hamming_match_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp, vp]
     l.ftk_cosine_match.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp, C.POINTER(C.c_int)]
     l.ftk_cosine_match_device.argtypes = [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, i32, i32, vp]
+    l.ftk_ldlt6_solve.argtypes = [vp, vp, vp, vp, i32]
     l.ftk_default_direct_options.argtypes = [C.POINTER(DirectOptions)]
     l.ftk_default_direct_options.restype = None
     l.ftk_direct_track.argtypes = [vp, C.POINTER(DirectOptions), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, C.c_int, u32p]

@@ -16,9 +16,9 @@
 //     the 1 x 6 Jacobian row and writes the 27 products of its pixel into a ring slot in LDS;
 //   * wave 0 is the CONSUMER: lane k < 27 adds row k of every chunk in stream order (the exact-order
 //     chain of the KLT kernels, klt_basic_kernels.hip);
-//   * one barrier per round of 7 chunks; after the last round every thread solves the same 6 x 6
-//     system (Eigen-compatible LDLT, klt_common.h) and applies the same pose update, so the pose
-//     lives in registers and needs no further exchange.
+//   * one barrier per round of 7 chunks; after the last round wave 0 solves the 6 x 6 system with
+//     the lane-parallel Eigen-compatible LDLT (klt_common.h: rows on lanes 0..5), publishes dx in
+//     LDS, and every thread applies the same pose update, so the pose lives in registers.
 //
 // Projection of the features (cur_pixel_uv, :141-142) happens once per iteration in a prologue pass
 // and is kept in LDS for the producers; the Jacobian of the pixel w.r.t. the pose (:145-148) depends
@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const bool consumer = wave == 0;
     float *const ring = reinterpret_cast<float *>(dm_lds);                   // [2][kDmProducers][kDmTerms][kDmRow]
-    float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;         // [32]
-    float *const feat = sums + 32;                                           // [n_track][4]: cur u, cur v, usable, -
+    float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;         // [96]: 27 sums | H 6x6 at 32 | dx at 68
+    float *const feat = sums + 96;                                           // [n_track][4]: cur u, cur v, usable, -
     const int n = pr.n;
     const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
     const int P = pp.patch_rows * pp.patch_cols;
@@ -233,30 +233,29 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                         }
                     }
                 }
-                if (consumer && lane < kDmTerms) {
-                    sums[lane] = acc;
+                if (consumer) {
+                    // wave 0: sums -> full symmetric H in LDS -> lane-parallel LDLT (klt_common.h) -> dx in LDS
+                    if (lane < kDmTerms) {
+                        sums[lane] = acc;
+                    }
+                    __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
+                    if (lane < 36) {
+                        const int r0 = lane / 6, c0 = lane - 6 * r0;
+                        const int r = r0 < c0 ? r0 : c0, cc = r0 < c0 ? c0 : r0;
+                        sums[32 + lane] = sums[r * (13 - r) / 2 + (cc - r)];  // upper triangle, row-major
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const Ldlt6 fac = ldlt6_factor(sums + 32, lane);
+                    ldlt6_solve(fac, sums + 21, sums + 68, lane);
                 }
                 __syncthreads();
 
-                // ---- solve and update, redundantly in every thread (:170-181) ----
-                float H[6][6], b[6], dx[6];
-                {
-                    int k = 0;
+                // ---- update, redundantly in every thread (:170-181) ----
+                float dx[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                        for (int c = r; c < 6; ++c) {
-                            H[r][c] = sums[k];
-                            H[c][r] = sums[k];
-                            ++k;
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        b[r] = sums[21 + r];
-                    }
+                for (int k = 0; k < 6; ++k) {
+                    dx[k] = sums[68 + k];
                 }
-                ldlt_solve<6>(H, b, dx);
                 bool has_nan = false;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
@@ -306,7 +305,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
 }  // namespace
 
 size_t direct_lds_bytes(uint32_t max_features) {
-    return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 32 + 4 * (size_t)max_features);
+    return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 96 + 4 * (size_t)max_features);
 }
 
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream) {

@@ -1102,6 +1102,34 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     return FTK_OK;
 }
 
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+
+int ftk_ldlt6_solve(ftk_context *ctx, const float *a, const float *b, float *x, int32_t n) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "ldlt6_solve: null context");
+    }
+    if (n < 0 || (n > 0 && (!a || !b || !x))) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "ldlt6_solve: bad arguments");
+    }
+    if (n == 0) {
+        return FTK_OK;
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t a_bytes = align_up(sizeof(float) * 36 * (size_t)n, 256), b_bytes = align_up(sizeof(float) * 6 * (size_t)n, 256);
+    const int rc = ensure_scratch(ctx, a_bytes + 2 * b_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    float *d_a = reinterpret_cast<float *>(base), *d_b = reinterpret_cast<float *>(base + a_bytes), *d_x = reinterpret_cast<float *>(base + a_bytes + b_bytes);
+    FTK_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(float) * 36 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(d_b, b, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, ftk::ldlt6_launch(d_a, d_b, d_x, n, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(x, d_x, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
 /* ---- direct method ------------------------------------------------------------------------ */
 
 void ftk_default_direct_options(ftk_direct_options *opt) {

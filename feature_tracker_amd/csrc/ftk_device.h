@@ -59,6 +59,8 @@ struct KltParams {
 size_t klt_lds_bytes(int model, int method, const KltParams &p);
 // Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
+// Lane-parallel 6x6 LDLT (klt_common.h) on n systems, one wave each: the test hook behind ftk_ldlt6_solve.
+hipError_t ldlt6_launch(const float *d_a, const float *d_b, float *d_x, int n, hipStream_t stream);
 // Pipelined kernel for (FTK_MODEL_BASIC, FTK_METHOD_INVERSE); klt_launch dispatches to it when p.pb_enabled.
 size_t klt_basic_pipelined_lds_bytes(const KltParams &p);
 hipError_t klt_basic_pipelined_launch(const KltParams &p, hipStream_t stream);

@@ -382,6 +382,131 @@ __device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N]
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 6x6 LDLT, rows spread over lanes (affine trackers, direct method).
+//
+// ldlt_solve<6> above is ~1 000 dependent instructions on one lane per Gauss-Newton iteration — the
+// longest serial stretch of an affine iteration.  Two facts make it parallel without changing a
+// single rounding:
+//   * Eigen's in-place LDLT is LEFT-looking: step k touches column k only, so the diagonal entries
+//     the pivot search looks at are still the ORIGINAL ones (moved by the swaps).  The whole pivot
+//     order can therefore be replayed up front on the six diagonal magnitudes alone, with the same
+//     strict '>' first-maximum rule and the same position swaps.
+//   * with the permutation known, row i of B = P A P^T lives on lane i: column k of L is one
+//     multiply-add sweep over all lanes at once (same products, same left-to-right sums per
+//     element), the divisions of a column happen side by side, and the triangular solves
+//     broadcast one y_j per step.
+// a_lds: 36 floats, row-major, symmetric (bitwise).  All 64 lanes of ONE wave call; lanes 0..5 work.
+// ---------------------------------------------------------------------------------------------
+struct Ldlt6 {
+    float l[6];    // lane i: L(i, j) for j < i (unit diagonal implied), of the permuted matrix
+    float d_mine;  // lane i: D(i)
+    int perm;      // lane i: original index of position i
+};
+
+__device__ __forceinline__ float bcast_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+
+__device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) {
+    // ---- pivot order, replayed on the diagonal (uniform) ----
+    float ad[6];
+    int pos[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        ad[i] = fabsf(a_lds[i * 7]);
+        pos[i] = i;
+    }
+    bool degenerate = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        float biggest = ad[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            if (ad[i] > biggest) {
+                biggest = ad[i];
+                p = i;
+            }
+        }
+        if (k == 0) {
+            // the k == 0 pivot is its (unmodified) diagonal entry: |akk| > 0 fails for an all-zero / NaN diagonal,
+            // and the reference then stops factorising (identity order from here on)
+            degenerate = !(biggest > 0.0f);
+        }
+#pragma unroll
+        for (int q = k + 1; q < 6; ++q) {
+            if (p == q && !(degenerate && k > 0)) {
+                swap_values(ad[k], ad[q]);
+                swap_values(pos[k], pos[q]);
+            }
+        }
+    }
+    // ---- row `lane` of the permuted matrix ----
+    const int me = lane < 6 ? lane : 5;
+    int pi = pos[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        pi = (me == i) ? pos[i] : pi;
+    }
+    float bmat[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        bmat[j] = a_lds[pi * 6 + pos[j]];
+    }
+    Ldlt6 f;
+    f.perm = pi;
+    f.d_mine = 0.0f;
+    float dk[6];  // D(j), uniform
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float m_ik = bmat[k];
+        if (k > 0) {
+            // temp[j] = D(j) * L(k, j); s = sum_j L(i, j) * temp[j], j ascending — the reference's order
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < k; ++j) {
+                const float temp_j = dk[j] * bcast_lane(f.l[j], k);
+                s = (j == 0) ? f.l[0] * temp_j : s + f.l[j] * temp_j;
+            }
+            m_ik = degenerate ? m_ik : m_ik - s;
+        }
+        const float akk = bcast_lane(m_ik, k);
+        dk[k] = akk;
+        f.d_mine = (me == k) ? akk : f.d_mine;
+        const bool pivot_valid = fabsf(akk) > 0.0f;
+        f.l[k] = (pivot_valid && !degenerate) ? m_ik / akk : m_ik;  // meaningful on lanes > k
+    }
+    return f;
+}
+
+__device__ __forceinline__ void ldlt6_solve(const Ldlt6 &f, const float *b_lds, float *x_lds, int lane) {
+    const int me = lane < 6 ? lane : 5;
+    float y = b_lds[f.perm];  // transpositions applied to the right-hand side
+    // forward: y_i -= sum_{j<i} L(i, j) y_j, j ascending
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float yj = bcast_lane(y, j);  // final: lane j committed its sum at the end of step j - 1
+        s = (j == 0) ? f.l[0] * yj : s + f.l[j] * yj;
+        y = (me == j + 1) ? y - s : y;
+    }
+    // D^+: components with |d| <= FLT_MIN become 0
+    y = (fabsf(f.d_mine) > 1.17549435e-38f) ? y / f.d_mine : 0.0f;
+    // backward: y_i -= sum_{j>i} L(j, i) y_j, j ascending; the terms of column i live on lanes j > i
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+        const float term = f.l[i] * y;  // lane j: L(j, i) * y_j
+        float t = bcast_lane(term, i + 1);
+#pragma unroll
+        for (int j = i + 2; j < 6; ++j) {
+            t = t + bcast_lane(term, j);
+        }
+        y = (me == i) ? y - t : y;
+    }
+    if (lane < 6) {
+        x_lds[f.perm] = y;  // transpositions undone
+    }
+}
+
 // Phase B: lane k < K of wave 0 adds terms[k][0..Ppad) strictly left to right and publishes the sum.
 // The adds form one dependent chain (that IS the reference's order); the LDS reads are software
 // pipelined one round (8 x ds_read_b128 = 32 terms) ahead in two ping-pong register sets, pinned

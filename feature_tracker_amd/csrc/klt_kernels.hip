@@ -32,6 +32,10 @@
 //   lssd_klt.cpp:7-250, lssd_klt_fast.cpp:7-229, optical_flow.cpp:49-102.
 #include "ftk_device.h"
 
+// Chain prefetch depth: two ping-pong sets of 4 x ds_read_b128 (16 terms, ~144 cycles of dependent adds) cover the
+// LDS latency; the default of 8 costs 32 more VGPRs in every variant (basic 104 -> 72, lssd fast 111 -> 85, affine
+// inverse 134 -> 122, which then fits 4 waves per SIMD instead of 3).
+#define FTK_CHAIN_ROUND 4
 #include "klt_common.h"
 
 namespace ftk {
@@ -754,15 +758,21 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
         }
         publish_count(b, n_valid, c.wave_cnt, iter);
         chain_then(b, c.terms, A_COUNT, p.Ppad, c.sums, true, [&]() {
+            // H as a full 6x6 in LDS (sums[32..67]), then the lane-parallel LDLT (klt_common.h): rows on lanes 0..5
             float m[6][6];
             affine_fill_matrix(c.sums, m);
-            const float bb[6] = {c.sums[A_B0], c.sums[A_B1], c.sums[A_B2], c.sums[A_B3], c.sums[A_B4], c.sums[A_B5]};
-            float sol[6];
-            ldlt_solve<6>(m, bb, sol);
+            if (b.lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                c.sums[A_COUNT + i] = sol[i];
+                for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        c.sums[32 + i * 6 + j] = m[i][j];
+                    }
+                }
             }
+            __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
+            const Ldlt6 fac = ldlt6_factor(c.sums + 32, b.lane);
+            ldlt6_solve(fac, c.sums + A_B0, c.sums + A_COUNT, b.lane);
         });
         n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
@@ -813,16 +823,30 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
         affine_hessian_terms(p, c.terms, pxi, has_gradient, x, y, dx, dy);
     }
     __syncthreads();
+    // The Hessian is fixed for the level (affine_klt_fast.cpp:71-138), so it is FACTORISED once here — rows on
+    // lanes 0..5 of wave 0 — and every iteration below only runs the two triangular solves (same arithmetic as
+    // factorising each time: the factorisation is a pure function of H).
+    Ldlt6 fac;
+    fac.perm = 0;
+    fac.d_mine = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        fac.l[i] = 0.0f;
+    }
     chain_then(b, c.terms, A_B0, p.Ppad, c.sums, false, [&]() {
         float h[6][6];
-        affine_fill_matrix(c.sums, h);  // the per-level Hessian lives in LDS (sums[32..67]) for the iterations below
+        affine_fill_matrix(c.sums, h);
+        if (b.lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 6; ++i) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                c.sums[32 + i * 6 + j] = h[i][j];
+                for (int j = 0; j < 6; ++j) {
+                    c.sums[32 + i * 6 + j] = h[i][j];
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        fac = ldlt6_factor(c.sums + 32, b.lane);
     });
 
     status = FTK_LARGE_RESIDUAL;
@@ -853,23 +877,7 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
             n_valid += (uint32_t)__popcll(__ballot(ok));
         }
         publish_count(b, n_valid, c.wave_cnt, iter);
-        chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() {
-            float m[6][6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    m[i][j] = c.sums[32 + i * 6 + j];
-                }
-            }
-            const float bb[6] = {c.sums[0], c.sums[1], c.sums[2], c.sums[3], c.sums[4], c.sums[5]};
-            float sol[6];
-            ldlt_solve<6>(m, bb, sol);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                c.sums[A_COUNT + i] = sol[i];
-            }
-        });
+        chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() { ldlt6_solve(fac, c.sums, c.sums + A_COUNT, b.lane); });
         n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
@@ -1207,10 +1215,10 @@ constexpr int kMaxWaves = 4;
 #endif
 #define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU)))
 
-// The non-fast affine variants (6x6 LDLT + 24 chains in registers) do not fit 128 VGPRs without
-// spilling; they run at 3 waves per SIMD instead.
+// The direct affine variant (6x6 LDLT + 24 chains + five current-image taps in registers) does not fit 128 VGPRs
+// without spilling; it runs at 3 waves per SIMD instead.
 template <int MODEL, int METHOD>
-__global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) ? 3 : FTK_WAVES_PER_EU)))
+__global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && METHOD == FTK_METHOD_DIRECT) ? 3 : FTK_WAVES_PER_EU)))
 __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
@@ -1380,6 +1388,38 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p) {
         return 0;
     }
     return (carve_bytes(k, p) + 15) & ~(size_t)15;
+}
+
+namespace {
+// Test hook for the lane-parallel 6x6 LDLT: one wave per system.
+__global__ void __launch_bounds__(kWave) ldlt6_kernel(const float *a, const float *b, float *x, int n) {
+    __shared__ float sa[36], sb[6], sx[6];
+    const int sys = blockIdx.x;
+    if (sys >= n) {
+        return;
+    }
+    if (threadIdx.x < 36) {
+        sa[threadIdx.x] = a[(size_t)sys * 36 + threadIdx.x];
+    }
+    if (threadIdx.x < 6) {
+        sb[threadIdx.x] = b[(size_t)sys * 6 + threadIdx.x];
+    }
+    __syncthreads();
+    const Ldlt6 f = ldlt6_factor(sa, (int)threadIdx.x);
+    ldlt6_solve(f, sb, sx, (int)threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        x[(size_t)sys * 6 + threadIdx.x] = sx[threadIdx.x];
+    }
+}
+}  // namespace
+
+hipError_t ldlt6_launch(const float *a, const float *b, float *x, int n, hipStream_t stream) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(ldlt6_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, a, b, x, n);
+    return hipGetLastError();
 }
 
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream) {

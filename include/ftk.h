@@ -177,6 +177,17 @@ int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
 /* The response map alone (rows*cols floats, host memory; 0 outside the 11-pixel border). */
 int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t level, float *response);
 
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+
+/*
+ * Solves n independent 6x6 systems A x = b with the device's Eigen-compatible pivoted LDLT — the
+ * primitive inside the affine trackers (affine_klt.cpp:103, affine_klt_fast.cpp:39 `H.ldlt().solve(b)`)
+ * and the direct method (direct_method_tracker.cpp:170) — so that tests can compare it with the oracle
+ * on matrices a tracker would rarely produce (ties, zero pivots, NaN).  a: n x 36 row-major symmetric,
+ * b: n x 6, x: n x 6; host buffers.
+ */
+int ftk_ldlt6_solve(ftk_context *ctx, const float *a, const float *b, float *x, int32_t n);
+
 /* ---- direct method ---------------------------------------------- */
 
 /* DirectMethodOptions, src/direct_method_tracker/direct_method_tracker.h:20-28 */
