@@ -1108,6 +1108,60 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         const int max_col = wadd(min_col, p.patch_cols * 2);
         const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
         uint32_t cur_valid_num = 0;
+        if (!p.consider_luminance) {
+            // Without the luminance scaling nothing separates ExtractPatchInCurrentImage from ComputeHessianAndBias but
+            // the "no valid pixel" exits, so one sweep samples a pixel and forms its nine products right away (same
+            // expressions, same values; the patch never makes the round trip through LDS).
+            uint32_t n_valid = 0;
+            for (int base = 0; base < p.P; base += b.nt) {
+                const int pxi = base + b.tid;
+                bool ok_cur = false, ok = false;
+                if (pxi < p.P) {
+                    int prow, pcol;
+                    pixel_rc(p, pxi, prow, pcol);
+                    const float row_i = (float)(prow - p.half_rows) + ref_v;
+                    const float col_i = (float)(pcol - p.half_cols) + ref_u;
+                    float row_j, col_j;
+                    se2_apply(s, col_i, row_i, col_j, row_j);
+                    float value = 0.0f;
+                    if (partly_outside) {
+                        ok_cur = sample(cur, cw, row_j, col_j, value);
+                        if (!ok_cur) {
+                            value = 0.0f;
+                        }
+                    } else {
+                        value = bilinear(cur, cw, row_j, col_j);
+                        ok_cur = true;
+                    }
+                    const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+                    ok = exv[ei] != 0 && ok_cur;
+                    const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
+                    const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
+                    const float dx = dxs[pxi], dy = dys[pxi];
+                    const float j0 = dx * s0 + dy * s1;
+                    const float residual = value - ex[ei];
+                    lssd_terms(p, c.terms, pxi, ok, j0, dx, dy, residual);
+                }
+                cur_valid_num += (uint32_t)__popcll(__ballot(ok_cur));
+                n_valid += (uint32_t)__popcll(__ballot(ok));
+            }
+            // both counts in one exchange: n_valid <= cur_valid_num <= P < 2^16
+            const uint32_t both = block_total(b, (cur_valid_num << 16) | n_valid, c.wave_cnt);
+            if ((both >> 16) == 0 || (both & 0xFFFFu) == 0) {
+                break;  // lssd_klt_fast.cpp:60-63 / :80-83
+            }
+            chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
+            float v[3];
+            const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+            __syncthreads();
+            if (!solved) {
+                break;
+            }
+            if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
+                break;
+            }
+            continue;
+        }
         for (int base = 0; base < p.P; base += b.nt) {
             const int pxi = base + b.tid;
             bool ok = false;

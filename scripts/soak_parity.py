@@ -140,11 +140,15 @@ def direct_round():
 
 t_end = time.time() + budget
 rounds = 0
+t_report = time.time() + 60.0
 while time.time() < t_end:
     klt_round()
     matcher_round()
     direct_round()
     rounds += 1
+    if time.time() > t_report:  # a line a minute: the GPU box takes a silent command for a hung one
+        print(f"soak: {rounds} rounds, {sum(v[0] for v in stats.values())} comparisons, {sum(v[1] for v in stats.values())} mismatches so far", flush=True)
+        t_report = time.time() + 60.0
 bad = 0
 for fam in sorted(stats):
     n, f, d = stats[fam]

@@ -147,3 +147,36 @@ def test_two_rank_gloo_exchange(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {rank} ok" in out
+
+
+def test_python_quaternion_helpers_match_oracle(oracle):
+    """The host-side algebra of DirectMethod's world-frame overload (tracker._quat_*) is the oracle's, bit for bit."""
+    from feature_tracker_amd import tracker as T
+    rs = np.random.RandomState(5)
+    for _ in range(200):
+        a = rs.standard_normal(4).astype(np.float32)
+        b = rs.standard_normal(4).astype(np.float32)
+        v = (rs.standard_normal(3) * 10).astype(np.float32)
+        assert np.array_equal(T._quat_mul(a, b).view(np.uint32), oracle.quat_mul(a, b).view(np.uint32))
+        assert np.array_equal(T._quat_rotate(a, v).view(np.uint32), oracle.quat_rotate(a, v).view(np.uint32))
+        assert np.array_equal(T._quat_inverse(a).view(np.uint32), oracle.quat_inverse(a).view(np.uint32))
+    assert np.array_equal(T._quat_inverse(np.zeros(4, np.float32)), np.zeros(4, np.float32))
+
+
+def test_direct_method_early_returns_need_no_device(ftk):
+    dm = ftk.DirectMethod()
+    assert dm.options().kMaxConvergeStep == 1e-6 and dm.options().kMethod == "direct" and dm.options().kMaxTrackPointsNumber == 500
+
+    class FakePyramid:  # level() is all the early returns look at
+        def __init__(self, n):
+            self._n = n
+
+        def level(self):
+            return self._n
+    ok, *_ = dm.TrackFeatures(FakePyramid(3), FakePyramid(3), [1, 1, 0, 0], np.zeros((0, 3)), np.zeros((0, 2), np.float32))
+    assert ok is False  # direct_method_tracker.cpp:38
+    ok, *_ = dm.TrackFeatures(FakePyramid(3), FakePyramid(4), [1, 1, 0, 0], np.zeros((2, 3)), np.zeros((2, 2), np.float32))
+    assert ok is False  # :39
+    m = ftk.CosineMatcher()
+    ok, _ = m.ForceMatch(np.zeros((3, 8), np.float32), np.zeros((0, 8), np.float32))
+    assert ok is False  # descriptor_matcher.h:58
