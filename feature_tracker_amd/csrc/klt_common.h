@@ -407,36 +407,57 @@ struct Ldlt6 {
 __device__ __forceinline__ float bcast_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
 __device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) {
-    // ---- pivot order, replayed on the diagonal (uniform) ----
-    float ad[6];
-    int pos[6];
+    // ---- pivot order, replayed on the diagonal ----
+    // Distinct, non-NaN magnitudes (the normal case): selection with swaps is then simply the descending order,
+    // and lane i finds its own position as the number of larger magnitudes — six broadcasts instead of a serial
+    // selection sort.  Ties, NaN or an all-zero diagonal take the literal replay (first maximum, position swaps).
+    const int me0 = lane < 6 ? lane : 5;
+    const float my_ad = fabsf(a_lds[me0 * 7]);
+    int rank = 0, equal = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        ad[i] = fabsf(a_lds[i * 7]);
-        pos[i] = i;
+    for (int j = 0; j < 6; ++j) {
+        const float aj = bcast_lane(my_ad, j);
+        rank += (aj > my_ad) ? 1 : 0;
+        equal += (aj == my_ad) ? 1 : 0;
     }
+    const bool irregular = __ballot(lane < 6 && (equal != 1)) != 0ull;  // equal == 0: NaN; > 1: a tie
+    int pos[6];
     bool degenerate = false;
+    if (!irregular) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        int p = k;
-        float biggest = ad[k];
+        for (int k = 0; k < 6; ++k) {
+            pos[k] = (int)__ffsll((long long)__ballot(lane < 6 && rank == k)) - 1;
+        }
+        // the largest magnitude is positive here (six distinct non-negative numbers), so the first pivot is valid
+    } else {
+        float ad[6];
 #pragma unroll
-        for (int i = k + 1; i < 6; ++i) {
-            if (ad[i] > biggest) {
-                biggest = ad[i];
-                p = i;
+        for (int i = 0; i < 6; ++i) {
+            ad[i] = fabsf(a_lds[i * 7]);
+            pos[i] = i;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int p = k;
+            float biggest = ad[k];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) {
+                if (ad[i] > biggest) {
+                    biggest = ad[i];
+                    p = i;
+                }
             }
-        }
-        if (k == 0) {
-            // the k == 0 pivot is its (unmodified) diagonal entry: |akk| > 0 fails for an all-zero / NaN diagonal,
-            // and the reference then stops factorising (identity order from here on)
-            degenerate = !(biggest > 0.0f);
-        }
+            if (k == 0) {
+                // the k == 0 pivot is its (unmodified) diagonal entry: |akk| > 0 fails for an all-zero / NaN diagonal,
+                // and the reference then stops factorising (identity order from here on)
+                degenerate = !(biggest > 0.0f);
+            }
 #pragma unroll
-        for (int q = k + 1; q < 6; ++q) {
-            if (p == q && !(degenerate && k > 0)) {
-                swap_values(ad[k], ad[q]);
-                swap_values(pos[k], pos[q]);
+            for (int q = k + 1; q < 6; ++q) {
+                if (p == q && !(degenerate && k > 0)) {
+                    swap_values(ad[k], ad[q]);
+                    swap_values(pos[k], pos[q]);
+                }
             }
         }
     }
