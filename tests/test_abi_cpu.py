@@ -85,3 +85,19 @@ def test_cpp_host_layer_builds_and_fails_loudly_without_gpu(tmp_path):
     out = subprocess.run([exe, "basic", "2", "2", "4", "4", str(tmp_path / "ref.pgm"), str(tmp_path / "cur.pgm"), str(tmp_path / "f.txt")],
                          capture_output=True, text=True)
     assert out.returncode == 1 and "ok 0" in out.stdout and "no CPU fallback" in (out.stdout + out.stderr)
+
+
+def test_cmake_project_configures(tmp_path):
+    """CMakeLists.txt (the reference's target names) configures; the full build is exercised by hand / by maintainers."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None:
+        import pytest
+        pytest.skip("cmake not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    res = subprocess.run(["cmake", "-S", root, "-B", str(tmp_path / "b")] + gen, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    text = open(os.path.join(root, "CMakeLists.txt")).read()
+    for target in ("lib_optical_flow_tracker", "lib_descriptor_matcher", "lib_direct_method_tracker", "test_optical_flow", "test_direct_method"):
+        assert target in text
