@@ -264,8 +264,19 @@ def main():
             if int(agree.item()) == 0:
                 graph = None
             if graph is not None:
-                graph.replay()  # one untimed replay: first-use initialisation of the instantiated graph
+                # one untimed replay (first-use initialisation of the instantiated graph) under a watchdog: collectives
+                # inside a graph that never complete would otherwise hold the node until the caller's own timeout
+                import threading
+
+                def _abort():
+                    print("bench.py: the graph replay did not finish within 180 s; aborting this rank", file=sys.stderr, flush=True)
+                    os._exit(3)
+                guard = threading.Timer(180.0, _abort)
+                guard.daemon = True
+                guard.start()
+                graph.replay()
                 torch.cuda.synchronize()
+                guard.cancel()
 
         if use_dist:
             dist.barrier()
