@@ -180,3 +180,19 @@ def test_direct_method_early_returns_need_no_device(ftk):
     m = ftk.CosineMatcher()
     ok, _ = m.ForceMatch(np.zeros((3, 8), np.float32), np.zeros((0, 8), np.float32))
     assert ok is False  # descriptor_matcher.h:58
+
+
+def test_argument_errors_are_raised_before_any_device_call(ftk):
+    import pytest
+
+    class FakePyramid:
+        def level(self):
+            return 2
+    m = ftk.CosineMatcher()
+    with pytest.raises(ValueError):
+        m.ForceMatch(np.zeros((3, 8), np.float32), np.zeros((4, 16), np.float32))  # descriptor lengths differ
+    dm = ftk.DirectMethod()
+    with pytest.raises(ValueError):
+        dm.TrackFeatures(FakePyramid(), FakePyramid(), [1, 1, 0, 0], np.zeros((2, 3), np.float32), np.zeros((5, 2), np.float32))  # fewer points than features
+    ok, idx = ftk.CosineMatcher().NearbyMatch(np.zeros((3, 8), np.float32), np.zeros((2, 8), np.float32), np.zeros((2, 2)), np.zeros((2, 2)))
+    assert ok is False  # descriptor_matcher.h:95 — pred size != ref size
