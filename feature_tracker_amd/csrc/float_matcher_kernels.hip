@@ -304,15 +304,33 @@ __global__ void __launch_bounds__(256) cosine_gemm_kernel(const CosineParams p) 
 // cur chunks of 256 rows x 64 K through a double-buffered LDS tile with the global loads issued
 // TWO chunks ahead (two named register sets), and pays one barrier per chunk.  Wave (wm, wn) of
 // the 4 x 2 grid computes 64 cur x 64 ref = 2 x 2 MFMA tiles; the epilogue is unchanged.
+//
+// kMode 0 / 1 are steps 2 / 3 of the header (row maximum, then collection against it).  kMode 2 does
+// both in ONE walk: the workgroup keeps a running maximum per ref row in LDS (sMax) and collects every
+// pair within 2 * margin of the maximum seen SO FAR — a superset of the final list, because the running
+// maximum never exceeds the final one.  The first cur tile only feeds sMax and is walked a second time at
+// the end, so collection never starts from an empty bound; after that a row adds entries only when a
+// tile raises (or comes within the margin of) its maximum, ~ln(tiles) times per workgroup for any
+// exchangeable order of the cur rows.  Each entry carries its approximate score; the recheck kernel
+// drops those below the final row maximum - 2 * margin, so the exact work is that of the two-pass path.
+// A row whose list overflows takes the exact scan, as before.
+// Entries are staged in LDS (sStage: one ds_add for the slot, ~100 cycles) and appended to the per-row global lists
+// after the walk, all at once: a returning global atomic per entry, waited for inside the epilogue, costs ~1.5 us each
+// and a wave meets ~50 entries per walk — measured, that alone made the single walk slower than the two launches.
 constexpr int kCurTile = 256;
+constexpr int kStageCap = 1024;  // entries {ref row in the tile, cur row, score}; beyond it an entry goes to global directly
 
-template <bool kCollect, bool kNearby>
+template <int kMode, bool kNearby>
 __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams p) {
+    constexpr bool kCollect = kMode == 1, kSingle = kMode == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
     const int pitch_y = p.dim_pad + 8;                                         // halfs
     _Float16 *const sY = reinterpret_cast<_Float16 *>(rs_lds);                 // [128][pitch_y]
     _Float16 *const sX = sY + kTile * pitch_y;                                 // [2][256][kPitch]
     float4 *const sInfo = reinterpret_cast<float4 *>(sX + 2 * kCurTile * kPitch);  // [2][256]: {bias, u, v, -}
+    uint32_t *const sMax = reinterpret_cast<uint32_t *>(sInfo + 2 * kCurTile);     // [128] running row maxima (kMode 2)
+    uint32_t *const sStageCount = sMax + kTile;                                    // [4], first word used
+    uint32_t *const sStage = sStageCount + 4;                                      // [kStageCap][3]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -324,7 +342,15 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
         return;
     }
     const int n_chunks = p.dim_pad / kChunkK;
-    const int total_chunks = (jt_end - jt_begin) * n_chunks;
+    const int n_tiles = jt_end - jt_begin;
+    const int n_steps = kSingle ? n_tiles + 1 : n_tiles;  // kMode 2: tile 0 once more at the end
+    const int total_chunks = n_steps * n_chunks;
+    if (kSingle && tid < kTile) {
+        sMax[tid] = 0u;  // key 0 = nothing seen (visible after the first barrier of the walk)
+        if (tid == 0) {
+            sStageCount[0] = 0u;
+        }
+    }
     const float pos_inf = __uint_as_float(0x7F800000u), neg_inf = __uint_as_float(0xFF800000u);
 
     int row_i[2];
@@ -358,8 +384,13 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
     // cur chunk staging: thread t carries 64 B (32 halfs) of row t / 2
     const int srow = tid >> 1, scol = (tid & 1) * 32;
     const _Float16 *const gx_base = p.cur_h + (size_t)srow * p.dim_pad + scol;
+    // chunk index -> (tile, K chunk) without a runtime division (n_chunks = dim_pad / 64 <= 4; c < 2^16):
+    // ceil(2^16 / d) is exact for these ranges
+    const unsigned div_magic = (65536u + (unsigned)n_chunks - 1u) / (unsigned)n_chunks;
+    auto tile_of = [&](int c) { return (int)(((unsigned)c * div_magic) >> 16); };
     auto chunk_src = [&](int c) {
-        const int jt = jt_begin + c / n_chunks, kc = c - (c / n_chunks) * n_chunks;
+        const int t_ = tile_of(c);
+        const int jt = jt_begin + ((kSingle && t_ == n_tiles) ? 0 : t_), kc = c - t_ * n_chunks;
         return reinterpret_cast<const uint4 *>(gx_base + (size_t)jt * kCurTile * p.dim_pad + kc * kChunkK);
     };
     // two named register sets (an aggregate passed by reference into a lambda ends up in scratch memory)
@@ -380,9 +411,9 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
         d_[2] = C;                                                                                           \
         d_[3] = D;                                                                                           \
     } while (0)
-    auto write_info = [&](int tile_index) {  // per-candidate data of cur tile jt_begin + tile_index
+    auto write_info = [&](int tile_index) {  // per-candidate data of the cur tile walked at step tile_index
         if (tid < kCurTile) {
-            const int j = (jt_begin + tile_index) * kCurTile + tid;
+            const int j = (jt_begin + ((kSingle && tile_index == n_tiles) ? 0 : tile_index)) * kCurTile + tid;
             float4 info = make_float4(p.cur_bias[j], 0.0f, 0.0f, 0.0f);
             if (kNearby && j < p.n_cur) {
                 info.y = p.cur_uv[2 * j];
@@ -421,30 +452,43 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
     // one pipeline step: chunk c is in LDS buffer c & 1; the set named at the call site holds chunk c + 1 and is
     // refilled with chunk c + 3 (FTK_RS_STEP below); `compute` is the part that touches no staging register
     auto compute = [&](int c) {
-        const int tile_index = c / n_chunks, kc = c - tile_index * n_chunks;
-        if (kc == 0 && jt_begin + tile_index + 1 < jt_end) {
+        const int tile_index = tile_of(c), kc = c - tile_index * n_chunks;
+        if (kc == 0 && tile_index + 1 < n_steps) {
             write_info(tile_index + 1);
         }
         const _Float16 *bx = sX + ((c & 1) * kCurTile) * kPitch;
+        // fragments of K-step kk + 1 are read while the four MFMAs of step kk run (two register sets; the compiler
+        // otherwise re-reads into the same registers right before each use and exposes the LDS latency four times a chunk)
+        const _Float16 *ax0 = &bx[(wm * 64 + (lane & 31)) * kPitch + 8 * (lane >> 5)];
+        const _Float16 *by0 = &sY[(wn * 64 + (lane & 31)) * pitch_y + kc * kChunkK + 8 * (lane >> 5)];
+        half8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[0][t] = *reinterpret_cast<const half8 *>(ax0 + t * 32 * kPitch);
+            fb[0][t] = *reinterpret_cast<const half8 *>(by0 + t * 32 * pitch_y);
+        }
 #pragma unroll
         for (int kk = 0; kk < kChunkK / 16; ++kk) {
-            half8 a[2], b[2];
+            const int cur_set = kk & 1, nxt_set = cur_set ^ 1;
+            if (kk + 1 < kChunkK / 16) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *reinterpret_cast<const half8 *>(&bx[(wm * 64 + t * 32 + (lane & 31)) * kPitch + kk * 16 + 8 * (lane >> 5)]);
-                b[t] = *reinterpret_cast<const half8 *>(&sY[(wn * 64 + t * 32 + (lane & 31)) * pitch_y + kc * kChunkK + kk * 16 + 8 * (lane >> 5)]);
+                for (int t = 0; t < 2; ++t) {
+                    fa[nxt_set][t] = *reinterpret_cast<const half8 *>(ax0 + t * 32 * kPitch + (kk + 1) * 16);
+                    fb[nxt_set][t] = *reinterpret_cast<const half8 *>(by0 + t * 32 * pitch_y + (kk + 1) * 16);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs: the scheduler sinks them otherwise
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_set][mt], fb[cur_set][nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
         if (kc == n_chunks - 1) {
             // epilogue of this cur tile: C/D map of the 32x32 MFMA — col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-            const int j0 = (jt_begin + tile_index) * kCurTile;
+            const int j0 = (jt_begin + ((kSingle && tile_index == n_tiles) ? 0 : tile_index)) * kCurTile;
             const float4 *info_tile = sInfo + (tile_index & 1) * kCurTile;
             // straight-line pass: bias, window, running maximum (per tile in collect mode, per launch otherwise)
             float tile_best[2] = {neg_inf, neg_inf};
@@ -461,14 +505,52 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
                             const bool out = (int)(fabsf(pu[nt] - info.y) > p.max_col) | (int)(fabsf(pv[nt] - info.z) > p.max_row);
                             v = out ? neg_inf : v;
                         }
-                        if (kCollect) {
+                        if (kCollect || kSingle) {
                             acc[mt][nt][r] = v;  // kept for the (rare) second look below
                         }
                         tile_best[nt] = fmaxf(tile_best[nt], v);
                     }
                 }
             }
-            if (!kCollect) {
+            if (kSingle) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int slot_row = wn * 64 + nt * 32 + (lane & 31);
+                    const float mine = live[nt] ? tile_best[nt] : neg_inf;  // padding / irregular rows collect nothing
+                    if (tile_index > 0 && mine > neg_inf) {
+                        // bound = maximum over the tiles before this one (all waves, published before the last barrier)
+                        // joined with this lane's share of the current tile
+                        const uint32_t seen = sMax[slot_row];
+                        const float bound = fmaxf(seen ? order_value(seen) : neg_inf, mine) - 2.0f * kMargin;
+                        if (mine >= bound) {
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    if (acc[mt][nt][r] >= bound) {
+                                        const int jl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                        const uint32_t at = atomicAdd(&sStageCount[0], 1u);
+                                        if (at < (uint32_t)kStageCap) {
+                                            sStage[3 * at] = (uint32_t)slot_row;
+                                            sStage[3 * at + 1] = (uint32_t)(j0 + jl);
+                                            sStage[3 * at + 2] = __float_as_uint(acc[mt][nt][r]);
+                                        } else {
+                                            const uint32_t slot = atomicAdd(&p.cand_count[row_i[nt]], 1u);
+                                            if (slot < (uint32_t)kCosineCandCap) {
+                                                p.cand[(size_t)row_i[nt] * kCosineCandCap + slot] = j0 + jl;
+                                                p.cand_score[(size_t)row_i[nt] * kCosineCandCap + slot] = acc[mt][nt][r];
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (tile_index < n_tiles && mine > neg_inf) {
+                        atomicMax(&sMax[slot_row], order_key(mine));
+                    }
+                }
+            } else if (!kCollect) {
                 best[0] = fmaxf(best[0], tile_best[0]);
                 best[1] = fmaxf(best[1], tile_best[1]);
             } else {
@@ -516,7 +598,25 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
 #undef FTK_RS_STEP
 #undef FTK_RS_LOAD
 #undef FTK_RS_STORE
-    if (!kCollect) {
+    if (kSingle) {
+        __syncthreads();
+        if (tid < kTile) {
+            const int i = i0 + tid;
+            const uint32_t key = sMax[tid];
+            if (key != 0u && i < p.n_ref) {
+                atomicMax(&p.row_max[i], key);
+            }
+        }
+        const uint32_t staged = min(sStageCount[0], (uint32_t)kStageCap);
+        for (uint32_t e = (uint32_t)tid; e < staged; e += 512u) {
+            const int i = i0 + (int)sStage[3 * e];
+            const uint32_t slot = atomicAdd(&p.cand_count[i], 1u);
+            if (slot < (uint32_t)kCosineCandCap) {
+                p.cand[(size_t)i * kCosineCandCap + slot] = (int32_t)sStage[3 * e + 1];
+                p.cand_score[(size_t)i * kCosineCandCap + slot] = __uint_as_float(sStage[3 * e + 2]);
+            }
+        }
+    } else if (!kCollect) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const float other = __shfl_xor(best[nt], 32);
@@ -541,27 +641,51 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
     const uint32_t n_irr = *p.irregular_count;
     const uint32_t cnt = p.cand_count[row];
     const bool scan_all = p.ref_irregular[row] != 0 || cnt > (uint32_t)kCosineCandCap || n_irr > (uint32_t)kCosineIrregularCap;
-    const int n_list = scan_all ? p.n_cur : (int)(cnt + n_irr);
+    // single-walk lists were cut against the running maximum: keep what the final maximum admits
+    const uint32_t max_key = p.cand_score ? p.row_max[row] : 0u;
+    const float admit = max_key ? order_value(max_key) - 2.0f * kMargin : __uint_as_float(0xFF800000u);
     const float pu = nearby ? p.pred_uv[2 * row] : 0.0f, pv = nearby ? p.pred_uv[2 * row + 1] : 0.0f;
     float best_d = __uint_as_float(0x7F800000u);
     int best_j = -1;
-    for (int t = 0; t < n_list; ++t) {
-        int j;
-        if (scan_all) {
-            j = t;
-        } else if (t < (int)cnt) {
-            j = p.cand[(size_t)row * kCosineCandCap + t];
-        } else {
-            j = p.irregular_list[t - (int)cnt];
-        }
-        if (nearby && (fabsf(pu - p.cur_uv[2 * j]) > p.max_col || fabsf(pv - p.cur_uv[2 * j + 1]) > p.max_row)) {
-            continue;
-        }
+    auto consider = [&](int j) {  // whole octet, same j
         const float dot = eigen_dot_octet(x, p.cur + (size_t)j * p.dim, p.dim, c, base);
         const float d = 0.5f - dot / na / p.cur_norm[j] * 0.5f;
         if (d < best_d || (d == best_d && j < best_j)) {
             best_d = d;
             best_j = j;
+        }
+    };
+    auto outside = [&](int j) { return nearby && (fabsf(pu - p.cur_uv[2 * j]) > p.max_col || fabsf(pv - p.cur_uv[2 * j + 1]) > p.max_row); };
+    if (scan_all) {
+        for (int j = 0; j < p.n_cur; ++j) {
+            if (!outside(j)) {
+                consider(j);
+            }
+        }
+    } else {
+        // eight list entries per round, one per lane: the filters (score, window) run in parallel and only the survivors —
+        // one or two per row — cost an exact distance; a serial walk pays the load latency once per entry instead
+        const int n_cand = (int)cnt, n_all = (int)(cnt + n_irr);
+        for (int t0 = 0; t0 < n_all; t0 += 8) {
+            const int t = t0 + c;
+            int j = -1;
+            if (t < n_cand) {
+                j = p.cand[(size_t)row * kCosineCandCap + t];
+                if (p.cand_score && p.cand_score[(size_t)row * kCosineCandCap + t] < admit) {
+                    j = -1;
+                }
+            } else if (t < n_all) {
+                j = p.irregular_list[t - n_cand];
+            }
+            if (j >= 0 && outside(j)) {
+                j = -1;
+            }
+            unsigned live_mask = (unsigned)((__ballot(j >= 0) >> base) & 0xFFull);
+            while (live_mask) {
+                const int k = __ffs(live_mask) - 1;
+                live_mask &= live_mask - 1u;
+                consider(__shfl(j, base + k));
+            }
         }
     }
     // strict '<' against a running minimum that starts at the threshold (descriptor_matcher.h:68-75, :114-117)
@@ -573,7 +697,8 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
 }  // namespace
 
 size_t cosine_rs_lds_bytes(int dim_pad) {
-    return sizeof(_Float16) * ((size_t)kTile * (dim_pad + 8) + (size_t)2 * kCurTile * kPitch) + sizeof(float4) * 2 * kCurTile;
+    return sizeof(_Float16) * ((size_t)kTile * (dim_pad + 8) + (size_t)2 * kCurTile * kPitch) + sizeof(float4) * 2 * kCurTile +
+           sizeof(uint32_t) * (kTile + 4 + 3 * kStageCap);
 }
 
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
@@ -595,21 +720,27 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
         const int splits = (tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
         const dim3 grid((unsigned)row_tiles, (unsigned)splits);
         const size_t lds = cosine_rs_lds_bytes(p.dim_pad);
-#define FTK_RS_LAUNCH(COLLECT, NEARBY)                                                                                            \
+#define FTK_RS_LAUNCH(MODE, NEARBY)                                                                                               \
     do {                                                                                                                            \
-        auto kern = cosine_gemm_rs_kernel<COLLECT, NEARBY>;                                                                         \
+        auto kern = cosine_gemm_rs_kernel<MODE, NEARBY>;                                                                            \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         if (e != hipSuccess) {                                                                                                      \
             return e;                                                                                                               \
         }                                                                                                                           \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);                                                                  \
     } while (0)
-        if (p.pred_uv) {
-            FTK_RS_LAUNCH(false, true);
-            FTK_RS_LAUNCH(true, true);
+        if (p.cand_score) {  // single walk
+            if (p.pred_uv) {
+                FTK_RS_LAUNCH(2, true);
+            } else {
+                FTK_RS_LAUNCH(2, false);
+            }
+        } else if (p.pred_uv) {
+            FTK_RS_LAUNCH(0, true);
+            FTK_RS_LAUNCH(1, true);
         } else {
-            FTK_RS_LAUNCH(false, false);
-            FTK_RS_LAUNCH(true, false);
+            FTK_RS_LAUNCH(0, false);
+            FTK_RS_LAUNCH(1, false);
         }
 #undef FTK_RS_LAUNCH
     } else {

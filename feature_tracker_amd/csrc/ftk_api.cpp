@@ -1378,6 +1378,10 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     const size_t o_irr_cnt = carve(sizeof(uint32_t));
     const size_t o_clear_end = off;
     const size_t o_cand = carve(sizeof(int32_t) * (size_t)p.n_ref_pad * ftk::kCosineCandCap);
+    // ref-stationary mode walks cur ONCE (running row maximum + scored candidate lists); FTK_COSINE_TWO_PASS=1 keeps the
+    // maximum-then-collect pair of launches for comparison
+    const bool single_walk = p.ref_stationary && !(getenv("FTK_COSINE_TWO_PASS") && atoi(getenv("FTK_COSINE_TWO_PASS")) == 1);
+    const size_t o_cand_score = single_walk ? carve(sizeof(float) * (size_t)p.n_ref_pad * ftk::kCosineCandCap) : 0;
     const size_t o_irr_list = carve(sizeof(int32_t) * ftk::kCosineIrregularCap);
     const int rc = ensure_cosine_ws(ctx, off);
     if (rc != FTK_OK) {
@@ -1393,6 +1397,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.row_max = reinterpret_cast<uint32_t *>(ws + o_row_max);
     p.cand_count = reinterpret_cast<uint32_t *>(ws + o_cnt);
     p.cand = reinterpret_cast<int32_t *>(ws + o_cand);
+    p.cand_score = single_walk ? reinterpret_cast<float *>(ws + o_cand_score) : nullptr;
     p.irregular_count = reinterpret_cast<uint32_t *>(ws + o_irr_cnt);
     p.irregular_list = reinterpret_cast<int32_t *>(ws + o_irr_list);
     p.clear_begin = ws + o_row_max;

@@ -94,6 +94,7 @@ struct CosineParams {
     uint8_t *ref_irregular;
     uint32_t *row_max, *cand_count;
     int32_t *cand;            // [n_ref_pad][kCosineCandCap]
+    float *cand_score;        // approximate score of each entry; non-null selects the single-walk contraction (ref-stationary only)
     uint32_t *irregular_count;
     int32_t *irregular_list;  // [kCosineIrregularCap]
     void *clear_begin;        // row_max | cand_count | irregular_count, contiguous: zeroed by one memset per call

@@ -13,13 +13,13 @@ for grp in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/$name" -- python3 $ROOT/scripts/bench_configs.py --only cosine --quick > "$OUT/${name}.log" 2>&1 || echo "failed: $grp" >> "$OUT/errors.log"
 done
 python3 - "$OUT" <<'PY'
-import csv,glob,sys,statistics,collections
+import csv,glob,sys,statistics,collections,re
 vals=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1]+'/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name']
-        if 'cosine' in k or 'hamming' in k: vals[k.split('(')[0][-60:]+' grid='+r['Grid_Size']][r['Counter_Name']].append(float(r['Counter_Value']))
+        m=re.search(r'((cosine|hamming)_\w+(<[^>]*>)?)', r['Kernel_Name'])
+        if m: vals[m.group(1)+' grid='+r['Grid_Size']][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(vals):
     print(k)
-    for c,v in sorted(vals[k].items()): print(f"    {c:28s} median {statistics.median(v):16.0f}  n={len(v)}")
+    for c,v in sorted(vals[k].items()): print(f"    {c:28s} median {statistics.median(v):14.0f} min {min(v):14.0f} max {max(v):14.0f} n={len(v)}")
 PY

@@ -152,3 +152,45 @@ def test_full_size_properties(ftk):
     shuffle = rs.permutation(n)
     ok, idx2 = matcher(ftk, 0.1).ForceMatch(ref, cur[shuffle])
     assert np.array_equal(shuffle[idx2[idx2 >= 0]], idx[idx >= 0])
+
+
+@pytest.mark.parametrize("env", [{}, {"FTK_COSINE_TWO_PASS": "1"}, {"FTK_COSINE_CHUNKED": "1"}, {"FTK_COSINE_SPLITS": "1"}, {"FTK_COSINE_SPLITS": "5"}])
+def test_contraction_variants_agree_with_oracle(ftk, oracle, monkeypatch, env):
+    """The shortlist has three implementations behind one decision rule (single walk with a running row maximum,
+    maximum-then-collect, chunked for long descriptors) and a split count chosen from the grid size: each of them,
+    at forced split counts, must give the oracle's indices — force and nearby, ragged sizes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rs = np.random.RandomState(21)
+    for n_ref, n_cur, dim in ((700, 2100, 256), (260, 1500, 128), (130, 513, 200)):
+        ref, cur, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=0.25)
+        _, g = matcher(ftk, 0.4).ForceMatch(ref, cur)
+        _, c = oracle.match_float(ref, cur, 0.4)
+        assert np.array_equal(g, c), (env, n_ref, n_cur, dim)
+        cur_uv = rs.uniform(0, 400, size=(n_cur, 2)).astype(np.float32)
+        pred_uv = rs.uniform(0, 400, size=(n_ref, 2)).astype(np.float32)
+        m = matcher(ftk, 0.9, col=60, row=45)
+        _, g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+        _, c = oracle.match_float(ref, cur, 0.9, pred_uv, cur_uv, max_col=60, max_row=45)
+        assert np.array_equal(g, c), (env, "nearby", n_ref, n_cur, dim)
+
+
+def test_candidates_in_ascending_order_of_similarity(ftk, oracle):
+    """Worst case for the running row maximum: every later cur row beats all earlier ones for one ref row, so the single
+    walk collects an entry per tile until the list overflows and the row takes the exact scan.  Other rows see the
+    same cur rows in an unrelated order.  Results must not depend on any of it."""
+    rs = np.random.RandomState(3)
+    dim, n_cur = 256, 4096
+    base = rs.standard_normal(dim).astype(np.float32)
+    base /= np.linalg.norm(base)
+    noise = rs.standard_normal((n_cur, dim)).astype(np.float32)
+    noise /= np.linalg.norm(noise, axis=1, keepdims=True)
+    w = np.linspace(0.0, 0.98, n_cur, dtype=np.float32)[:, None]  # similarity to `base` grows with j
+    cur = (w * base[None, :] + (1.0 - w) * noise).astype(np.float32)
+    ref = rs.standard_normal((300, dim)).astype(np.float32)
+    ref[:40] = base[None, :] + 0.01 * rs.standard_normal((40, dim)).astype(np.float32)
+    for thr in (0.5, 1.0):
+        _, g = matcher(ftk, thr).ForceMatch(ref, cur)
+        _, c = oracle.match_float(ref, cur, thr)
+        assert np.array_equal(g, c)
+    assert (c[:40] > n_cur // 2).all()
