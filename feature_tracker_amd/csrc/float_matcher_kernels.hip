@@ -116,7 +116,13 @@ __global__ void __launch_bounds__(256) cosine_prep_kernel(const CosineParams p) 
     }
     if (c == 0) {
         if (which) {
-            p.cur_bias[row] = regular ? 0.0f : __uint_as_float(0xFF800000u);  // -inf keeps the column out of every maximum
+            const float bias = regular ? 0.0f : __uint_as_float(0xFF800000u);  // -inf keeps the column out of every maximum
+            p.cur_bias[row] = bias;
+            if (p.cur_info) {
+                const bool windowed = p.pred_uv != nullptr && row < n;
+                // finite "never": cosine_gemm_rr_kernel writes index bits into the score and -inf would turn into a NaN
+                p.cur_info[row] = make_float4(regular ? 0.0f : -3.0e38f, windowed ? p.cur_uv[2 * row] : 0.0f, windowed ? p.cur_uv[2 * row + 1] : 0.0f, 0.0f);
+            }
             if (row < n) {
                 p.cur_norm[row] = norm;
                 if (!regular) {
@@ -628,6 +634,334 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
     }
 }
 
+// ---- 2 + 3 (dim_pad <= 256), register-stationary: the ref fragments never leave the register file ----------
+// rocprofv3 on the LDS-stationary kernel above (10 000^2 x 256, single walk): ~93 us, MFMA busy ~30 %.  Every wave
+// reads one 1 KB fragment from LDS per MFMA (2 cur + 2 ref fragments for 2 x 2 tiles), which alone fills the LDS
+// pipe at the MFMA peak rate, and every workgroup streams the whole cur slice through L2 -> LDS for only 128 ref rows.
+// Here each of the 8 waves keeps ITS 64 ref rows for the whole K as MFMA B operands in registers (2 x dim_pad / 16
+// fragments = 128 VGPRs at dim 256, loaded once), so a workgroup covers 512 ref rows; cur tiles of 64 rows x whole K
+// stream through a double-buffered LDS tile that ALL waves read (2 fragment reads per 4 MFMAs — half the LDS traffic
+// per flop, a quarter of the L2 -> LDS traffic per pair).  A ref row belongs to exactly one wave, so the running row
+// maximum of the single walk is a register (exact, no cross-wave staleness).  Scored entries are staged in LDS and
+// appended after the walk if they lie within the margin of the workgroup's own final maximum; the recheck kernel cuts
+// against the global one.
+#ifndef FTK_RR_DEBUG
+#define FTK_RR_DEBUG 0  // timing experiments only (scripts/build_variant.sh): 1 no collection, 2 one epilogue row, 4 one MFMA step
+#endif
+constexpr int kRrTile = 64;        // cur rows per step
+constexpr int kRrRows = 512;       // ref rows per workgroup
+constexpr int kRrWaveStageCap = 512;  // staged entries per wave (64 rows; measured need ~3.3 per row)
+constexpr int kRrStageCap = 8 * kRrWaveStageCap;
+constexpr float kRrNone = -1.0e30f;   // scores at or below it are "no candidate": cur_info.x is -3e38 (finite, so the
+                                      // index bits never turn it into a NaN) for padding / irregular cur rows
+
+// The cur tile goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, which the 128 resident
+// fragment registers leave no room for — with register staging the compiler spilled it to scratch).  One instruction
+// writes 64 consecutive 16-byte chunks, so rows cannot be padded; instead chunk g of row r sits at position
+// g ^ swizzle(r), which spreads the 16 rows a fragment read touches at once over all bank groups.  The two tile buffers
+// are distinct static arrays: the compiler then knows a read of one does not wait for the transfer into the other (it
+// orders LDS transfers against LDS reads by alias analysis) and completes the transfer at the next barrier.
+template <int kKSteps>
+__device__ __forceinline__ int rr_swizzle(int row) {
+    return ((2 * kKSteps) % 16 == 0) ? (row & 15) : ((row >> 1) & 7);
+}
+
+// cur row, relative to the first row of the lane's share, of accumulator element e = 16 * mt + r (32x32 MFMA C/D map)
+__device__ __forceinline__ uint32_t rr_share_offset(uint32_t e) { return (e >> 4) * 32u + (e & 3u) + 8u * ((e & 15u) >> 2); }
+
+template <int kKSteps, bool kNearby>
+__global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams p) {
+    constexpr int kDimPad = kKSteps * 16, kChunks = 2 * kKSteps /* 16-byte chunks per row */, kStageVecs = kKSteps / 4;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    __shared__ __attribute__((aligned(16))) _Float16 sXa[kRrTile * kDimPad];
+    __shared__ __attribute__((aligned(16))) _Float16 sXb[kRrTile * kDimPad];
+    __shared__ __attribute__((aligned(16))) float4 sInfoA[kRrTile];  // {bias, u, v, -} per cur row
+    __shared__ __attribute__((aligned(16))) float4 sInfoB[kRrTile];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
+    uint32_t *const sRun = reinterpret_cast<uint32_t *>(rr_lds);  // [512] final row maxima of this walk
+    uint32_t *const sStage = sRun + kRrRows;                      // [8 waves][kRrWaveStageCap][3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid of row_groups x splits workgroups.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2):
+    // renumber so that the workgroups of ONE XCD are consecutive in (split, row group) order and share as few cur slices
+    // as possible — otherwise every XCD streams all of cur through its 4 MB L2 (30 % misses measured).
+    const int row_groups = p.n_ref_pad / kRrRows, n_splits = p.splits;
+    const int n_wg = row_groups * n_splits;
+    int wg = (int)blockIdx.x;
+    {
+        const int per_xcd = n_wg / 8, rem = n_wg % 8, xcd = wg % 8, k = wg / 8;
+        wg = xcd * per_xcd + (xcd < rem ? xcd : rem) + k;  // XCD x owns a contiguous run of per_xcd (+1 for the first rem) ids
+    }
+    const int split = wg / row_groups, row_group = wg - split * row_groups;
+    const int i0 = row_group * kRrRows + wave * 64;
+    const int tiles_total = p.n_cur_pad / kRrTile;
+    // even split of the cur tiles
+    const int jt_begin = (int)(((long long)split * tiles_total) / n_splits);
+    const int jt_end = (int)(((long long)(split + 1) * tiles_total) / n_splits);
+    if (jt_begin >= jt_end) {
+        return;
+    }
+    const int n_tiles = jt_end - jt_begin, n_steps = n_tiles + 1;  // the first tile once more at the end (see kMode 2 above)
+    const float neg_inf = __uint_as_float(0xFF800000u);
+    uint32_t wcount = 0u;  // entries this wave has staged (wave-uniform)
+
+    int row_i[2];
+    bool live[2];
+    float pu[2], pv[2], run[2];
+    half8 bfrag[2][kKSteps];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int i = i0 + nt * 32 + (lane & 31);
+        row_i[nt] = i;
+        live[nt] = i < p.n_ref && p.ref_irregular[i] == 0;
+        pu[nt] = (kNearby && i < p.n_ref) ? p.pred_uv[2 * i] : 0.0f;
+        pv[nt] = (kNearby && i < p.n_ref) ? p.pred_uv[2 * i + 1] : 0.0f;
+        run[nt] = neg_inf;
+        const _Float16 *src = p.ref_h + (size_t)i * kDimPad + 8 * (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < kKSteps; ++kk) {
+            bfrag[nt][kk] = *reinterpret_cast<const half8 *>(src + kk * 16);
+        }
+    }
+
+    // transfer q of this wave fills LDS chunks [(wave * kStageVecs + q) * 64, +64); this lane's chunk L = row * kChunks + pos
+    // holds global chunk pos ^ swizzle(row) of that row
+    int soff0 = 0, soff1 = 0, soff2 = 0, soff3 = 0;  // half offsets into a cur tile; kStageVecs of them in use
+    {
+        auto source_of = [&](int q) {
+            const int L = (wave * kStageVecs + q) * 64 + lane;
+            const int r = L / kChunks, pos = L % kChunks;
+            return r * kDimPad + (pos ^ rr_swizzle<kKSteps>(r)) * 8;
+        };
+        soff0 = source_of(0);
+        if (kStageVecs > 1) soff1 = source_of(1);
+        if (kStageVecs > 2) soff2 = source_of(2);
+        if (kStageVecs > 3) soff3 = source_of(3);
+    }
+#define FTK_RR_TILE(step_) (jt_begin + (((step_) == n_tiles) ? 0 : (step_)))
+#define FTK_RR_FETCH(step_, SX, SINFO)                                                                                        \
+    do {                                                                                                                      \
+        const int jt_ = FTK_RR_TILE(step_);                                                                                   \
+        const _Float16 *g_ = p.cur_h + (size_t)jt_ * kRrTile * kDimPad;                                                       \
+        _Float16 *d_ = SX + (wave * kStageVecs) * 64 * 8;                                                                     \
+        __builtin_amdgcn_global_load_lds(g_ + soff0, (lds_ptr)(d_), 16, 0, 0);                                                \
+        if (kStageVecs > 1) __builtin_amdgcn_global_load_lds(g_ + soff1, (lds_ptr)(d_ + 512), 16, 0, 0);                      \
+        if (kStageVecs > 2) __builtin_amdgcn_global_load_lds(g_ + soff2, (lds_ptr)(d_ + 1024), 16, 0, 0);                     \
+        if (kStageVecs > 3) __builtin_amdgcn_global_load_lds(g_ + soff3, (lds_ptr)(d_ + 1536), 16, 0, 0);                     \
+        if (wave == 0) {                                                                                                      \
+            __builtin_amdgcn_global_load_lds(p.cur_info + (size_t)jt_ * kRrTile + lane, (lds_ptr)(SINFO), 16, 0, 0);          \
+        }                                                                                                                     \
+    } while (0)
+
+    float16v acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[mt][nt][r] = 0.0f;
+            }
+        }
+    }
+    // fragment address of this lane: row (lane & 31) (+ 32 for the second tile row block), chunk 2 * kk + (lane >> 5)
+    // -> byte offset row * kDimPad * 2 + ((32 * kk) ^ frag_flip)
+    const int frag_row_bytes = (lane & 31) * kDimPad * 2;
+    const int frag_flip = ((lane >> 5) ^ rr_swizzle<kKSteps>(lane & 31)) << 4;
+
+#define FTK_RR_STEP(s_, SX, SINFO, SXN, SINFON)                                                                               \
+    do {                                                                                                                      \
+        __syncthreads(); /* tile s complete and visible; everyone is done with tile s - 1 (the other buffer) */               \
+        if ((s_) + 1 < n_steps) {                                                                                             \
+            FTK_RR_FETCH((s_) + 1, SXN, SINFON);                                                                              \
+        }                                                                                                                     \
+        rr_compute(s_, reinterpret_cast<const unsigned char *>(SX) + frag_row_bytes, SINFO);                                  \
+    } while (0)
+
+    auto rr_compute = [&](int s, const unsigned char *ax0, const float4 *info_tile) {
+        // 64 cur rows x 64 ref rows x whole K: fragments of K step kk + 1 are read while the MFMAs of step kk run
+        half8 fa[2][2];
+        int flip = frag_flip;
+        asm volatile("" : "+v"(flip));  // per step: otherwise the 2 x kKSteps fragment addresses are all hoisted out of the walk
+        fa[0][0] = *reinterpret_cast<const half8 *>(ax0 + flip);
+        fa[0][1] = *reinterpret_cast<const half8 *>(ax0 + flip + 32 * kDimPad * 2);
+#pragma unroll
+        for (int kk = 0; kk < kKSteps; ++kk) {
+            const int cur_set = kk & 1, nxt_set = cur_set ^ 1;
+            if (kk + 1 < kKSteps) {
+                const int off = (32 * (kk + 1)) ^ flip;
+                fa[nxt_set][0] = *reinterpret_cast<const half8 *>(ax0 + off);
+                fa[nxt_set][1] = *reinterpret_cast<const half8 *>(ax0 + off + 32 * kDimPad * 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+#if FTK_RR_DEBUG & 4
+                    if (kk == 0)
+#endif
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur_set][mt], bfrag[nt][kk], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: C/D map of the 32x32 MFMA — col (ref) = lane & 31, row (cur) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        const int j0 = FTK_RR_TILE(s) * kRrTile;
+        // Pass 1, branch-free: score = accumulator + bias (window applied), with the element's index e = 16 * mt + r written
+        // into the five low mantissa bits (a perturbation below 2e-6, see the margin budget in the header), and the two
+        // largest of the lane's 32 scores: m1 (which then names its own element) and m2.
+        float m1[2] = {neg_inf, neg_inf}, m2[2] = {neg_inf, neg_inf};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#if FTK_RR_DEBUG & 2
+                if (r != 5) continue;
+#endif
+                const int jl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float4 info = info_tile[jl];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float v = acc[mt][nt][r] + info.x;
+                    v = __uint_as_float((__float_as_uint(v) & ~31u) | (uint32_t)(mt * 16 + r));
+                    if (kNearby) {
+                        const bool out = (int)(fabsf(pu[nt] - info.y) > p.max_col) | (int)(fabsf(pv[nt] - info.z) > p.max_row);
+                        v = out ? neg_inf : v;
+                    }
+                    acc[mt][nt][r] = v;  // in place, for the rare look at every element below
+                    m2[nt] = __builtin_amdgcn_fmed3f(m1[nt], m2[nt], v);
+                    m1[nt] = fmaxf(m1[nt], v);
+                }
+                if ((r & 3) == 3) {
+                    // four rows of per-candidate data in flight, not all thirty-two: the running values are pinned here, or the
+                    // compiler sinks the whole nt = 1 chain below the nt = 0 one and keeps every loaded value alive for it
+                    asm volatile("" : "+v"(m1[0]), "+v"(m1[1]), "+v"(m2[0]), "+v"(m2[1]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // Collection.  A lane whose best score reaches the bound stages that one element without looking at the others (the
+        // usual case); one whose second best does too stages both; the wave appends through a ballot, no atomic.  Only when
+        // a lane's second best is in do its 32 scores get counted, and three or more above the bound name the whole share.
+        const uint32_t lanes_below = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        uint32_t *const wave_stage = sStage + (size_t)wave * kRrWaveStageCap * 3;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bool has = live[nt] && m1[nt] > kRrNone;  // padding / irregular rows and empty windows collect nothing
+            float mine = has ? m1[nt] : neg_inf;
+            mine = fmaxf(mine, __shfl_xor(mine, 32));  // lanes l and l ^ 32 hold the two halves of the row's tile
+#if !(FTK_RR_DEBUG & 1)
+            if (s > 0) {
+                const float bound = fmaxf(run[nt], mine) - 2.0f * kMargin;
+                const bool hit1 = has && m1[nt] >= bound;
+                const bool hit2 = has && m2[nt] >= bound && m2[nt] > kRrNone;
+                const uint32_t slot_row = (uint32_t)(wave * 64 + nt * 32 + (lane & 31));
+                // wave-uniform call; lanes with `on` append (row word, cur index word, score).  Row word bit 31: the entry names the
+                // lane's whole share of the tile (cur index word = its first row); the flush expands it if the score survives.
+                auto append = [&](bool on, uint32_t row_word, uint32_t cur_word, float v) {
+                    const unsigned long long mask = __ballot(on);
+                    if (mask != 0ull) {
+                        const uint32_t at = wcount + (uint32_t)__popcll(mask & ((1ull << lanes_below) - 1ull));
+                        if (on) {
+                            if (at < (uint32_t)kRrWaveStageCap) {
+                                wave_stage[3 * at] = row_word;
+                                wave_stage[3 * at + 1] = cur_word;
+                                wave_stage[3 * at + 2] = __float_as_uint(v);
+                            } else {
+                                p.cand_count[row_i[nt]] = (uint32_t)kCosineCandCap + 1u;  // stage full (never seen): the row takes the exact scan
+                            }
+                        }
+                        wcount += (uint32_t)__popcll(mask);
+                    }
+                };
+                const uint32_t share_first = (uint32_t)(j0 + 4 * (lane >> 5));
+                const uint32_t e1 = __float_as_uint(m1[nt]) & 31u, e2 = __float_as_uint(m2[nt]) & 31u;
+                append(hit1, slot_row, share_first + rr_share_offset(e1), m1[nt]);
+                if (__ballot(hit2) != 0ull) {  // wave-uniform, so the wave's count stays uniform
+                    append(hit2, slot_row, share_first + rr_share_offset(e2), m2[nt]);  // med3 returns one of its inputs: m2 names its element too
+                    // a third score above the bound?  count, branch-free
+                    const float bound2 = hit2 ? bound : __uint_as_float(0x7F800000u);
+                    int above = 0;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            above += (acc[mt][nt][r] >= bound2) ? 1 : 0;
+                        }
+                    }
+                    // rare: name all 32 cur rows of this lane's share, under the lane's best score; the recheck decides
+                    append(above > 2, slot_row | 0x80000000u, share_first, m1[nt]);
+                }
+            }
+#endif
+            if (s < n_tiles) {
+                run[nt] = fmaxf(run[nt], mine);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[mt][nt][r] = 0.0f;
+                }
+            }
+        }
+    };
+
+    FTK_RR_FETCH(0, sXa, sInfoA);
+    for (int s = 0; s < n_steps; s += 2) {
+        FTK_RR_STEP(s, sXa, sInfoA, sXb, sInfoB);
+        if (s + 1 < n_steps) {
+            FTK_RR_STEP(s + 1, sXb, sInfoB, sXa, sInfoA);
+        }
+    }
+#undef FTK_RR_STEP
+#undef FTK_RR_FETCH
+#undef FTK_RR_TILE
+    // the wave's 64 rows and its staged entries are its own: no workgroup barrier
+    if (lane < 32) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const uint32_t key = run[nt] > neg_inf ? order_key(run[nt]) : 0u;
+            sRun[wave * 64 + nt * 32 + lane] = key;
+            if (key != 0u) {  // implies live
+                atomicMax(&p.row_max[row_i[nt]], key);
+            }
+        }
+    }
+    const uint32_t staged = min(wcount, (uint32_t)kRrWaveStageCap);
+    const uint32_t *const wave_stage = sStage + (size_t)wave * kRrWaveStageCap * 3;
+    const int g0 = row_group * kRrRows;
+    for (uint32_t e = (uint32_t)lane; e < staged; e += 64u) {
+        const uint32_t row_word = wave_stage[3 * e], local = row_word & 0x7FFFFFFFu;
+        const uint32_t cur_word = wave_stage[3 * e + 1];
+        const float score = __uint_as_float(wave_stage[3 * e + 2]);
+        if (score >= order_value(sRun[local]) - 2.0f * kMargin) {  // sRun[local] != 0: the row staged something
+            const int i = g0 + (int)local;
+            if (row_word & 0x80000000u) {
+                const uint32_t first = atomicAdd(&p.cand_count[i], 32u);
+                if (first + 32u <= (uint32_t)kCosineCandCap) {
+                    const uint32_t j_best = cur_word + rr_share_offset(__float_as_uint(score) & 31u);
+                    for (uint32_t k = 0; k < 32u; ++k) {
+                        const uint32_t j = cur_word + rr_share_offset(k);
+                        // padding rows of the last tile are not candidates: their slots repeat the lane's best
+                        p.cand[(size_t)i * kCosineCandCap + first + k] = (int32_t)(j < (uint32_t)p.n_cur ? j : j_best);
+                        p.cand_score[(size_t)i * kCosineCandCap + first + k] = score;
+                    }
+                }
+            } else {
+                const uint32_t slot = atomicAdd(&p.cand_count[i], 1u);
+                if (slot < (uint32_t)kCosineCandCap) {
+                    p.cand[(size_t)i * kCosineCandCap + slot] = (int32_t)cur_word;
+                    p.cand_score[(size_t)i * kCosineCandCap + slot] = score;
+                }
+            }
+        }
+    }
+}
+
 // ---- 4. exact decision -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams p) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,6 +1035,11 @@ size_t cosine_rs_lds_bytes(int dim_pad) {
            sizeof(uint32_t) * (kTile + 4 + 3 * kStageCap);
 }
 
+size_t cosine_rr_lds_bytes(int dim_pad) {
+    (void)dim_pad;  // the tile buffers are static arrays of the kernel instance
+    return sizeof(uint32_t) * (kRrRows + 3 * kRrStageCap);
+}
+
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     if (p.n_ref <= 0 || p.n_cur <= 0) {
         return hipSuccess;
@@ -715,7 +1054,36 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
         hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((rows * 8 + 255) / 256), 2u), dim3(256), 0, stream, p);
     }
     const int row_tiles = p.n_ref_pad / kTile;
-    if (p.ref_stationary) {
+    if (p.ref_stationary == 2) {
+        const dim3 grid((unsigned)((p.n_ref_pad / kRrRows) * p.splits));
+        const size_t lds = cosine_rr_lds_bytes(p.dim_pad);
+#define FTK_RR_LAUNCH(KSTEPS, NEARBY)                                                                                             \
+    do {                                                                                                                            \
+        auto kern = cosine_gemm_rr_kernel<KSTEPS, NEARBY>;                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        if (e != hipSuccess) {                                                                                                      \
+            return e;                                                                                                               \
+        }                                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);                                                                  \
+    } while (0)
+#define FTK_RR_DISPATCH(KSTEPS)            \
+    do {                                   \
+        if (p.pred_uv) {                   \
+            FTK_RR_LAUNCH(KSTEPS, true);   \
+        } else {                           \
+            FTK_RR_LAUNCH(KSTEPS, false);  \
+        }                                  \
+    } while (0)
+        switch (p.dim_pad / 16) {
+            case 4: FTK_RR_DISPATCH(4); break;
+            case 8: FTK_RR_DISPATCH(8); break;
+            case 12: FTK_RR_DISPATCH(12); break;
+            case 16: FTK_RR_DISPATCH(16); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef FTK_RR_DISPATCH
+#undef FTK_RR_LAUNCH
+    } else if (p.ref_stationary) {
         const int tiles_total = p.n_cur_pad / kCurTile;
         const int splits = (tiles_total + p.tiles_per_split - 1) / p.tiles_per_split;
         const dim3 grid((unsigned)row_tiles, (unsigned)splits);

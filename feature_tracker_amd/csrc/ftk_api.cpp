@@ -1342,22 +1342,29 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.dim_pad = (int32_t)align_up((size_t)dim, 64);
     // dim <= 256 (SuperPoint, DISK): the ref-stationary contraction — 128 ref rows for the whole K resident in LDS,
     // cur streamed in 256-row tiles, one 8-wave workgroup per CU.  Longer descriptors use the chunked kernel.
-    p.ref_stationary = (p.dim_pad <= 256 && !(getenv("FTK_COSINE_CHUNKED") && atoi(getenv("FTK_COSINE_CHUNKED")) == 1)) ? 1 : 0;
-    const int cur_tile = p.ref_stationary ? 256 : 128;
-    p.n_ref_pad = (int32_t)align_up((size_t)n_ref, 128);
+    // dim <= 256 (SuperPoint, DISK): the ref fragments stay on chip for the whole walk over cur — in registers
+    // (cosine_gemm_rr_kernel, 512 ref rows per workgroup; the default) or in LDS (cosine_gemm_rs_kernel, 128 rows;
+    // FTK_COSINE_KERNEL=rs).  Longer descriptors, or FTK_COSINE_KERNEL=chunked, use the chunked kernel.
+    const char *kernel_env = getenv("FTK_COSINE_KERNEL");
+    const bool want_chunked = (kernel_env && !strcmp(kernel_env, "chunked")) || (getenv("FTK_COSINE_CHUNKED") && atoi(getenv("FTK_COSINE_CHUNKED")) == 1);
+    p.ref_stationary = (p.dim_pad <= 256 && !want_chunked) ? ((kernel_env && !strcmp(kernel_env, "rs")) ? 1 : 2) : 0;
+    const int cur_tile = p.ref_stationary == 2 ? 64 : (p.ref_stationary == 1 ? 256 : 128);
+    const int row_group = p.ref_stationary == 2 ? 512 : 128;
+    p.n_ref_pad = (int32_t)align_up((size_t)n_ref, (size_t)row_group);
     p.n_cur_pad = (int32_t)align_up((size_t)n_cur, (size_t)cur_tile);
     p.max_distance = max_distance;
     p.max_col = (float)max_col_distance;
     p.max_row = (float)max_row_distance;
-    // Keep the whole grid co-resident in ONE round (ref-stationary: one workgroup per CU -> <= 256; chunked: two per
+    // Keep the whole grid co-resident in ONE round (on-chip ref: one workgroup per CU -> <= 256; chunked: two per
     // CU -> <= 512), each workgroup walking a contiguous run of cur tiles: a second, partly filled round costs more
     // than slightly longer runs.
-    const int row_tiles = p.n_ref_pad / 128, tiles_total = p.n_cur_pad / cur_tile;
+    const int row_tiles = p.n_ref_pad / row_group, tiles_total = p.n_cur_pad / cur_tile;
     int splits = (p.ref_stationary ? 256 : 512) / row_tiles;
     if (const char *env = getenv("FTK_COSINE_SPLITS")) {
         splits = atoi(env);  // experiment override
     }
     splits = std::max(1, std::min(splits, tiles_total));
+    p.splits = splits;
     p.tiles_per_split = (tiles_total + splits - 1) / splits;
     // workspace carve-up (every region 256-byte aligned)
     size_t off = 0;
@@ -1371,6 +1378,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     const size_t o_ref_norm = carve(sizeof(float) * (size_t)p.n_ref_pad);
     const size_t o_cur_norm = carve(sizeof(float) * (size_t)p.n_cur_pad);
     const size_t o_cur_bias = carve(sizeof(float) * (size_t)p.n_cur_pad);
+    const size_t o_cur_info = carve(sizeof(float) * 4 * (size_t)p.n_cur_pad);
     const size_t o_ref_irr = carve((size_t)p.n_ref_pad);
     // row_max | cand_count | irregular_count are adjacent: ONE memset clears them (key 0 = "no candidate yet")
     const size_t o_row_max = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
@@ -1378,9 +1386,10 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     const size_t o_irr_cnt = carve(sizeof(uint32_t));
     const size_t o_clear_end = off;
     const size_t o_cand = carve(sizeof(int32_t) * (size_t)p.n_ref_pad * ftk::kCosineCandCap);
-    // ref-stationary mode walks cur ONCE (running row maximum + scored candidate lists); FTK_COSINE_TWO_PASS=1 keeps the
-    // maximum-then-collect pair of launches for comparison
-    const bool single_walk = p.ref_stationary && !(getenv("FTK_COSINE_TWO_PASS") && atoi(getenv("FTK_COSINE_TWO_PASS")) == 1);
+    // the on-chip-ref kernels walk cur ONCE (running row maximum + scored candidate lists); FTK_COSINE_TWO_PASS=1 with
+    // FTK_COSINE_KERNEL=rs keeps the maximum-then-collect pair of launches for comparison
+    const bool single_walk =
+        p.ref_stationary == 2 || (p.ref_stationary == 1 && !(getenv("FTK_COSINE_TWO_PASS") && atoi(getenv("FTK_COSINE_TWO_PASS")) == 1));
     const size_t o_cand_score = single_walk ? carve(sizeof(float) * (size_t)p.n_ref_pad * ftk::kCosineCandCap) : 0;
     const size_t o_irr_list = carve(sizeof(int32_t) * ftk::kCosineIrregularCap);
     const int rc = ensure_cosine_ws(ctx, off);
@@ -1393,6 +1402,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.ref_norm = reinterpret_cast<float *>(ws + o_ref_norm);
     p.cur_norm = reinterpret_cast<float *>(ws + o_cur_norm);
     p.cur_bias = reinterpret_cast<float *>(ws + o_cur_bias);
+    p.cur_info = reinterpret_cast<float4 *>(ws + o_cur_info);
     p.ref_irregular = ws + o_ref_irr;
     p.row_max = reinterpret_cast<uint32_t *>(ws + o_row_max);
     p.cand_count = reinterpret_cast<uint32_t *>(ws + o_cnt);

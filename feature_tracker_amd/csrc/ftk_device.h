@@ -81,7 +81,7 @@ struct MatchParams {
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 
 // Float-descriptor (cosine distance) matcher: float_matcher_kernels.hip.
-constexpr int kCosineCandCap = 32;       // candidates kept per ref row before the row falls back to the exact scan
+constexpr int kCosineCandCap = 64;       // candidates kept per ref row before the row falls back to the exact scan
 constexpr int kCosineIrregularCap = 64;  // cur rows with a zero / non-finite / extreme norm kept in the side list
 struct CosineParams {
     const float *ref, *cur;   // [n][dim] fp32 descriptors, row-major
@@ -91,6 +91,7 @@ struct CosineParams {
     // workspace (see ftk_cosine_workspace_bytes)
     _Float16 *ref_h, *cur_h;  // unit-length fp16 copies, [n_pad][dim_pad], zero padded
     float *ref_norm, *cur_norm, *cur_bias;
+    float4 *cur_info;         // {bias, u, v, 0} per (padded) cur row: what cosine_gemm_rr_kernel streams beside the tile
     uint8_t *ref_irregular;
     uint32_t *row_max, *cand_count;
     int32_t *cand;            // [n_ref_pad][kCosineCandCap]
@@ -101,10 +102,14 @@ struct CosineParams {
     size_t clear_bytes;
     int32_t n_ref, n_cur, dim, n_ref_pad, n_cur_pad, dim_pad;
     int32_t tiles_per_split;  // cur tiles (128 rows; 256 in ref-stationary mode) walked by one workgroup
-    int32_t ref_stationary;   // dim_pad <= 256: cosine_gemm_rs_kernel (n_cur_pad is then a multiple of 256)
+    int32_t ref_stationary;   // dim_pad <= 256.  2: cosine_gemm_rr_kernel (ref fragments in registers; n_ref_pad % 512 == 0,
+                              // n_cur_pad % 64 == 0, `splits` workgroups share the cur tiles evenly);
+                              // 1: cosine_gemm_rs_kernel (ref rows in LDS; n_cur_pad % 256 == 0, tiles_per_split)
+    int32_t splits;
     float max_distance, max_col, max_row;
 };
 size_t cosine_rs_lds_bytes(int dim_pad);
+size_t cosine_rr_lds_bytes(int dim_pad);
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
 
 // DirectMethod (direct_kernels.hip): one workgroup per pose problem; all problems of a launch share
