@@ -97,6 +97,30 @@ __device__ __forceinline__ float eigen_dot_octet(const float *__restrict__ x, co
     return res;
 }
 
+__device__ __forceinline__ void cosine_prep_row_outputs(const CosineParams &p, int which, int row, int n, float norm, bool regular) {
+    if (which) {
+        const float bias = regular ? 0.0f : __uint_as_float(0xFF800000u);  // -inf keeps the column out of every maximum
+        p.cur_bias[row] = bias;
+        if (p.cur_info) {
+            const bool windowed = p.pred_uv != nullptr && row < n;
+            // finite "never": cosine_gemm_rr_kernel writes index bits into the score and -inf would turn into a NaN
+            p.cur_info[row] = make_float4(regular ? 0.0f : -3.0e38f, windowed ? p.cur_uv[2 * row] : 0.0f, windowed ? p.cur_uv[2 * row + 1] : 0.0f, 0.0f);
+        }
+        if (row < n) {
+            p.cur_norm[row] = norm;
+            if (!regular) {
+                const uint32_t slot = atomicAdd(p.irregular_count, 1u);
+                if (slot < (uint32_t)kCosineIrregularCap) {
+                    p.irregular_list[slot] = row;
+                }
+            }
+        }
+    } else if (row < n) {
+        p.ref_norm[row] = norm;
+        p.ref_irregular[row] = regular ? 0 : 1;
+    }
+}
+
 // ---- 1. norms + unit-length fp16 copies ------------------------------------------------------
 // One octet per (padded) row of one operand; blockIdx.y == 0: ref, 1: cur.
 __global__ void __launch_bounds__(256) cosine_prep_kernel(const CosineParams p) {
@@ -117,32 +141,97 @@ __global__ void __launch_bounds__(256) cosine_prep_kernel(const CosineParams p) 
         regular = norm >= kNormLo && norm <= kNormHi;             // false for NaN
     }
     const float inv = regular ? 1.0f / norm : 0.0f;
-    for (int k = c; k < p.dim_pad; k += 8) {
-        const float v = (regular && k < p.dim) ? src[k] * inv : 0.0f;
-        dst[k] = (_Float16)v;
+    if ((p.dim & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        // four elements per lane and step: the octet reads 128 and writes 64 contiguous bytes (dst rows are 128-byte aligned)
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        for (int f = c; f < p.dim_pad / 4; f += 8) {
+            float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (regular && 4 * f < p.dim) {
+                x = src4[f];
+            }
+            half4 h;
+            h[0] = (_Float16)(x.x * inv);
+            h[1] = (_Float16)(x.y * inv);
+            h[2] = (_Float16)(x.z * inv);
+            h[3] = (_Float16)(x.w * inv);
+            *reinterpret_cast<half4 *>(dst + 4 * f) = h;
+        }
+    } else {
+        for (int k = c; k < p.dim_pad; k += 8) {
+            const float v = (regular && k < p.dim) ? src[k] * inv : 0.0f;
+            dst[k] = (_Float16)v;
+        }
     }
     if (c == 0) {
-        if (which) {
-            const float bias = regular ? 0.0f : __uint_as_float(0xFF800000u);  // -inf keeps the column out of every maximum
-            p.cur_bias[row] = bias;
-            if (p.cur_info) {
-                const bool windowed = p.pred_uv != nullptr && row < n;
-                // finite "never": cosine_gemm_rr_kernel writes index bits into the score and -inf would turn into a NaN
-                p.cur_info[row] = make_float4(regular ? 0.0f : -3.0e38f, windowed ? p.cur_uv[2 * row] : 0.0f, windowed ? p.cur_uv[2 * row + 1] : 0.0f, 0.0f);
-            }
-            if (row < n) {
-                p.cur_norm[row] = norm;
-                if (!regular) {
-                    const uint32_t slot = atomicAdd(p.irregular_count, 1u);
-                    if (slot < (uint32_t)kCosineIrregularCap) {
-                        p.irregular_list[slot] = row;
-                    }
-                }
-            }
-        } else if (row < n) {
-            p.ref_norm[row] = norm;
-            p.ref_irregular[row] = regular ? 0 : 1;
+        cosine_prep_row_outputs(p, which, row, n, norm, regular);
+    }
+}
+
+// Same result for the common layouts (dim a multiple of 8, rows 16-byte aligned: SuperPoint-256, DISK-128), TWO lanes
+// per row: lane a IS packet accumulator a of Eigen's reduction and holds its four components as a float4, so every
+// load is a whole 16-byte packet (the octet form reads 4 bytes per lane) and a wave covers 32 rows.
+// squaredNorm = predux(acc0 + acc1) with acc_a = sum over i of packet(2 i + a)^2, each component in index order.
+__global__ void __launch_bounds__(256) cosine_prep_pair_kernel(const CosineParams p) {
+    const int which = (int)blockIdx.y;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = tid >> 1, a = tid & 1;
+    const int n = which ? p.n_cur : p.n_ref;
+    const int n_pad = which ? p.n_cur_pad : p.n_ref_pad;
+    if (row >= n_pad) {
+        return;  // pairs leave together
+    }
+    const float4 *src4 = reinterpret_cast<const float4 *>((which ? p.cur : p.ref) + (size_t)(row < n ? row : 0) * p.dim);
+    _Float16 *dst = (which ? p.cur_h : p.ref_h) + (size_t)row * p.dim_pad;
+    const int packets = p.dim / 4;  // even
+    float norm = 0.0f;
+    bool regular = false;
+    if (row < n) {  // uniform within the pair
+        float4 x = src4[a];
+        float4 acc = make_float4(x.x * x.x, x.y * x.y, x.z * x.z, x.w * x.w);
+#pragma unroll 8
+        for (int f = 2 + a; f < packets; f += 2) {  // loads of eight steps in flight; the adds stay in index order
+            x = src4[f];
+            acc.x = acc.x + x.x * x.x;
+            acc.y = acc.y + x.y * x.y;
+            acc.z = acc.z + x.z * x.z;
+            acc.w = acc.w + x.w * x.w;
         }
+        // acc0 + acc1 (lane a = 0 adds its partner's), then SSE2 predux (p0 + p2) + (p1 + p3)
+        const float ox = __shfl_xor(acc.x, 1), oy = __shfl_xor(acc.y, 1), oz = __shfl_xor(acc.z, 1), ow = __shfl_xor(acc.w, 1);
+        const float p0 = a ? ox + acc.x : acc.x + ox, p1 = a ? oy + acc.y : acc.y + oy;
+        const float p2 = a ? oz + acc.z : acc.z + oz, p3 = a ? ow + acc.w : acc.w + ow;
+        norm = sqrtf((p0 + p2) + (p1 + p3));
+        regular = norm >= kNormLo && norm <= kNormHi;
+    }
+    const float inv = regular ? 1.0f / norm : 0.0f;
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    // eight packets per lane and round: all loads first (unconditional, from a valid packet — a load under a branch, or
+    // behind a store the compiler cannot prove disjoint, is waited for one at a time), then the stores
+    const int packets_pad = p.dim_pad / 4;
+    for (int f0 = a; f0 < packets_pad; f0 += 16) {
+        float4 x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = f0 + 2 * j;
+            x[j] = src4[f < packets ? f : packets - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = f0 + 2 * j;
+            const bool keep = regular && f < packets;
+            half4 h;
+            h[0] = (_Float16)(keep ? x[j].x * inv : 0.0f);
+            h[1] = (_Float16)(keep ? x[j].y * inv : 0.0f);
+            h[2] = (_Float16)(keep ? x[j].z * inv : 0.0f);
+            h[3] = (_Float16)(keep ? x[j].w * inv : 0.0f);
+            if (f < packets_pad) {
+                *reinterpret_cast<half4 *>(dst + 4 * f) = h;
+            }
+        }
+    }
+    if (a == 0) {
+        cosine_prep_row_outputs(p, which, row, n, norm, regular);
     }
 }
 
@@ -1060,7 +1149,12 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     // both operands in one launch: blockIdx.y selects ref / cur
     {
         const int rows = p.n_ref_pad > p.n_cur_pad ? p.n_ref_pad : p.n_cur_pad;
-        hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((rows * 8 + 255) / 256), 2u), dim3(256), 0, stream, p);
+        const bool packets = (p.dim % 8) == 0 && ((reinterpret_cast<uintptr_t>(p.ref) | reinterpret_cast<uintptr_t>(p.cur)) & 15u) == 0;
+        if (packets) {
+            hipLaunchKernelGGL(cosine_prep_pair_kernel, dim3((unsigned)((rows * 2 + 255) / 256), 2u), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(cosine_prep_kernel, dim3((unsigned)((rows * 8 + 255) / 256), 2u), dim3(256), 0, stream, p);
+        }
     }
     const int row_tiles = p.n_ref_pad / kTile;
     if (p.ref_stationary == 2) {

@@ -20,7 +20,7 @@ def matcher(ftk, max_dist, col=40, row=40):
     return m
 
 
-@pytest.mark.parametrize("n_ref,n_cur,dim", [(1000, 1000, 256), (777, 1300, 128), (300, 257, 256), (100, 3000, 64), (129, 127, 96), (50, 70, 250), (33, 40, 7), (20, 20, 3)])
+@pytest.mark.parametrize("n_ref,n_cur,dim", [(1000, 1000, 256), (777, 1300, 128), (300, 257, 256), (100, 3000, 64), (129, 127, 96), (50, 70, 250), (60, 90, 100), (33, 40, 7), (20, 20, 3)])
 def test_force_match(ftk, oracle, n_ref, n_cur, dim):
     ref, cur, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim)
     for thr in (0.1, 0.6):
