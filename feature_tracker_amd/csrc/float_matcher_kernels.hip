@@ -77,7 +77,8 @@ __device__ __forceinline__ float eigen_dot_octet(const float *__restrict__ x, co
     float acc = 0.0f;
     if (a == 0 || aligned_size > 4) {
         acc = x[off] * y[off];
-        for (int index = 8; index < aligned_end2; index += 8) {
+#pragma unroll 8
+        for (int index = 8; index < aligned_end2; index += 8) {  // eight steps of loads in flight (a rolled loop waits for each pair); adds in index order
             acc = acc + x[index + off] * y[index + off];
         }
     }
