@@ -2,7 +2,8 @@
 """Randomised parity soak (GPU box): the HIP path against the CPU oracle on randomly drawn problems for a fixed
 time budget — every tracker variant, both descriptor matchers, the direct method — comparing bit for bit.
 
-    python scripts/soak_parity.py [seconds] [seed]        prints one summary line per family, exits 1 on any mismatch
+    python scripts/soak_parity.py [seconds] [seed] [family]   prints one summary line per family, exits 1 on any mismatch
+                                                              family: all (default) | matcher (both matchers only, larger sets)
 
 Random axes: image size (odd sizes included), motion (translation / rotation / scale, up to ~15 px), pyramid depth,
 patch size (rectangular too), feature count, border features, predictions, incoming status, kMaxTrackPointsNumber,
@@ -22,6 +23,7 @@ from tests import oracle_lib as O  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+ONLY = sys.argv[3] if len(sys.argv) > 3 else "all"
 CLASSES = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}
 stats = {}
 
@@ -82,7 +84,8 @@ def klt_round():
 
 
 def matcher_round():
-    n_ref, n_cur = int(rs.choice([1, 33, 300, 1500])), int(rs.choice([1, 40, 257, 2000]))
+    big = ONLY == "matcher"
+    n_ref, n_cur = int(rs.choice([1, 33, 300, 1500] + ([700, 4000] if big else []))), int(rs.choice([1, 40, 257, 2000] + ([129, 5000] if big else [])))
     n_bits = int(rs.choice([32, 64, 200, 256, 512]))
     ref, cur, _ = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=max(1, n_bits // int(rs.choice([8, 13, 30]))), seed=int(rs.randint(1 << 30)))
     if n_cur > 4:
@@ -97,12 +100,16 @@ def matcher_round():
     note("match/hamming/force", np.array_equal(idx, O.force_match(ref, cur, thr)[1]), f"{n_ref}x{n_cur}x{n_bits} thr{thr}")
     ok, idx = m.NearbyMatch(ref, cur, puv, cuv)
     note("match/hamming/nearby", np.array_equal(idx, O.nearby_match(ref, cur, puv, cuv, thr, win, win // 2 + 1)[1]), f"{n_ref}x{n_cur}x{n_bits} thr{thr} w{win}")
-    dim = int(rs.choice([3, 32, 100, 128, 256, 320]))
+    dim = int(rs.choice([3, 32, 64, 100, 128, 192, 200, 256, 320]))
     fr, fc, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=float(rs.choice([0.1, 0.3, 1.0])), seed=int(rs.randint(1 << 30)), normalize=bool(rs.rand() < 0.5))
     if n_cur > 4:
         fc[rs.randint(n_cur)] = fc[rs.randint(n_cur)]
         if rs.rand() < 0.3:
             fc[rs.randint(n_cur)] = 0
+        if rs.rand() < 0.4:  # runs of near-identical neighbours: several scores inside the shortlist margin in one tile
+            start, run = int(rs.randint(n_cur - 4)), int(rs.randint(2, min(40, n_cur - 4) + 1))
+            run = min(run, n_cur - start)
+            fc[start:start + run] = fc[start] * (1.0 + 1e-4 * rs.standard_normal((run, dim))).astype(np.float32)
     fthr = float(rs.choice([0.0, 0.05, 0.3, 0.6, 2.0]))
     c = F.CosineMatcher()
     c.options().kMaxValidDescriptorDistance, c.options().kMaxValidPredictColDistance, c.options().kMaxValidPredictRowDistance = fthr, win, win // 2 + 1
@@ -142,9 +149,12 @@ t_end = time.time() + budget
 rounds = 0
 t_report = time.time() + 60.0
 while time.time() < t_end:
-    klt_round()
-    matcher_round()
-    direct_round()
+    if ONLY == "matcher":
+        matcher_round()
+    else:
+        klt_round()
+        matcher_round()
+        direct_round()
     rounds += 1
     if time.time() > t_report:  # a line a minute: the GPU box takes a silent command for a hung one
         print(f"soak: {rounds} rounds, {sum(v[0] for v in stats.values())} comparisons, {sum(v[1] for v in stats.values())} mismatches so far", flush=True)
