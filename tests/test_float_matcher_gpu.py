@@ -175,10 +175,15 @@ def test_contraction_variants_agree_with_oracle(ftk, oracle, monkeypatch, env):
         assert np.array_equal(g, c), (env, "nearby", n_ref, n_cur, dim)
 
 
-def test_candidates_in_ascending_order_of_similarity(ftk, oracle):
+@pytest.mark.parametrize("splits", [None, "1", "2"])
+def test_candidates_in_ascending_order_of_similarity(ftk, oracle, monkeypatch, splits):
     """Worst case for the running row maximum: every later cur row beats all earlier ones for one ref row, so the single
     walk collects an entry per tile until the list overflows and the row takes the exact scan.  Other rows see the
     same cur rows in an unrelated order.  Results must not depend on any of it."""
+    if splits is not None:
+        # one or two workgroups walk ALL tiles: the rows below then stage an entry per tile, more than a wave's staging
+        # region holds, and must fall back to the exact scan
+        monkeypatch.setenv("FTK_COSINE_SPLITS", splits)
     rs = np.random.RandomState(3)
     dim, n_cur = 256, 4096
     base = rs.standard_normal(dim).astype(np.float32)
@@ -194,3 +199,26 @@ def test_candidates_in_ascending_order_of_similarity(ftk, oracle):
         _, c = oracle.match_float(ref, cur, thr)
         assert np.array_equal(g, c)
     assert (c[:40] > n_cur // 2).all()
+
+
+@pytest.mark.parametrize("dim", [256, 128, 64])
+def test_runs_of_identical_neighbours(ftk, oracle, dim):
+    """Identical (and nearly identical) candidates next to each other land in ONE lane's share of a tile: more than two
+    scores inside the shortlist margin there make the kernel name the whole share.  The lowest index among exact
+    duplicates must win, with and without a window, also when the run crosses a tile boundary and at the ragged end."""
+    rs = np.random.RandomState(11)
+    n_ref, n_cur = 300, 1000
+    ref, cur, perm = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=0.2)
+    for start, run in ((10, 40), (60, 9), (500, 3), (n_cur - 7, 7)):
+        cur[start:start + run] = cur[start]                         # exact duplicates
+    cur[700:730] = cur[700] * (1.0 + 3e-5 * rs.standard_normal((30, dim))).astype(np.float32)  # near duplicates
+    ok, g = matcher(ftk, 0.6).ForceMatch(ref, cur)
+    ok, c = oracle.match_float(ref, cur, 0.6)
+    assert np.array_equal(g, c), np.flatnonzero(g != c)[:10]
+    assert np.isin(c, [10, 60, 500, n_cur - 7]).sum() > 0           # some rows do pick the first of a run
+    cur_uv = rs.uniform(0, 300, size=(n_cur, 2)).astype(np.float32)
+    pred_uv = rs.uniform(0, 300, size=(n_ref, 2)).astype(np.float32)
+    m = matcher(ftk, 0.9, col=80, row=60)
+    _, g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+    _, c = oracle.match_float(ref, cur, 0.9, pred_uv, cur_uv, max_col=80, max_row=60)
+    assert np.array_equal(g, c)
