@@ -772,8 +772,10 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     typedef __attribute__((address_space(3))) void *lds_ptr;
     __shared__ __attribute__((aligned(16))) _Float16 sXa[kRrTile * kDimPad];
     __shared__ __attribute__((aligned(16))) _Float16 sXb[kRrTile * kDimPad];
-    __shared__ __attribute__((aligned(16))) float4 sInfoA[kRrTile];  // {bias, u, v, -} per cur row
-    __shared__ __attribute__((aligned(16))) float4 sInfoB[kRrTile];
+    __shared__ __attribute__((aligned(16))) float4 sInfo0[kRrTile];  // {bias, u, v, -} per cur row; four of them: the late
+    __shared__ __attribute__((aligned(16))) float4 sInfo1[kRrTile];  // waves (see the walk) still read step s - 1's while
+    __shared__ __attribute__((aligned(16))) float4 sInfo2[kRrTile];  // step s + 1's is in flight
+    __shared__ __attribute__((aligned(16))) float4 sInfo3[kRrTile];
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
     uint32_t *const sRun = reinterpret_cast<uint32_t *>(rr_lds);  // [512] final row maxima of this walk
     uint32_t *const sStage = sRun + kRrRows;                      // [8 waves][kRrWaveStageCap][3]
@@ -866,17 +868,18 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     const int frag_row_bytes = (lane & 31) * kDimPad * 2;
     const int frag_flip = ((lane >> 5) ^ rr_swizzle<kKSteps>(lane & 31)) << 4;
 
-#define FTK_RR_STEP(s_, SX, SINFO, SXN, SINFON)                                                                               \
-    do {                                                                                                                      \
-        __syncthreads(); /* tile s complete and visible; everyone is done with tile s - 1 (the other buffer) */               \
-        if ((s_) + 1 < n_steps) {                                                                                             \
-            FTK_RR_FETCH((s_) + 1, SXN, SINFON);                                                                              \
-        }                                                                                                                     \
-        rr_compute(s_, reinterpret_cast<const unsigned char *>(SX) + frag_row_bytes, SINFO);                                  \
-    } while (0)
-
-    auto rr_compute = [&](int s, const unsigned char *ax0, const float4 *info_tile) {
+    auto rr_mfma = [&](const unsigned char *ax0) {
         // 64 cur rows x 64 ref rows x whole K: fragments of K step kk + 1 are read while the MFMAs of step kk run
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[mt][nt][r] = 0.0f;
+                }
+            }
+        }
         half8 fa[2][2];
         int flip = frag_flip;
         asm volatile("" : "+v"(flip));  // per step: otherwise the 2 x kKSteps fragment addresses are all hoisted out of the walk
@@ -902,7 +905,9 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
                 }
             }
         }
-        // epilogue: C/D map of the 32x32 MFMA — col (ref) = lane & 31, row (cur) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    };
+    // epilogue: C/D map of the 32x32 MFMA — col (ref) = lane & 31, row (cur) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    auto rr_epilogue = [&](int s, const float4 *info_tile) {
         const int j0 = FTK_RR_TILE(s) * kRrTile;
         // Pass 1, branch-free: score = accumulator + bias (window applied), with the element's index e = 16 * mt + r written
         // into the five low mantissa bits (a perturbation below 2e-6, see the margin budget in the header), and the two
@@ -997,24 +1002,43 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
                 run[nt] = fmaxf(run[nt], mine);
             }
         }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[mt][nt][r] = 0.0f;
-                }
-            }
-        }
     };
 
-    FTK_RR_FETCH(0, sXa, sInfoA);
-    for (int s = 0; s < n_steps; s += 2) {
-        FTK_RR_STEP(s, sXa, sInfoA, sXb, sInfoB);
-        if (s + 1 < n_steps) {
-            FTK_RR_STEP(s + 1, sXb, sInfoB, sXa, sInfoA);
-        }
+    // The walk.  Waves 0-3 ("early") run MFMA(s) then epilogue(s) inside step s; waves 4-7 ("late") run epilogue(s - 1)
+    // then MFMA(s), keeping their accumulators across the barrier.  Wave w and wave w + 4 share a SIMD: in lockstep both
+    // would feed the matrix pipe together and then both run their epilogues on the vector ALU; staggered by half a step
+    // one pipe works while the other does.  One barrier per step, before anybody reads tile s — it also says that everyone
+    // is done reading tile s - 1, whose buffer the transfer of tile s + 1 overwrites.  The late waves still read the
+    // per-candidate data of step s - 1 then, hence four rotating buffers for it and the walk unrolled by four (the buffers
+    // are distinct static arrays so that the compiler waits for a transfer only where its target is read).
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#define FTK_RR_STEP(s_, SX, SINFO, SXN, SINFON, SINFOP)                                                                     \
+    {                                                                                                                         \
+        if ((s_) >= n_steps) {                                                                                                \
+            break; /* leaving (not skipping) keeps the accumulators out of a merge: a skipped MFMA block costs 64 copies */    \
+        }                                                                                                                     \
+        __syncthreads();                                                                                                      \
+        if ((s_) + 1 < n_steps) {                                                                                             \
+            FTK_RR_FETCH((s_) + 1, SXN, SINFON);                                                                              \
+        }                                                                                                                     \
+        if (late && (s_) >= 1) {                                                                                              \
+            rr_epilogue((s_) - 1, SINFOP);                                                                                    \
+        }                                                                                                                     \
+        rr_mfma(reinterpret_cast<const unsigned char *>(SX) + frag_row_bytes);                                               \
+        if (!late) {                                                                                                          \
+            rr_epilogue(s_, SINFO);                                                                                           \
+        }                                                                                                                     \
+    }
+    FTK_RR_FETCH(0, sXa, sInfo0);
+    for (int s = 0;; s += 4) {
+        FTK_RR_STEP(s, sXa, sInfo0, sXb, sInfo1, sInfo3)
+        FTK_RR_STEP(s + 1, sXb, sInfo1, sXa, sInfo2, sInfo0)
+        FTK_RR_STEP(s + 2, sXa, sInfo2, sXb, sInfo3, sInfo1)
+        FTK_RR_STEP(s + 3, sXb, sInfo3, sXa, sInfo0, sInfo2)
+    }
+    if (late) {  // the last step's epilogue of the late waves (its per-candidate data landed before that step's barrier)
+        const int last = n_steps - 1, slot = last & 3;
+        rr_epilogue(last, slot == 0 ? sInfo0 : slot == 1 ? sInfo1 : slot == 2 ? sInfo2 : sInfo3);
     }
 #undef FTK_RR_STEP
 #undef FTK_RR_FETCH
