@@ -953,7 +953,10 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         for (int nt = 0; nt < 2; ++nt) {
             const bool has = live[nt] && m1[nt] > kRrNone;  // padding / irregular rows and empty windows collect nothing
             float mine = has ? m1[nt] : neg_inf;
-            mine = fmaxf(mine, __shfl_xor(mine, 32));  // lanes l and l ^ 32 hold the two halves of the row's tile
+            {   // lanes l and l ^ 32 hold the two halves of the row's tile: one v_permlane32_swap instead of an LDS round trip
+                const auto halves = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+                mine = fmaxf(__uint_as_float(halves[0]), __uint_as_float(halves[1]));
+            }
 #if !(FTK_RR_DEBUG & 1)
             if (s > 0) {
                 const float bound = fmaxf(run[nt], mine) - 2.0f * kMargin;
