@@ -222,3 +222,28 @@ def test_runs_of_identical_neighbours(ftk, oracle, dim):
     _, g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
     _, c = oracle.match_float(ref, cur, 0.9, pred_uv, cur_uv, max_col=80, max_row=60)
     assert np.array_equal(g, c)
+
+
+@pytest.mark.parametrize("dim", [256, 100])
+def test_device_buffers_not_16_byte_aligned(ftk, oracle, dim):
+    """Device-resident descriptors handed over at an address that is only 4-byte aligned (a view into a larger tensor):
+    the packet-wide loads of the norm / conversion kernels do not apply and the element-wise forms must give the same
+    indices."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref, cur, _ = synth.make_float_descriptors(333, 777, dim=dim, noise=0.3)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        big_r = torch.zeros(ref.size + 3, dtype=torch.float32, device=dev)
+        big_c = torch.zeros(cur.size + 1, dtype=torch.float32, device=dev)
+        d_ref = big_r[3:].view(ref.shape)   # base + 12 bytes
+        d_cur = big_c[1:].view(cur.shape)   # base + 4 bytes
+        d_ref.copy_(torch.from_numpy(ref))
+        d_cur.copy_(torch.from_numpy(cur))
+        assert d_ref.data_ptr() % 16 != 0 and d_cur.data_ptr() % 16 != 0
+        idx = torch.full((ref.shape[0],), -1, dtype=torch.int32, device=dev)
+        D.cosine_match_device(ctx, d_ref, d_cur, 0.5, idx)
+        got = idx.cpu().numpy()
+    assert np.array_equal(got, oracle.match_float(ref, cur, 0.5)[1])
