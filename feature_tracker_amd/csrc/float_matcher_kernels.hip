@@ -234,6 +234,48 @@ __global__ void __launch_bounds__(256) cosine_prep_pair_kernel(const CosineParam
     if (a == 0) {
         cosine_prep_row_outputs(p, which, row, n, norm, regular);
     }
+    // NearbyMatch: the bounding boxes of the 64-row cur tiles (see cosine_tile_box_kernel) ride along — a block holds two
+    // tiles, a wave half of one.  Waves past the padded end have left above, whole tiles at a time.
+    if (which == 1 && p.tile_box != nullptr) {  // block-uniform
+        __shared__ float box_part[4][5];
+        const float pos_inf = __uint_as_float(0x7F800000u), neg_inf = __uint_as_float(0xFF800000u);
+        float u0 = pos_inf, u1 = neg_inf, v0 = pos_inf, v1 = neg_inf;
+        bool unordered = false;
+        if (row < n) {
+            const float u = p.cur_uv[2 * row], v = p.cur_uv[2 * row + 1];
+            unordered = isnan(u) || isnan(v);
+            if (!unordered) {
+                u0 = u1 = u;
+                v0 = v1 = v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            u0 = fminf(u0, __shfl_xor(u0, off));
+            u1 = fmaxf(u1, __shfl_xor(u1, off));
+            v0 = fminf(v0, __shfl_xor(v0, off));
+            v1 = fmaxf(v1, __shfl_xor(v1, off));
+        }
+        const int w = (int)threadIdx.x >> 6;
+        const bool any_unordered = __ballot(unordered) != 0ull;
+        if ((threadIdx.x & 63) == 0) {
+            box_part[w][0] = u0;
+            box_part[w][1] = u1;
+            box_part[w][2] = v0;
+            box_part[w][3] = v1;
+            box_part[w][4] = any_unordered ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 && ((int)blockIdx.x * 2 + (int)threadIdx.x) * 64 < n_pad) {
+            const int t = (int)threadIdx.x, wa = 2 * t, wb = 2 * t + 1;
+            float4 bx = make_float4(fminf(box_part[wa][0], box_part[wb][0]), fmaxf(box_part[wa][1], box_part[wb][1]),
+                                    fminf(box_part[wa][2], box_part[wb][2]), fmaxf(box_part[wa][3], box_part[wb][3]));
+            if (box_part[wa][4] != 0.0f || box_part[wb][4] != 0.0f) {
+                bx = make_float4(neg_inf, pos_inf, neg_inf, pos_inf);
+            }
+            p.tile_box[(int)blockIdx.x * 2 + t] = bx;
+        }
+    }
 }
 
 // ---- 2 / 3. the contraction --------------------------------------------------------------------
@@ -747,6 +789,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
 #endif
 constexpr int kRrTile = 64;        // cur rows per step
 constexpr int kRrRows = 512;       // ref rows per workgroup
+constexpr int kRrListCap = 1024;   // tiles of one workgroup's slice that the NearbyMatch tile list can hold (longer slices: no list)
 constexpr int kRrWaveStageCap = 512;  // staged entries per wave (64 rows; measured need ~3.3 per row)
 constexpr int kRrStageCap = 8 * kRrWaveStageCap;
 constexpr float kRrNone = -1.0e30f;   // scores at or below it are "no candidate": cur_info.x is -3e38 (finite, so the
@@ -761,6 +804,38 @@ constexpr float kRrNone = -1.0e30f;   // scores at or below it are "no candidate
 template <int kKSteps>
 __device__ __forceinline__ int rr_swizzle(int row) {
     return ((2 * kKSteps) % 16 == 0) ? (row & 15) : ((row >> 1) & 7);
+}
+
+// NearbyMatch only: bounding box {u min, u max, v min, v max} of the candidate pixels of every 64-row cur tile.  A
+// candidate with a NaN coordinate passes every window test (fabs(NaN) > x is false, descriptor_matcher.h:108-111), so its
+// tile gets the whole plane; a tile of padding rows only gets the empty box.
+__global__ void __launch_bounds__(64) cosine_tile_box_kernel(const CosineParams p) {
+    const int lane = threadIdx.x, j = (int)blockIdx.x * 64 + lane;
+    const float pos_inf = __uint_as_float(0x7F800000u), neg_inf = __uint_as_float(0xFF800000u);
+    float u0 = pos_inf, u1 = neg_inf, v0 = pos_inf, v1 = neg_inf;
+    bool unordered = false;
+    if (j < p.n_cur) {
+        const float u = p.cur_uv[2 * j], v = p.cur_uv[2 * j + 1];
+        unordered = isnan(u) || isnan(v);
+        if (!unordered) {
+            u0 = u1 = u;
+            v0 = v1 = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        u0 = fminf(u0, __shfl_xor(u0, off));
+        u1 = fmaxf(u1, __shfl_xor(u1, off));
+        v0 = fminf(v0, __shfl_xor(v0, off));
+        v1 = fmaxf(v1, __shfl_xor(v1, off));
+    }
+    if (__ballot(unordered) != 0ull) {
+        u0 = v0 = neg_inf;
+        u1 = v1 = pos_inf;
+    }
+    if (lane == 0) {
+        p.tile_box[blockIdx.x] = make_float4(u0, u1, v0, v1);
+    }
 }
 
 // cur row, relative to the first row of the lane's share, of accumulator element e = 16 * mt + r (32x32 MFMA C/D map)
@@ -779,6 +854,8 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_lds[];
     uint32_t *const sRun = reinterpret_cast<uint32_t *>(rr_lds);  // [512] final row maxima of this walk
     uint32_t *const sStage = sRun + kRrRows;                      // [8 waves][kRrWaveStageCap][3]
+    int *const sTiles = reinterpret_cast<int *>(sStage + 3 * kRrStageCap);  // [kRrListCap] tiles this workgroup walks (NearbyMatch)
+    float *const sBox = reinterpret_cast<float *>(sTiles + kRrListCap);     // [8 waves][4] + [1] list length
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid of row_groups x splits workgroups.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2):
@@ -800,7 +877,8 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     if (jt_begin >= jt_end) {
         return;
     }
-    const int n_tiles = jt_end - jt_begin, n_steps = n_tiles + 1;  // the first tile once more at the end (see kMode 2 above)
+    int n_tiles = jt_end - jt_begin, n_steps = n_tiles + 1;  // the first tile once more at the end (see kMode 2 above)
+    bool use_list = false;
     const float neg_inf = __uint_as_float(0xFF800000u);
     uint32_t wcount = 0u;  // entries this wave has staged (wave-uniform)
 
@@ -823,6 +901,89 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         }
     }
 
+    int list_lo = 0;
+    if (kNearby && p.tile_box != nullptr && tiles_total <= kRrListCap) {
+        // NearbyMatch: walk only the tiles whose candidates can lie in the window of SOME row of this workgroup.  Every
+        // workgroup of a row group builds the same list over ALL cur tiles and takes its n_splits-th share of it, so the
+        // listed tiles — not the raw tiles — are what is balanced over the workgroups.  Tile and
+        // workgroup bounding boxes more than window + 1 px apart on an axis cannot hold a pair that passes
+        // fabs(du) <= max_col && fabs(dv) <= max_row (the extra pixel covers the rounding of the fp32 difference; a NaN on
+        // either side makes its box the whole plane).  Exact for any input; it pays when features arrive in spatial
+        // order (detectors scan the image), where a workgroup's 512 rows see a band of the image.
+        const float pos_inf = __uint_as_float(0x7F800000u);
+        float u0 = pos_inf, u1 = neg_inf, v0 = pos_inf, v1 = neg_inf;
+        bool unordered = false;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (live[nt]) {
+                if (isnan(pu[nt]) || isnan(pv[nt])) {
+                    unordered = true;
+                } else {
+                    u0 = fminf(u0, pu[nt]);
+                    u1 = fmaxf(u1, pu[nt]);
+                    v0 = fminf(v0, pv[nt]);
+                    v1 = fmaxf(v1, pv[nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            u0 = fminf(u0, __shfl_xor(u0, off));
+            u1 = fmaxf(u1, __shfl_xor(u1, off));
+            v0 = fminf(v0, __shfl_xor(v0, off));
+            v1 = fmaxf(v1, __shfl_xor(v1, off));
+        }
+        if (__ballot(unordered) != 0ull) {
+            u0 = v0 = neg_inf;
+            u1 = v1 = pos_inf;
+        }
+        if (lane == 0) {
+            sBox[4 * wave] = u0;
+            sBox[4 * wave + 1] = u1;
+            sBox[4 * wave + 2] = v0;
+            sBox[4 * wave + 3] = v1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float wu0 = sBox[0], wu1 = sBox[1], wv0 = sBox[2], wv1 = sBox[3];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                wu0 = fminf(wu0, sBox[4 * w]);
+                wu1 = fmaxf(wu1, sBox[4 * w + 1]);
+                wv0 = fminf(wv0, sBox[4 * w + 2]);
+                wv1 = fmaxf(wv1, sBox[4 * w + 3]);
+            }
+            const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            int listed = 0;
+            for (int t0 = 0; t0 < tiles_total; t0 += 64) {
+                const int t = t0 + lane;
+                bool hit = false;
+                if (t < tiles_total) {
+                    const float4 bx = p.tile_box[t];
+                    hit = !(bx.x - wu1 > reach_u || wu0 - bx.y > reach_u || bx.z - wv1 > reach_v || wv0 - bx.w > reach_v);
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (hit) {
+                    sTiles[listed + (int)__popcll(mask & ((1ull << below) - 1ull))] = t;
+                }
+                listed += (int)__popcll(mask);
+            }
+            if (lane == 0) {
+                sBox[32] = __int_as_float(listed);
+            }
+        }
+        __syncthreads();
+        const int listed = __float_as_int(sBox[32]);
+        list_lo = (int)(((long long)split * listed) / n_splits);
+        n_tiles = (int)(((long long)(split + 1) * listed) / n_splits) - list_lo;
+        if (n_tiles == 0) {
+            return;  // nothing (left) for this workgroup: no candidate lies in any window of these rows, or fewer listed tiles than workgroups
+        }
+        n_steps = n_tiles + 1;
+        use_list = true;
+    }
+
     // transfer q of this wave fills LDS chunks [(wave * kStageVecs + q) * 64, +64); this lane's chunk L = row * kChunks + pos
     // holds global chunk pos ^ swizzle(row) of that row
     int soff0 = 0, soff1 = 0, soff2 = 0, soff3 = 0;  // half offsets into a cur tile; kStageVecs of them in use
@@ -837,7 +998,8 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         if (kStageVecs > 2) soff2 = source_of(2);
         if (kStageVecs > 3) soff3 = source_of(3);
     }
-#define FTK_RR_TILE(step_) (jt_begin + (((step_) == n_tiles) ? 0 : (step_)))
+    auto rr_tile_of = [&](int idx) { return (kNearby && use_list) ? sTiles[list_lo + idx] : jt_begin + idx; };
+#define FTK_RR_TILE(step_) rr_tile_of(((step_) == n_tiles) ? 0 : (step_))
 #define FTK_RR_FETCH(step_, SX, SINFO)                                                                                        \
     do {                                                                                                                      \
         const int jt_ = FTK_RR_TILE(step_);                                                                                   \
@@ -1163,7 +1325,7 @@ size_t cosine_rs_lds_bytes(int dim_pad) {
 
 size_t cosine_rr_lds_bytes(int dim_pad) {
     (void)dim_pad;  // the tile buffers are static arrays of the kernel instance
-    return sizeof(uint32_t) * (kRrRows + 3 * kRrStageCap);
+    return sizeof(uint32_t) * (kRrRows + 3 * kRrStageCap + kRrListCap + 40);
 }
 
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
@@ -1175,9 +1337,9 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
         return e;
     }
     // both operands in one launch: blockIdx.y selects ref / cur
+    const bool packets = (p.dim % 8) == 0 && ((reinterpret_cast<uintptr_t>(p.ref) | reinterpret_cast<uintptr_t>(p.cur)) & 15u) == 0;
     {
         const int rows = p.n_ref_pad > p.n_cur_pad ? p.n_ref_pad : p.n_cur_pad;
-        const bool packets = (p.dim % 8) == 0 && ((reinterpret_cast<uintptr_t>(p.ref) | reinterpret_cast<uintptr_t>(p.cur)) & 15u) == 0;
         if (packets) {
             hipLaunchKernelGGL(cosine_prep_pair_kernel, dim3((unsigned)((rows * 2 + 255) / 256), 2u), dim3(256), 0, stream, p);
         } else {
@@ -1186,6 +1348,9 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     }
     const int row_tiles = p.n_ref_pad / kTile;
     if (p.ref_stationary == 2) {
+        if (p.pred_uv && p.tile_box && !packets) {  // the packet-wide prep kernel has written the boxes itself
+            hipLaunchKernelGGL(cosine_tile_box_kernel, dim3((unsigned)(p.n_cur_pad / kRrTile)), dim3(64), 0, stream, p);
+        }
         const dim3 grid((unsigned)((p.n_ref_pad / kRrRows) * p.splits));
         const size_t lds = cosine_rr_lds_bytes(p.dim_pad);
 #define FTK_RR_LAUNCH(KSTEPS, NEARBY)                                                                                             \

@@ -1379,6 +1379,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     const size_t o_cur_norm = carve(sizeof(float) * (size_t)p.n_cur_pad);
     const size_t o_cur_bias = carve(sizeof(float) * (size_t)p.n_cur_pad);
     const size_t o_cur_info = carve(sizeof(float) * 4 * (size_t)p.n_cur_pad);
+    const size_t o_tile_box = carve(sizeof(float) * 4 * ((size_t)p.n_cur_pad / 64 + 1));
     const size_t o_ref_irr = carve((size_t)p.n_ref_pad);
     // row_max | cand_count | irregular_count are adjacent: ONE memset clears them (key 0 = "no candidate yet")
     const size_t o_row_max = carve(sizeof(uint32_t) * (size_t)p.n_ref_pad);
@@ -1403,6 +1404,8 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     p.cur_norm = reinterpret_cast<float *>(ws + o_cur_norm);
     p.cur_bias = reinterpret_cast<float *>(ws + o_cur_bias);
     p.cur_info = reinterpret_cast<float4 *>(ws + o_cur_info);
+    // NearbyMatch tile lists (float_matcher_kernels.hip): worth their extra launch from a few thousand candidates on
+    p.tile_box = (d_pred_uv && p.n_cur_pad / 64 >= 32) ? reinterpret_cast<float4 *>(ws + o_tile_box) : nullptr;
     p.ref_irregular = ws + o_ref_irr;
     p.row_max = reinterpret_cast<uint32_t *>(ws + o_row_max);
     p.cand_count = reinterpret_cast<uint32_t *>(ws + o_cnt);

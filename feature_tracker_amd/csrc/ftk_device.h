@@ -92,6 +92,7 @@ struct CosineParams {
     _Float16 *ref_h, *cur_h;  // unit-length fp16 copies, [n_pad][dim_pad], zero padded
     float *ref_norm, *cur_norm, *cur_bias;
     float4 *cur_info;         // {bias, u, v, 0} per (padded) cur row: what cosine_gemm_rr_kernel streams beside the tile
+    float4 *tile_box;         // NearbyMatch: {u min, u max, v min, v max} of every 64-row cur tile (cosine_tile_box_kernel); null: not used
     uint8_t *ref_irregular;
     uint32_t *row_max, *cand_count;
     int32_t *cand;            // [n_ref_pad][kCosineCandCap]

@@ -145,12 +145,18 @@ def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, c
     }
 
 
-def float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, cpu_pairs):
-    """SuperPoint-256 / DISK-128 shaped cosine matcher."""
+def float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, cpu_pairs, raster=False):
+    """SuperPoint-256 / DISK-128 shaped cosine matcher.  raster: both feature sets in the order a
+    detector scanning the image returns them (bands of 4 rows), instead of random order."""
     ref, cur, perm = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=0.2)
     rs = np.random.RandomState(11)
     cur_uv = np.stack([rs.uniform(0, 640, n_cur), rs.uniform(0, 480, n_cur)], axis=1).astype(np.float32)
     pred_uv = np.stack([rs.uniform(0, 640, n_ref), rs.uniform(0, 480, n_ref)], axis=1).astype(np.float32)
+    if raster:
+        oc = np.lexsort((cur_uv[:, 0], np.floor(cur_uv[:, 1] / 4)))
+        cur, cur_uv = np.ascontiguousarray(cur[oc]), np.ascontiguousarray(cur_uv[oc])
+        orf = np.lexsort((pred_uv[:, 0], np.floor(pred_uv[:, 1] / 4)))
+        ref, pred_uv = np.ascontiguousarray(ref[orf]), np.ascontiguousarray(pred_uv[orf])
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -334,11 +340,12 @@ def main():
 
 
 def float_matcher_cases(torch, F, D, synth, oracle, reps, quick=False):
-    for name, n_ref, n_cur, dim, nearby in (("cosine_superpoint256_10000_force", 10000, 10000, 256, False),
-                                            ("cosine_superpoint256_10000_nearby", 10000, 10000, 256, True),
-                                            ("cosine_disk128_10000_force", 10000, 10000, 128, False),
-                                            ("cosine_superpoint256_300_nearby", 300, 300, 256, True)):
-        out = float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, 2_000_000 if quick else 8_000_000)
+    for name, n_ref, n_cur, dim, nearby, raster in (("cosine_superpoint256_10000_force", 10000, 10000, 256, False, False),
+                                                    ("cosine_superpoint256_10000_nearby", 10000, 10000, 256, True, False),
+                                                    ("cosine_superpoint256_10000_nearby_raster_order", 10000, 10000, 256, True, True),
+                                                    ("cosine_disk128_10000_force", 10000, 10000, 128, False, False),
+                                                    ("cosine_superpoint256_300_nearby", 300, 300, 256, True, False)):
+        out = float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, oracle, reps, 2_000_000 if quick else 8_000_000, raster)
         print(json.dumps(out), flush=True)
 
 

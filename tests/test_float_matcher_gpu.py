@@ -247,3 +247,38 @@ def test_device_buffers_not_16_byte_aligned(ftk, oracle, dim):
         D.cosine_match_device(ctx, d_ref, d_cur, 0.5, idx)
         got = idx.cpu().numpy()
     assert np.array_equal(got, oracle.match_float(ref, cur, 0.5)[1])
+
+
+@pytest.mark.parametrize("n,dim,window", [(3000, 256, 30), (3000, 128, 8), (2500, 64, 200), (2100, 100, 25)])
+def test_nearby_match_in_spatial_order(ftk, oracle, n, dim, window):
+    """Features in raster order (what a detector scanning the image returns): a workgroup's rows see a band of the
+    image and the kernel walks only the candidate tiles whose bounding box can reach a window.  Same indices as the
+    scalar loop, including rows / candidates with NaN coordinates (which pass every window test) and a window that
+    nothing falls into."""
+    rs = np.random.RandomState(17)
+    ref, cur, perm = synth.make_float_descriptors(n, n, dim=dim, noise=0.25)
+    cur_uv = rs.uniform(0, 752, size=(n, 2)).astype(np.float32)
+    order = np.lexsort((cur_uv[:, 0], np.floor(cur_uv[:, 1] / 4)))  # raster order in bands of 4 rows
+    cur, cur_uv = cur[order], cur_uv[order]
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    pred_uv = rs.uniform(0, 752, size=(n, 2)).astype(np.float32)
+    # half of the rows predict the position of a candidate planted for them (+ a few pixels), the rest are elsewhere
+    partner = np.full(n, -1, np.int64)
+    partner[perm] = inv                     # ref row perm[j] was planted as candidate j, now at position inv[j]
+    near = (rs.rand(n) < 0.5) & (partner >= 0)
+    pred_uv[near] = cur_uv[partner[near]] + rs.uniform(-window, window, size=(int(near.sum()), 2)).astype(np.float32) * np.float32(0.8)
+    rorder = np.lexsort((pred_uv[:, 0], np.floor(pred_uv[:, 1] / 4)))
+    ref, pred_uv = ref[rorder], pred_uv[rorder]
+    pred_uv[5] = np.nan
+    pred_uv[n // 2, 1] = np.nan
+    cur_uv[7, 0] = np.nan
+    cur_uv[n - 3] = np.nan
+    for col, row in ((window, window // 2 + 1), (0, 0)):
+        m = matcher(ftk, 0.45, col=col, row=row)
+        with np.errstate(all="ignore"):
+            ok_g, g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+            ok_c, c = oracle.match_float(ref, cur, 0.45, pred_uv, cur_uv, max_col=col, max_row=row)
+        assert ok_g and ok_c
+        assert np.array_equal(g, c), (col, row, np.flatnonzero(g != c)[:10])
+    assert (c >= 0).sum() >= 1  # the NaN rows / candidates still match something at window 0
