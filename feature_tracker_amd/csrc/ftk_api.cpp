@@ -27,6 +27,8 @@ struct ftk_context {
     size_t scratch_bytes = 0;
     unsigned long long *match_keys = nullptr;
     size_t match_keys_count = 0;
+    float *match_boxes = nullptr;  // NearbyMatch bounding boxes (4 floats each)
+    size_t match_boxes_count = 0;
     // workspace of the float-descriptor matcher (fp16 copies, norms, candidate lists)
     void *cosine_ws = nullptr;
     size_t cosine_ws_bytes = 0;
@@ -119,6 +121,21 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     // all-ones = "no match yet"; the epilogue kernel restores this state after every call
     FTK_HIP(ctx, hipMemsetAsync(ctx->match_keys, 0xFF, sizeof(unsigned long long) * count, ctx->stream));
     ctx->match_keys_count = count;
+    return FTK_OK;
+}
+
+int ensure_match_boxes(ftk_context *ctx, size_t count) {
+    if (count <= ctx->match_boxes_count) {
+        return FTK_OK;
+    }
+    if (ctx->match_boxes) {
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FTK_HIP(ctx, hipFree(ctx->match_boxes));
+        ctx->match_boxes = nullptr;
+        ctx->match_boxes_count = 0;
+    }
+    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->match_boxes), sizeof(float) * 4 * count));
+    ctx->match_boxes_count = count;
     return FTK_OK;
 }
 
@@ -364,6 +381,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) {
         (void)hipFree(ctx->scratch);
+    }
+    if (ctx->match_boxes) {
+        (void)hipFree(ctx->match_boxes);
     }
     if (ctx->match_keys) {
         (void)hipFree(ctx->match_keys);
@@ -1027,6 +1047,18 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     int per = (n_cur + splits - 1) / splits;
     per = (per + 63) / 64 * 64;
     p.cur_per_block = per;
+    // NearbyMatch from a few thousand candidates on: bounding boxes for the early exit of workgroups whose candidates
+    // cannot reach any window of their rows (matcher_kernels.hip)
+    p.boxes = nullptr;
+    const bool boxes_off = getenv("FTK_MATCH_BOXES") && atoi(getenv("FTK_MATCH_BOXES")) == 0;  // experiment switch
+    if (d_pred_uv && n_bits > 0 && n_cur >= 2048 && !boxes_off) {
+        const size_t n_boxes = (size_t)row_blocks + (size_t)((n_cur + per - 1) / per);
+        const int rc = ensure_match_boxes(ctx, n_boxes);
+        if (rc != FTK_OK) {
+            return rc;
+        }
+        p.boxes = reinterpret_cast<float4 *>(ctx->match_boxes);
+    }
     FTK_HIP(ctx, ftk::match_launch(p, ctx->stream));
     return FTK_OK;
 }

@@ -77,6 +77,8 @@ struct MatchParams {
     float max_col, max_row;
     int32_t cur_per_block;  // candidates scanned by one workgroup
     int32_t keys_clean;     // keys already hold "no match" (context-owned workspace: the epilogue leaves it that way)
+    float4 *boxes;          // NearbyMatch, optional: ceil(n_ref / 512) prediction boxes, then one candidate box per split
+                            // ({u min, u max, v min, v max}; hamming_box_kernel fills them, the scan leaves early on them)
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 

@@ -93,6 +93,59 @@ __global__ void __launch_bounds__(kBlock) hamming_match_kernel(const MatchParams
     }
 }
 
+// NearbyMatch: bounding boxes {u min, u max, v min, v max} for the early exit of the tiled scan — block b < row_blocks: the
+// predictions of reference rows [512 b, 512 b + 512); block row_blocks + s: the candidates of split s.  A NaN coordinate
+// opens the box to the whole plane; no point at all leaves the empty box.
+__global__ void __launch_bounds__(kBlock) hamming_box_kernel(const MatchParams p, int row_blocks) {
+    __shared__ float part[kBlock / 64][5];
+    const float pos_inf = __uint_as_float(0x7F800000u), neg_inf = __uint_as_float(0xFF800000u);
+    float u0 = pos_inf, u1 = neg_inf, v0 = pos_inf, v1 = neg_inf;
+    bool unordered = false;
+    const bool pred = (int)blockIdx.x < row_blocks;
+    const float *uv = pred ? p.pred_uv : p.cur_uv;
+    const int first = pred ? (int)blockIdx.x * kBlock * 2 : ((int)blockIdx.x - row_blocks) * p.cur_per_block;
+    const int last = pred ? min(first + kBlock * 2, p.n_ref) : min(first + p.cur_per_block, p.n_cur);
+    for (int i = first + (int)threadIdx.x; i < last; i += kBlock) {
+        const float u = uv[2 * i], v = uv[2 * i + 1];
+        if (isnan(u) || isnan(v)) {
+            unordered = true;
+        } else {
+            u0 = fminf(u0, u);
+            u1 = fmaxf(u1, u);
+            v0 = fminf(v0, v);
+            v1 = fmaxf(v1, v);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        u0 = fminf(u0, __shfl_xor(u0, off));
+        u1 = fmaxf(u1, __shfl_xor(u1, off));
+        v0 = fminf(v0, __shfl_xor(v0, off));
+        v1 = fmaxf(v1, __shfl_xor(v1, off));
+    }
+    const bool any_unordered = __ballot(unordered) != 0ull;
+    const int w = (int)threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        part[w][0] = u0;
+        part[w][1] = u1;
+        part[w][2] = v0;
+        part[w][3] = v1;
+        part[w][4] = any_unordered ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool open_box = false;
+        for (int k = 0; k < kBlock / 64; ++k) {
+            u0 = fminf(k == 0 ? part[0][0] : u0, part[k][0]);
+            u1 = fmaxf(k == 0 ? part[0][1] : u1, part[k][1]);
+            v0 = fminf(k == 0 ? part[0][2] : v0, part[k][2]);
+            v1 = fmaxf(k == 0 ? part[0][3] : v1, part[k][3]);
+            open_box = open_box || part[k][4] != 0.0f;
+        }
+        p.boxes[blockIdx.x] = open_box ? make_float4(neg_inf, pos_inf, neg_inf, pos_inf) : make_float4(u0, u1, v0, v1);
+    }
+}
+
 // Register-tiled scan (n_bits > 0): thread i keeps kRefs reference descriptors in registers, so one
 // broadcast LDS read of a candidate feeds kRefs popcount chains, and the running best is a packed
 // integer key (distance << 16 | position in the tile) maintained with one v_lshl_or + one v_min_u32
@@ -107,6 +160,21 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
     __shared__ float2 tile_uv[kTile];
 
     const int i_base = (blockIdx.x * kBlock + threadIdx.x) * kRefs;
+    const int j_begin = blockIdx.y * p.cur_per_block;
+    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+    if (kNearby && p.boxes != nullptr) {
+        // NearbyMatch: when the bounding box of this workgroup's 512 predictions and the bounding box of its candidates
+        // (hamming_box_kernel) are more than window + 1 px apart on an axis, no pair passes
+        // fabs(du) <= max_col && fabs(dv) <= max_row (the pixel covers the rounding of the fp32 difference) and the
+        // workgroup is done before it stages a candidate.  A NaN coordinate passes every window test
+        // (descriptor_matcher.h:108-111), so it makes its box the whole plane.  Exact for any input; it pays when the
+        // features come in spatial order (a detector scanning the image), where most workgroups leave here.
+        const float4 pb = p.boxes[blockIdx.x], cb = p.boxes[gridDim.x + blockIdx.y];
+        const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
+        if (cb.x - pb.y > reach_u || pb.x - cb.y > reach_u || cb.z - pb.w > reach_v || pb.z - cb.w > reach_v) {
+            return;  // block-uniform
+        }
+    }
     uint32_t ref[kRefs][NW];
     float pred_u[kRefs], pred_v[kRefs];
 #pragma unroll
@@ -120,8 +188,6 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
         pred_u[r] = (kNearby && active) ? p.pred_uv[2 * i] : 0.0f;
         pred_v[r] = (kNearby && active) ? p.pred_uv[2 * i + 1] : 0.0f;
     }
-    const int j_begin = blockIdx.y * p.cur_per_block;
-    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
 
     uint32_t best_d[kRefs];
     int best_j[kRefs];
@@ -214,6 +280,9 @@ hipError_t launch_nw(const MatchParams &p, hipStream_t stream) {
     }
     const int row_blocks = (p.n_ref + kBlock * kRefs - 1) / (kBlock * kRefs);
     if (p.pred_uv) {
+        if (p.boxes) {
+            hipLaunchKernelGGL(hamming_box_kernel, dim3((unsigned)(row_blocks + splits)), dim3(kBlock), 0, stream, p, row_blocks);
+        }
         hipLaunchKernelGGL((hamming_match_tiled_kernel<NW, true>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
     } else {
         hipLaunchKernelGGL((hamming_match_tiled_kernel<NW, false>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);

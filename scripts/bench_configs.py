@@ -98,12 +98,17 @@ def klt_case(name, cfg, torch, F, D, synth, oracle, reps, cpu_reps, motion=(3.3,
     }
 
 
-def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, cpu_pairs):
+def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, cpu_pairs, raster=False):
     ref, cur, perm = synth.make_descriptors(n_ref, n_cur, flips=20)
-    ref_w, cur_w = F.pack_brief(ref), F.pack_brief(cur)
     rs = np.random.RandomState(11)
     cur_uv = np.stack([rs.uniform(0, 640, n_cur), rs.uniform(0, 480, n_cur)], axis=1).astype(np.float32)
     pred_uv = np.stack([rs.uniform(0, 640, n_ref), rs.uniform(0, 480, n_ref)], axis=1).astype(np.float32)
+    if raster:  # the order a detector scanning the image returns features in (bands of 4 rows)
+        oc = np.lexsort((cur_uv[:, 0], np.floor(cur_uv[:, 1] / 4)))
+        cur, cur_uv = np.ascontiguousarray(cur[oc]), np.ascontiguousarray(cur_uv[oc])
+        orf = np.lexsort((pred_uv[:, 0], np.floor(pred_uv[:, 1] / 4)))
+        ref, pred_uv = np.ascontiguousarray(ref[orf]), np.ascontiguousarray(pred_uv[orf])
+    ref_w, cur_w = F.pack_brief(ref), F.pack_brief(cur)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -310,8 +315,9 @@ def main():
             print(json.dumps(out), flush=True)
         return
     if args.only == "match":
-        for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True)):
-            print(json.dumps(matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000)), flush=True)
+        for name, n_ref, n_cur, nearby, raster in (("match_config4_force", 10000, 10000, False, False), ("match_config4_nearby", 10000, 10000, True, False),
+                                                   ("match_config4_nearby_raster_order", 10000, 10000, True, True)):
+            print(json.dumps(matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000, raster)), flush=True)
         return
     cases = []
     for key in ("config1", "config2", "config3", "config4", "config5_shard"):
@@ -330,9 +336,10 @@ def main():
         print(json.dumps(out), flush=True)
     for out in producer_cases(torch, F, D, synth, oracle, reps):
         print(json.dumps(out), flush=True)
-    for name, n_ref, n_cur, nearby in (("match_config4_force", 10000, 10000, False), ("match_config4_nearby", 10000, 10000, True),
-                                       ("match_300x300_nearby", 300, 300, True), ("match_2000_force", 2000, 2000, False)):
-        out = matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000 if args.quick else 20_000_000)
+    for name, n_ref, n_cur, nearby, raster in (("match_config4_force", 10000, 10000, False, False), ("match_config4_nearby", 10000, 10000, True, False),
+                                               ("match_config4_nearby_raster_order", 10000, 10000, True, True),
+                                               ("match_300x300_nearby", 300, 300, True, False), ("match_2000_force", 2000, 2000, False, False)):
+        out = matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000 if args.quick else 20_000_000, raster)
         print(json.dumps(out), flush=True)
     float_matcher_cases(torch, F, D, synth, oracle, reps)
     for out in direct_method_cases(torch, F, D, synth, oracle, args.quick):

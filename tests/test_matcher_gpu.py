@@ -127,3 +127,35 @@ def test_sharded_matcher_on_device_world_size_1(ftk, oracle):
         gotf = sc.match_all(d_fr, d_fc).cpu().numpy()
     assert np.array_equal(got, oracle.force_match(ref, cur, 60.0)[1])
     assert np.array_equal(gotf, oracle.match_float(fref, fcur, 0.1)[1])
+
+
+@pytest.mark.parametrize("n,n_bits,window", [(3000, 256, 30), (2500, 128, 8), (1500, 512, 200)])
+def test_nearby_match_in_spatial_order(ftk, oracle, n, n_bits, window):
+    """Features in raster order: workgroups whose candidates cannot reach any window of their rows leave before they
+    load a descriptor.  Same indices as the scalar loop, including NaN coordinates (which pass every window test) and
+    a window of zero."""
+    rs = np.random.RandomState(23)
+    ref, cur, perm = synth.make_descriptors(n, n, n_bits=n_bits, flips=max(1, n_bits // 13))
+    cur_uv = rs.uniform(0, 752, size=(n, 2)).astype(np.float32)
+    order = np.lexsort((cur_uv[:, 0], np.floor(cur_uv[:, 1] / 4)))
+    cur, cur_uv = np.ascontiguousarray(cur[order]), np.ascontiguousarray(cur_uv[order])
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    pred_uv = rs.uniform(0, 752, size=(n, 2)).astype(np.float32)
+    partner = np.full(n, -1, np.int64)
+    partner[perm] = inv
+    near = (rs.rand(n) < 0.5) & (partner >= 0)
+    pred_uv[near] = cur_uv[partner[near]] + rs.uniform(-window, window, size=(int(near.sum()), 2)).astype(np.float32) * np.float32(0.8)
+    rorder = np.lexsort((pred_uv[:, 0], np.floor(pred_uv[:, 1] / 4)))
+    ref, pred_uv = np.ascontiguousarray(ref[rorder]), np.ascontiguousarray(pred_uv[rorder])
+    pred_uv[5] = np.nan
+    pred_uv[n // 2, 1] = np.nan
+    cur_uv[7, 0] = np.nan
+    cur_uv[n - 3] = np.nan
+    for col, row in ((window, window // 2 + 1), (0, 0)):
+        m = matcher(ftk, 70.0, col=col, row=row)
+        with np.errstate(all="ignore"):
+            ok_g, g = m.NearbyMatch(ref, cur, pred_uv, cur_uv)
+            ok_c, c = oracle.nearby_match(ref, cur, pred_uv, cur_uv, 70.0, max_col=col, max_row=row)
+        assert ok_g and ok_c
+        assert np.array_equal(g, c), (col, row, np.flatnonzero(g != c)[:10])
