@@ -85,7 +85,7 @@ def klt_round():
 
 def matcher_round():
     big = ONLY == "matcher"
-    n_ref, n_cur = int(rs.choice([1, 33, 300, 1500] + ([700, 4000] if big else []))), int(rs.choice([1, 40, 257, 2000] + ([129, 5000] if big else [])))
+    n_ref, n_cur = int(rs.choice([1, 33, 300, 1500] + ([700, 4000] if big else []))), int(rs.choice([1, 40, 257, 2000] + ([129, 2500, 5000] if big else [])))
     n_bits = int(rs.choice([32, 64, 200, 256, 512]))
     ref, cur, _ = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=max(1, n_bits // int(rs.choice([8, 13, 30]))), seed=int(rs.randint(1 << 30)))
     if n_cur > 4:
@@ -94,6 +94,18 @@ def matcher_round():
     cuv = rs.uniform(0, 500, (n_cur, 2)).astype(np.float32)
     puv = rs.uniform(0, 500, (n_ref, 2)).astype(np.float32)
     win = int(rs.choice([5, 50, 600]))
+    if rs.rand() < 0.5 and n_cur > 1:  # features in raster order (what the matchers' window-aware skipping keys on), sometimes with a NaN
+        oc = np.lexsort((cuv[:, 0], np.floor(cuv[:, 1] / 4)))
+        cur, cuv = np.ascontiguousarray(cur[oc]), np.ascontiguousarray(cuv[oc])
+        orf = np.lexsort((puv[:, 0], np.floor(puv[:, 1] / 4)))
+        ref, puv = np.ascontiguousarray(ref[orf]), np.ascontiguousarray(puv[orf])
+        raster = (oc, orf)
+        if rs.rand() < 0.2:
+            cuv[rs.randint(n_cur), rs.randint(2)] = np.nan
+        if rs.rand() < 0.2:
+            puv[rs.randint(n_ref), rs.randint(2)] = np.nan
+    else:
+        raster = None
     m = F.BriefMatcher()
     m.options().kMaxValidDescriptorDistance, m.options().kMaxValidPredictColDistance, m.options().kMaxValidPredictRowDistance = thr, win, win // 2 + 1
     ok, idx = m.ForceMatch(ref, cur)
@@ -102,6 +114,8 @@ def matcher_round():
     note("match/hamming/nearby", np.array_equal(idx, O.nearby_match(ref, cur, puv, cuv, thr, win, win // 2 + 1)[1]), f"{n_ref}x{n_cur}x{n_bits} thr{thr} w{win}")
     dim = int(rs.choice([3, 32, 64, 100, 128, 192, 200, 256, 320]))
     fr, fc, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=float(rs.choice([0.1, 0.3, 1.0])), seed=int(rs.randint(1 << 30)), normalize=bool(rs.rand() < 0.5))
+    if raster is not None:
+        fc, fr = np.ascontiguousarray(fc[raster[0]]), np.ascontiguousarray(fr[raster[1]])
     if n_cur > 4:
         fc[rs.randint(n_cur)] = fc[rs.randint(n_cur)]
         if rs.rand() < 0.3:
