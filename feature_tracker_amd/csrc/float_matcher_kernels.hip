@@ -790,6 +790,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
 constexpr int kRrTile = 64;        // cur rows per step
 constexpr int kRrRows = 512;       // ref rows per workgroup
 constexpr int kRrListCap = 1024;   // tiles of one workgroup's slice that the NearbyMatch tile list can hold (longer slices: no list)
+constexpr int kRrStepEntriesMax = 192;  // most a wave can stage in one step: best + second best (+ a whole-share entry) per lane and nt... 64 rows x 3
 constexpr int kRrWaveStageCap = 512;  // staged entries per wave (64 rows; measured need ~3.3 per row)
 constexpr int kRrStageCap = 8 * kRrWaveStageCap;
 constexpr float kRrNone = -1.0e30f;   // scores at or below it are "no candidate": cur_info.x is -3e38 (finite, so the
@@ -1030,6 +1031,51 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     const int frag_row_bytes = (lane & 31) * kDimPad * 2;
     const int frag_flip = ((lane >> 5) ^ rr_swizzle<kKSteps>(lane & 31)) << 4;
 
+    // Appends the wave's staged entries to the per-row global lists and empties the stage.  An entry survives if it lies
+    // within the margin of the row's maximum SO FAR (never above the final one, so nothing that can decide is dropped; the
+    // recheck cuts against the final global maximum).  Called at the end of the walk, and inside it whenever the stage
+    // could not take another step's worth of entries — long walks (few workgroups per row group, many candidates) would
+    // otherwise overflow it and send their rows to the exact scan.  The wave's 64 rows and its stage are its own: no
+    // workgroup barrier.
+    auto flush_stage = [&]() {
+        if (lane < 32) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sRun[wave * 64 + nt * 32 + lane] = run[nt] > neg_inf ? order_key(run[nt]) : 0u;
+            }
+        }
+        const uint32_t staged = min(wcount, (uint32_t)kRrWaveStageCap);
+        const uint32_t *const stage = sStage + (size_t)wave * kRrWaveStageCap * 3;
+        const int g0 = row_group * kRrRows;
+        for (uint32_t e = (uint32_t)lane; e < staged; e += 64u) {
+            const uint32_t row_word = stage[3 * e], local = row_word & 0x7FFFFFFFu;
+            const uint32_t cur_word = stage[3 * e + 1];
+            const float score = __uint_as_float(stage[3 * e + 2]);
+            if (score >= order_value(sRun[local]) - 2.0f * kMargin) {  // sRun[local] != 0: the row staged something
+                const int i = g0 + (int)local;
+                if (row_word & 0x80000000u) {
+                    const uint32_t first = atomicAdd(&p.cand_count[i], 32u);
+                    if (first + 32u <= (uint32_t)kCosineCandCap) {
+                        const uint32_t j_best = cur_word + rr_share_offset(__float_as_uint(score) & 31u);
+                        for (uint32_t k = 0; k < 32u; ++k) {
+                            const uint32_t j = cur_word + rr_share_offset(k);
+                            // padding rows of the last tile are not candidates: their slots repeat the lane's best
+                            p.cand[(size_t)i * kCosineCandCap + first + k] = (int32_t)(j < (uint32_t)p.n_cur ? j : j_best);
+                            p.cand_score[(size_t)i * kCosineCandCap + first + k] = score;
+                        }
+                    }
+                } else {
+                    const uint32_t slot = atomicAdd(&p.cand_count[i], 1u);
+                    if (slot < (uint32_t)kCosineCandCap) {
+                        p.cand[(size_t)i * kCosineCandCap + slot] = (int32_t)cur_word;
+                        p.cand_score[(size_t)i * kCosineCandCap + slot] = score;
+                    }
+                }
+            }
+        }
+        wcount = 0u;
+    };
+
     auto rr_mfma = [&](const unsigned char *ax0) {
         // 64 cur rows x 64 ref rows x whole K: fragments of K step kk + 1 are read while the MFMAs of step kk run
 #pragma unroll
@@ -1167,6 +1213,9 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
                 run[nt] = fmaxf(run[nt], mine);
             }
         }
+        if (wcount > (uint32_t)(kRrWaveStageCap - kRrStepEntriesMax)) {  // wave-uniform, rare
+            flush_stage();
+        }
     };
 
     // The walk.  Waves 0-3 ("early") run MFMA(s) then epilogue(s) inside step s; waves 4-7 ("late") run epilogue(s - 1)
@@ -1208,46 +1257,15 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
 #undef FTK_RR_STEP
 #undef FTK_RR_FETCH
 #undef FTK_RR_TILE
-    // the wave's 64 rows and its staged entries are its own: no workgroup barrier
     if (lane < 32) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const uint32_t key = run[nt] > neg_inf ? order_key(run[nt]) : 0u;
-            sRun[wave * 64 + nt * 32 + lane] = key;
-            if (key != 0u) {  // implies live
-                atomicMax(&p.row_max[row_i[nt]], key);
+            if (run[nt] > neg_inf) {  // implies live
+                atomicMax(&p.row_max[row_i[nt]], order_key(run[nt]));
             }
         }
     }
-    const uint32_t staged = min(wcount, (uint32_t)kRrWaveStageCap);
-    const uint32_t *const wave_stage = sStage + (size_t)wave * kRrWaveStageCap * 3;
-    const int g0 = row_group * kRrRows;
-    for (uint32_t e = (uint32_t)lane; e < staged; e += 64u) {
-        const uint32_t row_word = wave_stage[3 * e], local = row_word & 0x7FFFFFFFu;
-        const uint32_t cur_word = wave_stage[3 * e + 1];
-        const float score = __uint_as_float(wave_stage[3 * e + 2]);
-        if (score >= order_value(sRun[local]) - 2.0f * kMargin) {  // sRun[local] != 0: the row staged something
-            const int i = g0 + (int)local;
-            if (row_word & 0x80000000u) {
-                const uint32_t first = atomicAdd(&p.cand_count[i], 32u);
-                if (first + 32u <= (uint32_t)kCosineCandCap) {
-                    const uint32_t j_best = cur_word + rr_share_offset(__float_as_uint(score) & 31u);
-                    for (uint32_t k = 0; k < 32u; ++k) {
-                        const uint32_t j = cur_word + rr_share_offset(k);
-                        // padding rows of the last tile are not candidates: their slots repeat the lane's best
-                        p.cand[(size_t)i * kCosineCandCap + first + k] = (int32_t)(j < (uint32_t)p.n_cur ? j : j_best);
-                        p.cand_score[(size_t)i * kCosineCandCap + first + k] = score;
-                    }
-                }
-            } else {
-                const uint32_t slot = atomicAdd(&p.cand_count[i], 1u);
-                if (slot < (uint32_t)kCosineCandCap) {
-                    p.cand[(size_t)i * kCosineCandCap + slot] = (int32_t)cur_word;
-                    p.cand_score[(size_t)i * kCosineCandCap + slot] = score;
-                }
-            }
-        }
-    }
+    flush_stage();
 }
 
 // ---- 4. exact decision -------------------------------------------------------------------------

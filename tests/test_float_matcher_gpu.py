@@ -282,3 +282,21 @@ def test_nearby_match_in_spatial_order(ftk, oracle, n, dim, window):
         assert ok_g and ok_c
         assert np.array_equal(g, c), (col, row, np.flatnonzero(g != c)[:10])
     assert (c >= 0).sum() >= 1  # the NaN rows / candidates still match something at window 0
+
+
+@pytest.mark.parametrize("splits", [None, "1"])
+def test_long_walk_over_many_candidates(ftk, oracle, monkeypatch, splits):
+    """Few reference rows against 40 000 candidates: one or two workgroups per row group walk hundreds of tiles, so a
+    wave's staging region fills several times over and is emptied inside the walk.  Random descriptors (no planted
+    partner) make every row set new maxima again and again."""
+    if splits is not None:
+        monkeypatch.setenv("FTK_COSINE_SPLITS", splits)
+    rs = np.random.RandomState(31)
+    ref = rs.standard_normal((600, 64)).astype(np.float32)
+    cur = rs.standard_normal((40000, 64)).astype(np.float32)
+    cur[12345] = ref[17] * 3.0  # one exact partner
+    ok, g = matcher(ftk, 1.0).ForceMatch(ref, cur)
+    ok_c, c = oracle.match_float(ref, cur, 1.0)
+    assert ok and ok_c
+    assert np.array_equal(g, c), np.flatnonzero(g != c)[:10]
+    assert c[17] == 12345
