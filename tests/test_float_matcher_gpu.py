@@ -300,3 +300,26 @@ def test_long_walk_over_many_candidates(ftk, oracle, monkeypatch, splits):
     assert ok and ok_c
     assert np.array_equal(g, c), np.flatnonzero(g != c)[:10]
     assert c[17] == 12345
+
+
+def test_large_set_properties(ftk):
+    """40 000 x 40 000 x 128: more tiles than the NearbyMatch tile list holds per slice is not needed here, but the walk
+    is 4 x longer per workgroup than at 10 000 and the grid has 79 row groups.  Size-independent properties: every row
+    finds its planted partner (force and, with exact predictions, nearby), and a window that excludes the partner
+    returns no match."""
+    n = 40000
+    ref, cur, perm = synth.make_float_descriptors(n, n, dim=128, noise=0.15)
+    planted = np.full(n, -1, dtype=np.int64)
+    planted[perm[::-1]] = np.arange(n)[::-1]
+    ok, idx = matcher(ftk, 0.1).ForceMatch(ref, cur)
+    assert ok and np.array_equal(idx, planted.astype(np.int32))
+    rs = np.random.RandomState(8)
+    cur_uv = rs.uniform(0, 4000, size=(n, 2)).astype(np.float32)
+    pred_uv = np.zeros((n, 2), np.float32)
+    has = planted >= 0
+    pred_uv[has] = cur_uv[planted[has]]
+    ok, idx = matcher(ftk, 0.1, col=3, row=3).NearbyMatch(ref, cur, pred_uv, cur_uv)
+    assert ok and np.array_equal(idx[has], planted[has].astype(np.int32))
+    far = pred_uv + np.float32(10000.0)
+    ok, idx = matcher(ftk, 0.1, col=3, row=3).NearbyMatch(ref, cur, far, cur_uv)
+    assert ok and (idx == -1).all()
