@@ -23,9 +23,9 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))  # the newest run (gpurun_out keeps earlier ones)
     vals = defaultdict(lambda: defaultdict(list))
     meta = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
