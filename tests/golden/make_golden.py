@@ -118,6 +118,26 @@ def generate(only=()):
     cases.append(("match_float_nearby", dict(kind="float_nearby", ref_desc=fref.astype(np.float16), cur_desc=fcur.astype(np.float16), pred_uv=puv,
                                              cur_uv=cuv, max_distance=np.float32(0.6), max_col=50, max_row=40)))
 
+    # NearbyMatch over enough candidates (>= 2 048) for the window-aware early exits of both matchers, features in raster
+    # order (bands of 4 rows), NaN coordinates on both sides (a NaN passes every window test, descriptor_matcher.h:108-111)
+    rs2 = np.random.RandomState(77)
+    n_r, n_c = 600, 2304
+    cuv2 = np.stack([rs2.uniform(0, 640, n_c), rs2.uniform(0, 480, n_c)], axis=1).astype(np.float32)
+    puv2 = np.stack([rs2.uniform(0, 640, n_r), rs2.uniform(0, 480, n_r)], axis=1).astype(np.float32)
+    oc = np.lexsort((cuv2[:, 0], np.floor(cuv2[:, 1] / 4)))
+    orf = np.lexsort((puv2[:, 0], np.floor(puv2[:, 1] / 4)))
+    b_ref, b_cur, _ = synth.make_descriptors(n_r, n_c, n_bits=64, flips=6, seed=5)
+    f_ref, f_cur, _ = synth.make_float_descriptors(n_r, n_c, dim=32, noise=0.3, seed=6)
+    cuv2, puv2 = np.ascontiguousarray(cuv2[oc]), np.ascontiguousarray(puv2[orf])
+    cuv2[100, 0] = np.nan
+    puv2[7] = np.nan
+    cases.append(("match_nearby_raster", dict(kind="nearby", ref_bits=np.ascontiguousarray(b_ref[orf]), cur_bits=np.ascontiguousarray(b_cur[oc]),
+                                              pred_uv=puv2, cur_uv=cuv2, max_distance=np.float32(40.0), max_col=60, max_row=25)))
+    f_ref16 = np.ascontiguousarray(f_ref[orf]).astype(np.float16)
+    f_cur16 = np.ascontiguousarray(f_cur[oc]).astype(np.float16)
+    cases.append(("match_float_nearby_raster", dict(kind="float_nearby", ref_desc=f_ref16, cur_desc=f_cur16, pred_uv=puv2, cur_uv=cuv2,
+                                                    max_distance=np.float32(0.7), max_col=60, max_row=25)))
+
     # DirectMethod: small scene, prediction + initial pose + status, a point behind the camera, a cap
     from tests import scenes as _scenes
     rl, cl = _scenes.scene(160, 120, 3, "easy", "similarity")
