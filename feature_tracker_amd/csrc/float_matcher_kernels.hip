@@ -878,7 +878,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     if (jt_begin >= jt_end) {
         return;
     }
-    int n_tiles = jt_end - jt_begin, n_steps = n_tiles + 1;  // the first tile once more at the end (see kMode 2 above)
+    int n_tiles = jt_end - jt_begin, n_steps = n_tiles;  // no second visit of the first tile here: see the collection below
     bool use_list = false;
     const float neg_inf = __uint_as_float(0xFF800000u);
     uint32_t wcount = 0u;  // entries this wave has staged (wave-uniform)
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         if (n_tiles == 0) {
             return;  // nothing (left) for this workgroup: no candidate lies in any window of these rows, or fewer listed tiles than workgroups
         }
-        n_steps = n_tiles + 1;
+        n_steps = n_tiles;
         use_list = true;
     }
 
@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         if (kStageVecs > 3) soff3 = source_of(3);
     }
     auto rr_tile_of = [&](int idx) { return (kNearby && use_list) ? sTiles[list_lo + idx] : jt_begin + idx; };
-#define FTK_RR_TILE(step_) rr_tile_of(((step_) == n_tiles) ? 0 : (step_))
+#define FTK_RR_TILE(step_) rr_tile_of(step_)
 #define FTK_RR_FETCH(step_, SX, SINFO)                                                                                        \
     do {                                                                                                                      \
         const int jt_ = FTK_RR_TILE(step_);                                                                                   \
@@ -1166,7 +1166,10 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
                 mine = fmaxf(__uint_as_float(halves[0]), __uint_as_float(halves[1]));
             }
 #if !(FTK_RR_DEBUG & 1)
-            if (s > 0) {
+            {
+                // the row's maximum over this tile is exact here (one wave owns the row; both halves were just joined), so the
+                // first tile collects against its own maximum and needs no second visit (the LDS-stationary kernel above,
+                // whose waves share a row through a stale LDS word, does need one)
                 const float bound = fmaxf(run[nt], mine) - 2.0f * kMargin;
                 const bool hit1 = has && m1[nt] >= bound;
                 const bool hit2 = has && m2[nt] >= bound && m2[nt] > kRrNone;
@@ -1209,9 +1212,7 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
                 }
             }
 #endif
-            if (s < n_tiles) {
-                run[nt] = fmaxf(run[nt], mine);
-            }
+            run[nt] = fmaxf(run[nt], mine);
         }
         if (wcount > (uint32_t)(kRrWaveStageCap - kRrStepEntriesMax)) {  // wave-uniform, rare
             flush_stage();
