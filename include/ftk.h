@@ -271,7 +271,9 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
  * decide a row; every deciding comparison is made on the distance evaluated in fp32 in Eigen's
  * reduction order, so index_pairs is what the scalar loop returns (ties -> lowest index, strict
  * threshold).  pred_uv == NULL selects ForceMatch.  index_pairs in/out and *matched_ok as in
- * ftk_hamming_match.
+ * ftk_hamming_match.  NearbyMatch (both matchers): blocks of (reference rows x candidates) whose
+ * bounding boxes lie farther apart than the window are skipped — same indices for any order of the
+ * features, less time when they are in spatial order (a detector scanning the image).
  */
 int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, const float *cur_desc, int32_t n_cur, int32_t dim, float max_distance,
                      const float *pred_uv, const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs,
