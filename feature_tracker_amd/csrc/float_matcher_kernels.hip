@@ -790,8 +790,8 @@ __global__ void __launch_bounds__(512) cosine_gemm_rs_kernel(const CosineParams 
 constexpr int kRrTile = 64;        // cur rows per step
 constexpr int kRrRows = 512;       // ref rows per workgroup
 constexpr int kRrListCap = 1024;   // tiles of one workgroup's slice that the NearbyMatch tile list can hold (longer slices: no list)
-constexpr int kRrStepEntriesMax = 192;  // most a wave can stage in one step: best + second best (+ a whole-share entry) per lane and nt... 64 rows x 3
-constexpr int kRrWaveStageCap = 512;  // staged entries per wave (64 rows; measured need ~3.3 per row)
+constexpr int kRrStepEntriesMax = 384;  // most a wave can stage in one step: best, second best and a whole-share entry per lane and nt (64 x 2 x 3)
+constexpr int kRrWaveStageCap = 768;  // staged entries per wave (64 rows; measured need ~3.3 per row)
 constexpr int kRrStageCap = 8 * kRrWaveStageCap;
 constexpr float kRrNone = -1.0e30f;   // scores at or below it are "no candidate": cur_info.x is -3e38 (finite, so the
                                       // index bits never turn it into a NaN) for padding / irregular cur rows
