@@ -1227,22 +1227,34 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
     // per-candidate data of step s - 1 then, hence four rotating buffers for it and the walk unrolled by four (the buffers
     // are distinct static arrays so that the compiler waits for a transfer only where its target is read).
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+#ifdef FTK_RR_STAMPS  // timing build only: cycles per phase of one early and one late wave of one workgroup, printed at the end
+    unsigned long long st_wait = 0, st_fetch = 0, st_mfma = 0, st_epi = 0, st_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_begin = st_t;
+#define FTK_RR_LAP(acc_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - st_t; st_t = n_; } while (0)
+#else
+#define FTK_RR_LAP(acc_) do { } while (0)
+#endif
 #define FTK_RR_STEP(s_, SX, SINFO, SXN, SINFON, SINFOP)                                                                     \
     {                                                                                                                         \
         if ((s_) >= n_steps) {                                                                                                \
             break; /* leaving (not skipping) keeps the accumulators out of a merge: a skipped MFMA block costs 64 copies */    \
         }                                                                                                                     \
         __syncthreads();                                                                                                      \
+        FTK_RR_LAP(st_wait);                                                                                                  \
         if ((s_) + 1 < n_steps) {                                                                                             \
             FTK_RR_FETCH((s_) + 1, SXN, SINFON);                                                                              \
         }                                                                                                                     \
+        FTK_RR_LAP(st_fetch);                                                                                                 \
         if (late && (s_) >= 1) {                                                                                              \
             rr_epilogue((s_) - 1, SINFOP);                                                                                    \
         }                                                                                                                     \
+        FTK_RR_LAP(st_epi);                                                                                                   \
         rr_mfma(reinterpret_cast<const unsigned char *>(SX) + frag_row_bytes);                                               \
+        FTK_RR_LAP(st_mfma);                                                                                                  \
         if (!late) {                                                                                                          \
             rr_epilogue(s_, SINFO);                                                                                           \
         }                                                                                                                     \
+        FTK_RR_LAP(st_epi);                                                                                                   \
     }
     FTK_RR_FETCH(0, sXa, sInfo0);
     for (int s = 0;; s += 4) {
@@ -1267,6 +1279,13 @@ __global__ void __launch_bounds__(512) cosine_gemm_rr_kernel(const CosineParams 
         }
     }
     flush_stage();
+#ifdef FTK_RR_STAMPS
+    if (blockIdx.x == 100 && lane == 0 && (wave == 0 || wave == 4)) {
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - st_begin;
+        printf("rr stamps wave %d steps %d: wait %llu fetch %llu mfma %llu epilogue %llu (in loop) total %llu cycles (s_memtime ticks)\n", wave, n_steps,
+               st_wait, st_fetch, st_mfma, st_epi, total);
+    }
+#endif
 }
 
 // ---- 4. exact decision -------------------------------------------------------------------------
