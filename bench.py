@@ -11,12 +11,19 @@ N > 1 the RCCL all-gather of every rank's packed result shard.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
-  roofline     : algorithmic bytes of the tracker kernel / its average launch duration (HIP events
-                 on the launch stream) against the 8 TB/s HBM peak; traffic = PMC-derived bytes per
-                 launch when profiles/ holds a counter summary, else null.
-  cpu_baseline : the oracle (CPU restatement, single thread) timed on a bounded sample of the same
-                 workload on this host.
+Rank 0 prints one JSON line (contract in the task statement) with these extra objects:
+  roofline      : algorithmic bytes of the tracker kernel / its average launch duration against the
+                  8 TB/s HBM peak (the bound north_star names); traffic = PMC-derived HBM bytes per
+                  launch from the committed counter summary under profiles/, else null.
+  roofline_valu : the bound that actually binds this kernel — vector-ALU issue: SQ_INSTS_VALU per
+                  launch (committed PMC summary) / kernel time against 1024 SIMDs x 2.4 GHz / 2 cycles
+                  per wave64 instruction (MI355X_MICROARCH.md, cycle constants).
+  parity        : px-error vs CPU (BASELINE.json's metric): the first step's (u, v, status) of the
+                  device path against the oracle on the same inputs.
+  cpu_baseline  : the oracle (CPU restatement, single thread) timed on a bounded sample of the same
+                  workload on this host.
+The timed region contains ONLY the K steps (no event records); the kernel duration for the roofline
+objects comes from a separate pass of the same launches bracketed by HIP events on the launch stream.
 """
 from __future__ import annotations
 
@@ -45,28 +52,55 @@ def algorithmic_bytes(iters: np.ndarray, levels: int, half: int, method: str) ->
     return int(iters.size * (levels * r + 26) + int(iters.astype(np.int64).sum()) * c)
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if present."""
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz
+
+
+def pmc_profile(workload: str) -> dict:
+    """Counter-derived per-launch figures of the workload's tracker kernel from the committed rocprofv3 PMC summary
+    (profiles/pmc_traffic.json, written by scripts/summarize_profile.py from separate --pmc passes): HBM bytes
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and vector-ALU wave-instructions.  Empty when nothing is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("klt_config2_bytes_per_launch")
+            d = json.load(f)
     except Exception:
-        return None
+        return {}
+    w = d.get("workloads", {}).get(workload)
+    if w:
+        return w
+    if workload == "config2" and "klt_config2_bytes_per_launch" in d:  # round-1 layout
+        return {"bytes_per_launch": d["klt_config2_bytes_per_launch"], "source": d.get("source")}
+    return {}
 
 
-def cpu_baseline(cfg, ref_levels, cur_levels, uv, budget_s=12.0):
-    """Times the oracle on this host: single thread (the reference has no threads), whole 2000-feature
-    calls repeated until ~budget_s of CPU work, median per-call time."""
+def parity_report(gpu_uv, gpu_st, cpu_uv, cpu_st) -> dict:
+    """px-error vs CPU: |d(u, v)| per feature (Euclidean, over features whose CPU result is finite) and status mismatches."""
+    finite = np.isfinite(cpu_uv).all(axis=1)
+    d = np.linalg.norm(gpu_uv[finite].astype(np.float64) - cpu_uv[finite].astype(np.float64), axis=1) if finite.any() else np.zeros(0)
+    return {
+        "max_px": float(d.max()) if d.size else 0.0, "p99_px": float(np.percentile(d, 99)) if d.size else 0.0,
+        "frac_gt_1e-3": float((d > 1e-3).mean()) if d.size else 0.0, "status_mismatches": int((gpu_st != cpu_st).sum()),
+        "bit_identical": bool(np.array_equal(gpu_uv.view(np.uint32), cpu_uv.view(np.uint32)) and np.array_equal(gpu_st, cpu_st)),
+        "features": int(cpu_st.size), "tolerance_px": 1e-3, "against": "oracle/liboracle.so (CPU restatement, parity unpinned)",
+    }
+
+
+def oracle_once(cfg, ref_levels, cur_levels, uv):
     from tests import oracle_lib
 
     oracle_lib.lib()
+    t0 = time.perf_counter()
+    ok, c, s, it = oracle_lib.klt_track_pyramid(cfg["model"], ref_levels, cur_levels, uv, method=cfg["method"], half=cfg["half"], max_points=cfg["n"])
+    return c, s, it, time.perf_counter() - t0
+
+
+def cpu_baseline(cfg, ref_levels, cur_levels, uv, budget_s=12.0):
+    """Times the oracle on this host: single thread (the reference has no threads), whole-workload
+    calls repeated until ~budget_s of CPU work, median per-call time."""
     times = []
     t_all = time.perf_counter()
     while True:
-        t0 = time.perf_counter()
-        oracle_lib.klt_track_pyramid(cfg["model"], ref_levels, cur_levels, uv, method=cfg["method"], half=cfg["half"], max_points=cfg["n"])
-        times.append(time.perf_counter() - t0)
+        times.append(oracle_once(cfg, ref_levels, cur_levels, uv)[3])
         if time.perf_counter() - t_all > budget_s or len(times) >= 200:
             break
     med = float(np.median(times))
@@ -115,6 +149,12 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         elapsed = time.perf_counter() - t0
         guv, gst = FD.unpack_gathered(sharded.gathered, n, world)
         tracked = float((gst == 1).float().mean().item())
+        # result check: the gathered result must equal ONE unsharded launch over all n features on this rank, bit for bit
+        d_all, d_all_st = torch.empty_like(d_ref), torch.empty_like(d_st)
+        klt.track(d_ref, d_in, d_st, d_all, d_all_st, None)
+        torch.cuda.synchronize()
+        gathered_ok = bool(torch.equal(guv.view(torch.int32), d_all.view(torch.int32)) and torch.equal(gst, d_all_st))
+        assert gathered_ok, "gathered sharded result differs from the unsharded launch"
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -125,7 +165,8 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg['model']} KLT {cfg['method']}, {n} features in total sharded x{world}, {w}x{h}, {levels}-level pyramid, "
-                                   f"{2 * half + 1}x{2 * half + 1} patch", "tracked_fraction": tracked}}), flush=True)
+                                   f"{2 * half + 1}x{2 * half + 1} patch", "tracked_fraction": tracked,
+                       "gathered_equals_unsharded_bitwise": gathered_ok}}), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
@@ -217,13 +258,14 @@ def main():
             step()
         stream.synchronize()
 
+        first_uv, first_st = d_cur_out.cpu().numpy().copy(), status.copy()  # the first step's result, for the parity object
         launches = [klt.bind(d_ref, d_cur_in, d_st_in, views2[slot][0], views2[slot][1], None) for slot in range(2)]
-        # kernel-only duration: HIP events on the launch stream around tracker launches INSIDE the timed region.
-        # Every launch of a short run is bracketed; from 32 steps on every 4th one is (an event pair costs about as
-        # much queue time as a tenth of this kernel, and the sampled launches are the same kernel on the same data).
-        ev_stride = 1 if args.steps < 32 else 4
-        ev0 = {k: torch.cuda.Event(enable_timing=True) for k in range(0, args.steps, ev_stride)}
-        ev1 = {k: torch.cuda.Event(enable_timing=True) for k in range(0, args.steps, ev_stride)}
+        # kernel-only duration (roofline objects): HIP events on the launch stream around the same launches on the same
+        # data in a SEPARATE pass after the timed region — an event pair costs about a tenth of this kernel in queue
+        # time, so none is recorded between the K timed steps at any step count.
+        n_ev = max(10, min(args.steps, 50))
+        ev0 = {k: torch.cuda.Event(enable_timing=True) for k in range(n_ev)}
+        ev1 = {k: torch.cuda.Event(enable_timing=True) for k in range(n_ev)}
 
         # N > 1: every step is the tracker kernel followed by the RCCL all-gather of its packed result shard.  The
         # K steps are captured ONCE into a HIP graph in which the gather of step k runs on a side stream beside the
@@ -287,26 +329,19 @@ def main():
         else:
             for k in range(args.steps):
                 slot = k & 1
-                if k in ev0:
-                    ev0[k].record(stream)
-                    launches[slot]()
-                    ev1[k].record(stream)
-                else:
-                    launches[slot]()
+                launches[slot]()
                 if use_dist:
                     FD.all_gather_results(packed2[slot], world, force_collective=True, out=gathered2[slot])
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if graph is not None:
-            # events cannot be timed inside a captured graph: the kernel duration for the roofline line is taken from a
-            # short eager pass right after the timed region (same launches, same data)
-            for k in ev0:
-                ev0[k].record(stream)
-                launches[k & 1]()
-                ev1[k].record(stream)
-            torch.cuda.synchronize()
+        # kernel duration for the roofline objects: a short eager pass right after the timed region (same launches, same data)
+        for k in ev0:
+            ev0[k].record(stream)
+            launches[k & 1]()
+            ev1[k].record(stream)
+        torch.cuda.synchronize()
         if use_dist:
             # every rank must now hold every rank's result shard: spot-check the own shard inside the gathered buffer
             per = FD.packed_bytes(n)
@@ -324,6 +359,9 @@ def main():
         value = total_features / elapsed
         algo = algorithmic_bytes(iters, levels, half, cfg["method"])
         achieved = algo / (kernel_ms * 1e-3) / 1e9
+        pmc = pmc_profile(args.workload) if args.features == 0 else {}
+        kernel_name = "klt_basic_inverse_pipelined_kernel" if (cfg["model"], cfg["method"]) == ("basic", "inverse") else f"klt_track_kernel<{cfg['model']}, {cfg['method']}>"
+        cpu_uv, cpu_st, cpu_it, _ = oracle_once(cfg, ref_levels, cur_levels, uv)
         out = {
             "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": value, "unit": "tracked features/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -334,11 +372,16 @@ def main():
                        if use_dist else "single GPU",
                        "tracked_fraction": float((status == 1).mean()), "mean_iterations_per_feature": float(iters.mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(),
-                         "kernel": "klt_basic_inverse_pipelined_kernel" if (cfg["model"], cfg["method"]) == ("basic", "inverse") else "klt_track_kernel",
-                         "kernel_ms": kernel_ms, "kernel_launches_timed": len(ev0),
+                         "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "kernel_launches_timed": len(ev0),
                          "algorithmic_bytes_per_launch": algo},
+            "parity": dict(parity_report(first_uv, first_st, cpu_uv, cpu_st), iteration_counts_equal=bool(np.array_equal(iters, cpu_it))),
         }
+        if pmc.get("valu_insts_per_launch"):
+            valu = pmc["valu_insts_per_launch"] / (kernel_ms * 1e-3)
+            out["roofline_valu"] = {"bound": "valu_issue", "achieved": valu, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
+                                    "frac": valu / VALU_PEAK_WAVE_INSTS_PER_S, "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                                    "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "source": pmc.get("source")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
         print(json.dumps(out), flush=True)

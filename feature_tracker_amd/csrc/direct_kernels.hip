@@ -116,7 +116,9 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
     const bool consumer = wave == 0;
     float *const ring = reinterpret_cast<float *>(dm_lds);                   // [2][kDmProducers][kDmTerms][kDmRow]
     float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;         // [96]: 27 sums | H 6x6 at 32 | dx at 68
-    float *const feat = sums + 96;                                           // [n_track][4]: cur u, cur v, usable, -
+    // [n_track][4]: cur u, cur v, usable, - ; in LDS, or in device memory for problems too large for it (written and read
+    // by this workgroup only, with a workgroup barrier in between)
+    float4 *const feat = pr.feat != nullptr ? pr.feat : reinterpret_cast<float4 *>(sums + 96);
     const int n = pr.n;
     const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
     const int P = pp.patch_rows * pp.patch_cols;
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                             pr.cur_uv[2 * i + 1] = cv;
                         }
                     }
-                    reinterpret_cast<float4 *>(feat)[i] = make_float4(cu, cv, usable ? 1.0f : 0.0f, 0.0f);
+                    feat[i] = make_float4(cu, cv, usable ? 1.0f : 0.0f, 0.0f);
                 }
                 __syncthreads();
 
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                             const int i = (int)(g / P);
                             const int pix = (int)(g - (long long)i * P);
                             const int prow = pix / pp.patch_cols, pcol = pix - prow * pp.patch_cols;
-                            const float4 f = reinterpret_cast<const float4 *>(feat)[i];
+                            const float4 f = feat[i];
                             if (f.z != 0.0f) {
                                 const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
                                 const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -18,6 +19,11 @@
 using ftk::DevImage;
 
 struct ftk_context {
+    // Every entry point that takes a context holds this lock for its whole duration: the scratch / pinned / workspace
+    // buffers below are reused (and regrown) by every call, so calls on ONE context from several threads — e.g. the
+    // left and right tracker objects of a stereo front end, which share the process-wide context of the C++ classes —
+    // are serialised here instead of racing on them.  Recursive: the host-buffer wrappers call the *_device entries.
+    std::recursive_mutex lock;
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -35,6 +41,12 @@ struct ftk_context {
     // problem table of the direct-method launches
     void *direct_table = nullptr;
     size_t direct_table_bytes = 0;
+    // per-feature projection tables of direct-method problems too large for LDS (16 B per tracked feature)
+    void *direct_feat = nullptr;
+    size_t direct_feat_bytes = 0;
+    // zero-padded copies of descriptors whose width is not a power of two (device-resident matcher entry)
+    void *match_pad = nullptr;
+    size_t match_pad_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -155,6 +167,25 @@ int ensure_cosine_ws(ftk_context *ctx, size_t bytes) {
     return FTK_OK;
 }
 
+// Grows a context-owned device buffer (stream-synchronising first: earlier launches may still read the old one).
+int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) {
+    if (bytes <= *have) {
+        return FTK_OK;
+    }
+    if (*buf) {
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FTK_HIP(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4, 4096);
+    FTK_HIP(ctx, hipMalloc(buf, want));
+    *have = want;
+    return FTK_OK;
+}
+
+#define FTK_LOCK(ctx) std::lock_guard<std::recursive_mutex> ftk_lock_guard_((ctx)->lock)
+
 uint32_t div_magic(int32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, int32_t n,
@@ -188,9 +219,6 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     for (int i = 0; i < p.n_levels; ++i) {
         p.ref[i] = ref->levels[i];
         p.cur[i] = cur->levels[i];
-        if (p.ref[i].rows < 2 || p.ref[i].cols < 2 || p.cur[i].rows < 2 || p.cur[i].cols < 2) {
-            return fail(ctx, FTK_E_UNSUPPORTED, "klt: pyramid level %d smaller than 2x2", i);
-        }
     }
     p.n = n;
     p.n_track = ((uint32_t)n < opt->max_track_points) ? (uint32_t)n : opt->max_track_points;
@@ -394,6 +422,12 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->direct_table) {
         (void)hipFree(ctx->direct_table);
     }
+    if (ctx->direct_feat) {
+        (void)hipFree(ctx->direct_feat);
+    }
+    if (ctx->match_pad) {
+        (void)hipFree(ctx->match_pad);
+    }
     if (ctx->pinned) {
         (void)hipHostFree(ctx->pinned);
     }
@@ -412,6 +446,7 @@ int ftk_synchronize(ftk_context *ctx) {
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "synchronize: null context");
     }
+    FTK_LOCK(ctx);
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
 }
@@ -422,6 +457,7 @@ int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_upload: null context");
     }
+    FTK_LOCK(ctx);
     int rc = check_levels(ctx, host_levels, n_levels);
     if (rc != FTK_OK) {
         return rc;
@@ -473,6 +509,7 @@ int ftk_pyramid_wrap_device(ftk_context *ctx, const ftk_image *device_levels, in
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_wrap_device: null context");
     }
+    FTK_LOCK(ctx);
     int rc = check_levels(ctx, device_levels, n_levels);
     if (rc != FTK_OK) {
         return rc;
@@ -497,6 +534,7 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_build: null context");
     }
+    FTK_LOCK(ctx);
     if (!image || rows <= 0 || cols <= 0 || n_levels < 1 || n_levels > FTK_MAX_LEVELS || !out) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_build: bad image or level count");
     }
@@ -575,6 +613,7 @@ int ftk_pyramid_download_level(ftk_context *ctx, const ftk_pyramid *pyr, int32_t
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_download_level: null context");
     }
+    FTK_LOCK(ctx);
     if (!pyr || !host_out || level < 0 || level >= pyr->n_levels) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_download_level: bad arguments");
     }
@@ -603,6 +642,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "klt_track_device: null context");
     }
+    FTK_LOCK(ctx);
     if (n < 0) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track_device: negative feature count");
     }
@@ -683,6 +723,7 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "klt_track: null context");
     }
+    FTK_LOCK(ctx);
     if (n < 0) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track: negative feature count");
     }
@@ -765,6 +806,7 @@ int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t l
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "extract_extend_patch: null context");
     }
+    FTK_LOCK(ctx);
     if (!ref || level < 0 || level >= ref->n_levels || ex_rows <= 0 || ex_cols <= 0 || !ex_patch || !valid || !valid_count) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "extract_extend_patch: bad arguments");
     }
@@ -818,6 +860,7 @@ int ftk_brief_compute_device(ftk_context *ctx, const ftk_pyramid *image, int32_t
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "brief_compute_device: null context");
     }
+    FTK_LOCK(ctx);
     if (!image || level < 0 || level >= image->n_levels || n < 0 || n_bits <= 0 || half_patch <= 0 || half_patch > 63) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute_device: bad arguments (n %d, bits %d, half %d)", n, n_bits, half_patch);
     }
@@ -850,6 +893,7 @@ int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "brief_compute: null context");
     }
+    FTK_LOCK(ctx);
     if (n < 0 || n_bits <= 0) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute: bad sizes");
     }
@@ -937,6 +981,7 @@ int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t leve
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_response: null context");
     }
+    FTK_LOCK(ctx);
     if (!response) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris_response: null buffer");
     }
@@ -948,6 +993,7 @@ int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_detect: null context");
     }
+    FTK_LOCK(ctx);
     if (!n_out || max_count < 0 || (max_count > 0 && !uv)) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "harris_detect: bad output arguments");
     }
@@ -987,14 +1033,15 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "hamming_match_device: null context");
     }
+    FTK_LOCK(ctx);
     if (n_ref < 0 || n_cur < 0 || n_bits < 0) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: negative size");
     }
     if (n_ref == 0 || n_cur == 0) {
         return FTK_OK;
     }
-    if (!supported_words(n_words)) {
-        return fail(ctx, FTK_E_UNSUPPORTED, "hamming_match_device: n_words must be 1, 2, 4, 8 or 16 (got %d); zero-pad the descriptors", n_words);
+    if (n_words < 1) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: n_words %d < 1", n_words);
     }
     if (n_bits > 32 * n_words) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: n_bits %d exceeds %d words", n_bits, n_words);
@@ -1003,6 +1050,31 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match_device: null buffer");
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
+    // The register-tiled scan exists for 1, 2, 4, 8 and 16 words per descriptor.  Other widths up to 16 words are
+    // zero-padded on the device into a context-owned copy (equal pad bits in both sets: same distances); wider
+    // descriptors take the generic scan (matcher_kernels.hip), which reads any width.  Same indices either way.
+    if (!supported_words(n_words) && n_words < 16) {
+        int dev_words = 1;
+        while (dev_words < n_words) {
+            dev_words *= 2;
+        }
+        const size_t ref_bytes = align_up(sizeof(uint32_t) * (size_t)n_ref * dev_words, 256);
+        const size_t cur_bytes = align_up(sizeof(uint32_t) * (size_t)n_cur * dev_words, 256);
+        const int rc = ensure_device_buffer(ctx, &ctx->match_pad, &ctx->match_pad_bytes, ref_bytes + cur_bytes);
+        if (rc != FTK_OK) {
+            return rc;
+        }
+        uint32_t *pad_ref = static_cast<uint32_t *>(ctx->match_pad);
+        uint32_t *pad_cur = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(ctx->match_pad) + ref_bytes);
+        FTK_HIP(ctx, hipMemsetAsync(ctx->match_pad, 0, ref_bytes + cur_bytes, ctx->stream));
+        FTK_HIP(ctx, hipMemcpy2DAsync(pad_ref, sizeof(uint32_t) * dev_words, d_ref_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
+                                      (size_t)n_ref, hipMemcpyDeviceToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpy2DAsync(pad_cur, sizeof(uint32_t) * dev_words, d_cur_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
+                                      (size_t)n_cur, hipMemcpyDeviceToDevice, ctx->stream));
+        d_ref_words = pad_ref;
+        d_cur_words = pad_cur;
+        n_words = dev_words;
+    }
     int p_keys_clean = 0;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(d_workspace);
     p_keys_clean = 0;
@@ -1069,10 +1141,11 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "hamming_match: null context");
     }
+    FTK_LOCK(ctx);
     if (matched_ok) {
         *matched_ok = 0;
     }
-    if (n_ref < 0 || n_cur < 0 || n_words < 1 || n_words > 16 || n_bits < 0 || n_bits > 32 * n_words) {
+    if (n_ref < 0 || n_cur < 0 || n_words < 1 || n_bits < 0 || n_bits > 32 * n_words) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "hamming_match: bad sizes (n_ref %d, n_cur %d, n_words %d, n_bits %d)", n_ref, n_cur, n_words, n_bits);
     }
     if (n_cur == 0) {
@@ -1089,8 +1162,11 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
     int dev_words = 1;
-    while (dev_words < n_words) {
+    while (dev_words < n_words && dev_words < 16) {
         dev_words *= 2;
+    }
+    if (n_words > 16) {
+        dev_words = n_words;  // wider than any register-tiled instantiation: the generic scan reads the width as it is
     }
     const size_t ref_bytes = align_up(sizeof(uint32_t) * (size_t)n_ref * dev_words, 256);
     const size_t cur_bytes = align_up(sizeof(uint32_t) * (size_t)n_cur * dev_words, 256);
@@ -1140,6 +1216,7 @@ int ftk_ldlt6_solve(ftk_context *ctx, const float *a, const float *b, float *x, 
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "ldlt6_solve: null context");
     }
+    FTK_LOCK(ctx);
     if (n < 0 || (n > 0 && (!a || !b || !x))) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "ldlt6_solve: bad arguments");
     }
@@ -1181,6 +1258,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "direct_track: null context");
     }
+    FTK_LOCK(ctx);
     if (!opt || n_problems < 0 || (n_problems > 0 && !problems)) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: null options / problems");
     }
@@ -1214,9 +1292,6 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         for (int i = 0; i < n_levels; ++i) {
             out.ref[i] = in.ref->levels[i];
             out.cur[i] = in.cur->levels[i];
-            if (out.ref[i].rows < 2 || out.ref[i].cols < 2 || out.cur[i].rows < 2 || out.cur[i].cols < 2) {
-                return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: pyramid level %d smaller than 2x2", i);
-            }
         }
         for (int i = 0; i < 4; ++i) {
             out.K[i] = in.K[i];
@@ -1232,10 +1307,21 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         const uint32_t tracked = ((uint32_t)in.n < opt->max_track_points) ? (uint32_t)in.n : opt->max_track_points;
         max_features = std::max(max_features, tracked);
     }
-    if (max_features > 3072) {
-        return fail(ctx, FTK_E_UNSUPPORTED, "direct_track: %u tracked features in one problem (limit 3072); lower kMaxTrackPointsNumber", max_features);
-    }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
+    // The per-feature projections of an iteration live in LDS while they fit beside the product ring (16 B per tracked
+    // feature, up to kDirectLdsFeatures); larger problems keep that table in a context-owned device buffer instead —
+    // same kernel, same arithmetic, same order of the sums.
+    const bool feat_in_global = max_features > ftk::kDirectLdsFeatures;
+    if (feat_in_global) {
+        const size_t per = align_up(sizeof(float) * 4 * (size_t)max_features, 256);
+        const int rc = ensure_device_buffer(ctx, &ctx->direct_feat, &ctx->direct_feat_bytes, per * (size_t)n_problems);
+        if (rc != FTK_OK) {
+            return rc;
+        }
+        for (int32_t k = 0; k < n_problems; ++k) {
+            host[(size_t)k].feat = reinterpret_cast<float4 *>(static_cast<uint8_t *>(ctx->direct_feat) + per * (size_t)k);
+        }
+    }
     // the problem table travels through a context-owned device buffer (separate from the scratch the host-buffer wrapper uses)
     const size_t table_bytes = sizeof(ftk::DirectProblem) * (size_t)n_problems;
     if (table_bytes > ctx->direct_table_bytes) {
@@ -1262,7 +1348,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     p.patch_cols = 2 * opt->half_cols + 1;
     p.converge = opt->max_converge_step;
     p.method = opt->method;
-    FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, max_features, ctx->stream));
+    FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, feat_in_global ? 0u : max_features, ctx->stream));
     return FTK_OK;
 }
 
@@ -1272,6 +1358,7 @@ int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "direct_track: null context");
     }
+    FTK_LOCK(ctx);
     if (n < 0) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "direct_track: negative feature count");
     }
@@ -1349,6 +1436,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "cosine_match_device: null context");
     }
+    FTK_LOCK(ctx);
     if (n_ref < 0 || n_cur < 0 || dim < 1) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "cosine_match_device: bad sizes (n_ref %d, n_cur %d, dim %d)", n_ref, n_cur, dim);
     }
@@ -1457,6 +1545,7 @@ int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, con
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "cosine_match: null context");
     }
+    FTK_LOCK(ctx);
     if (matched_ok) {
         *matched_ok = 0;
     }

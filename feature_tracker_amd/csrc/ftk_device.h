@@ -129,7 +129,9 @@ struct DirectProblem {
     uint32_t *iterations;   // optional: Gauss-Newton iterations over all levels
     int32_t n;
     int32_t status_valid;   // 0: reset every status to kTracked first (direct_method_tracker.cpp:73-75)
+    float4 *feat;           // null: the per-feature projection table lives in LDS; else n_track entries of device memory (large problems)
 };
+constexpr uint32_t kDirectLdsFeatures = 3072;  // tracked features whose projection table still fits in LDS beside the ring
 struct DirectParams {
     const DirectProblem *problems;  // device memory, one per workgroup
     int32_t n_levels;

@@ -93,6 +93,45 @@ __global__ void __launch_bounds__(kBlock) hamming_match_kernel(const MatchParams
     }
 }
 
+// Any descriptor width (n_words at run time; used above 16 words, where no register-tiled instantiation exists): the
+// reference's scan as written, thread i against candidates [j_begin, j_end) in ascending j, words straight from
+// global memory (every lane reads the same candidate: one request per wave).
+__global__ void __launch_bounds__(kBlock) hamming_match_generic_kernel(const MatchParams p) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.n_ref) {
+        return;
+    }
+    const bool nearby = p.pred_uv != nullptr;
+    const int nw = p.n_words;
+    const uint32_t *ref = p.ref_words + (long long)i * nw;
+    const float pred_u = nearby ? p.pred_uv[2 * i] : 0.0f, pred_v = nearby ? p.pred_uv[2 * i + 1] : 0.0f;
+    const int j_begin = blockIdx.y * p.cur_per_block;
+    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+    float min_distance = p.max_distance;
+    unsigned best_d = 0xFFFFFFFFu;
+    int best_j = -1;
+    for (int j = j_begin; j < j_end; ++j) {
+        if (nearby && (fabsf(pred_u - p.cur_uv[2 * j]) > p.max_col || fabsf(pred_v - p.cur_uv[2 * j + 1]) > p.max_row)) {
+            continue;
+        }
+        const uint32_t *cur = p.cur_words + (long long)j * nw;
+        unsigned d = 0;
+        for (int w = 0; w < nw; ++w) {
+            d += __popc(ref[w] ^ cur[w]);
+        }
+        const unsigned du = (p.n_bits == 0) ? 0x7FFFFFFFu : d;
+        const float distance = (p.n_bits == 0) ? 2147483648.0f : (float)d;
+        if (distance < min_distance && distance < p.max_distance) {
+            min_distance = distance;
+            best_d = du;
+            best_j = j;
+        }
+    }
+    if (best_j >= 0) {
+        atomicMin(&p.keys[i], ((unsigned long long)best_d << 32) | (unsigned)best_j);
+    }
+}
+
 // NearbyMatch: bounding boxes {u min, u max, v min, v max} for the early exit of the tiled scan — block b < row_blocks: the
 // predictions of reference rows [512 b, 512 b + 512); block row_blocks + s: the candidates of split s.  A NaN coordinate
 // opens the box to the whole plane; no point at all leaves the empty box.
@@ -309,7 +348,12 @@ hipError_t match_launch(const MatchParams &p, hipStream_t stream) {
         case 4: e = launch_nw<4>(p, stream); break;
         case 8: e = launch_nw<8>(p, stream); break;
         case 16: e = launch_nw<16>(p, stream); break;
-        default: return hipErrorInvalidValue;
+        default: {
+            const int splits = (p.n_cur + p.cur_per_block - 1) / p.cur_per_block;
+            hipLaunchKernelGGL(hamming_match_generic_kernel, dim3((p.n_ref + kBlock - 1) / kBlock, splits), dim3(kBlock), 0, stream, p);
+            e = hipGetLastError();
+            break;
+        }
     }
     if (e != hipSuccess) {
         return e;

@@ -86,10 +86,20 @@ class DeviceKlt:
 
         return launch
 
-    def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None):
+    @property
+    def max_track_points(self) -> int:
+        """kMaxTrackPointsNumber of this tracker's options (the GLOBAL cap when the feature list is sharded)."""
+        return int(self.opt.max_track_points)
+
+    def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None, max_track_points=None):
+        """``max_track_points`` overrides the options' cap for this launch (a shard's share of the global cap)."""
         n = ref_uv.shape[0]
+        opt = self.opt
+        if max_track_points is not None and int(max_track_points) != int(opt.max_track_points):
+            opt = N.KltOptions.from_buffer_copy(self.opt)
+            opt.max_track_points = int(max_track_points)
         rc = N.lib().ftk_klt_track_device(
-            self.ctx.handle, self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, C.c_void_p(ref_uv.data_ptr()),
+            self.ctx.handle, self.model, C.byref(opt), self.ref_pyr.handle, self.cur_pyr.handle, C.c_void_p(ref_uv.data_ptr()),
             C.c_void_p(cur_uv_in.data_ptr()), C.c_void_p(cur_uv_out.data_ptr()), C.c_void_p(status_in.data_ptr()),
             C.c_void_p(status_out.data_ptr()), n, None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single,
             None if iters is None else C.c_void_p(iters.data_ptr()))

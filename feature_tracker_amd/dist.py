@@ -84,14 +84,22 @@ class ShardedKlt:
     its packed shard, and one all-gather gives every rank the complete result in the original feature
     order — identical to the single-GPU result because features do not interact.
 
-    ``tracker`` is any object with ``track(ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters)``
-    on torch tensors (``feature_tracker_amd.device.DeviceKlt`` on GPUs).
+    ``kMaxTrackPointsNumber`` is a GLOBAL cap in the reference (only features [0, cap) are tracked,
+    basic_klt.cpp:9), so rank r tracks the first ``clamp(cap - begin, 0, m)`` features of its block and
+    passes the rest through, exactly as the unsharded call does.
+
+    ``tracker`` is any object with ``track(ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters,
+    max_track_points=None)`` on torch tensors (``feature_tracker_amd.device.DeviceKlt`` on GPUs);
+    ``max_track_points`` (default: the tracker's own ``max_track_points`` attribute, i.e. its options) is the
+    global cap.
     """
 
-    def __init__(self, tracker, n: int, device, world_size: int = 1, rank: int = 0, group=None):
+    def __init__(self, tracker, n: int, device, world_size: int = 1, rank: int = 0, group=None, max_track_points=None):
         import torch
 
         self.tracker, self.n, self.world, self.rank, self.group = tracker, int(n), int(world_size), int(rank), group
+        cap = max_track_points if max_track_points is not None else getattr(tracker, "max_track_points", None)
+        self.global_cap = None if cap is None else int(cap)
         self.begin, self.end = shard_bounds(self.n, self.world, self.rank)
         self.cap = shard_capacity(self.n, self.world)
         self.packed = torch.zeros(packed_bytes(self.cap), dtype=torch.uint8, device=device)
@@ -102,8 +110,11 @@ class ShardedKlt:
         """Enqueue the local shard's kernel and the all-gather; returns the gathered byte buffer (asynchronous on GPUs)."""
         m = self.end - self.begin
         if m > 0:
+            kw = {}
+            if self.global_cap is not None:
+                kw["max_track_points"] = max(0, min(self.global_cap - self.begin, m))  # this block's share of the global cap
             self.tracker.track(ref_uv[self.begin:self.end], cur_uv_in[self.begin:self.end], status_in[self.begin:self.end],
-                               self.uv_view[:m], self.status_view[:m], None if iters is None else iters[self.begin:self.end])
+                               self.uv_view[:m], self.status_view[:m], None if iters is None else iters[self.begin:self.end], **kw)
         return all_gather_results(self.packed, self.world, group=self.group, force_collective=self.world > 1, out=self.gathered)
 
     def track(self, ref_uv, cur_uv_in, status_in, iters=None):

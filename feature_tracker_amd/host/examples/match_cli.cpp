@@ -1,7 +1,12 @@
 // match_cli — drives DescriptorMatcher<BriefType> through a subclass written exactly like the
 // reference's BriefMatcher (test/test_descriptor_matcher_brief.cpp:27-46).
 //
-//   match_cli <force|nearby> <max_distance> <max_col> <max_row> <descriptors.txt>
+//   match_cli <force|nearby> <max_distance> <max_col> <max_row> <descriptors.txt> [nearmiss|nooffload]
+//
+// nearmiss : the virtual distance is the Hamming distance EXCEPT that it answers 1000 below 25 differing bits — it agrees
+//            with the built-in distance on random pairs (the call-time probe) and differs exactly on the pairs a matcher
+//            returns; the library must notice (post-check) and honour the virtual on the host.
+// nooffload: Options::kAllowDeviceOffload = false (the host loop over the virtual, whatever the distance is).
 //
 // descriptors.txt: first line "n_ref n_cur n_bits"; then n_ref lines "bits [u v]" and n_cur lines
 // "bits [u v]" where bits is a 0/1 string.  Output: "ok <0|1>" then one index per ref descriptor and
@@ -19,6 +24,7 @@
 
 class BriefMatcher: public feature_tracker::DescriptorMatcher<feature_detector::BriefType> {
 public:
+    bool near_miss = false;
     virtual float ComputeDistance(const feature_detector::BriefType &descriptor_ref, const feature_detector::BriefType &descriptor_cur) override {
         if (descriptor_ref.empty() || descriptor_cur.empty()) {
             return kMaxInt32;
@@ -28,6 +34,9 @@ public:
             if (descriptor_ref[i] != descriptor_cur[i]) {
                 ++distance;
             }
+        }
+        if (near_miss && distance < 25) {
+            return 1000.0f;
         }
         return static_cast<float>(distance);
     }
@@ -42,6 +51,8 @@ int main(int argc, char **argv) {
     matcher.options().kMaxValidDescriptorDistance = std::strtof(argv[2], nullptr);
     matcher.options().kMaxValidPredictColDistance = std::atoi(argv[3]);
     matcher.options().kMaxValidPredictRowDistance = std::atoi(argv[4]);
+    matcher.near_miss = argc >= 7 && std::string(argv[6]) == "nearmiss";
+    matcher.options().kAllowDeviceOffload = !(argc >= 7 && std::string(argv[6]) == "nooffload");
     std::ifstream in(argv[5]);
     size_t n_ref = 0, n_cur = 0, n_bits = 0;
     in >> n_ref >> n_cur >> n_bits;

@@ -55,10 +55,6 @@ bool HammingMatch(const std::vector<std::vector<bool>> &descriptors_ref, const s
     }
     const int32_t n_bits = descriptors_ref.empty() ? 0 : static_cast<int32_t>(descriptors_ref[0].size());
     const int32_t n_words = n_bits == 0 ? 1 : (n_bits + 31) / 32;
-    if (n_words > 16) {
-        ReportError("[DescriptorMatcher] descriptors longer than 512 bits are not supported on the device path");
-        return false;
-    }
     std::vector<uint32_t> ref_words, cur_words;
     PackBits(descriptors_ref, n_words, ref_words);
     PackBits(descriptors_cur, n_words, cur_words);

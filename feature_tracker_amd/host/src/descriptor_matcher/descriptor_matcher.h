@@ -13,7 +13,9 @@
 //     cosine distance 0.5f - a.dot(b) / a.norm() / b.norm() * 0.5f (probed bit for bit on a few
 //     pairs): ftk_cosine_match — fp16 MFMA shortlist, exact fp32 decision on the device.
 //   * any other descriptor type / distance: the distance is arbitrary caller code behind a virtual,
-//     so the double loop below runs on the host exactly as written in the reference.
+//     so the double loop below runs on the host exactly as written in the reference.  The recognition
+//     is checked again on the pairs the device returned (Options::kAllowDeviceOffload explains it and
+//     is the switch to turn the offload off).
 #ifndef _DESCRIPTOR_MATCHER_H_
 #define _DESCRIPTOR_MATCHER_H_
 
@@ -63,6 +65,13 @@ public:
         int32_t kMaxValidPredictRowDistance = 40;
         int32_t kMaxValidPredictColDistance = 40;
         float kMaxValidDescriptorDistance = 0.0f;
+        // Not in the reference.  The distance is caller code behind a virtual, which the device cannot run: the all-pairs
+        // scan is offloaded only when that code is RECOGNISED as the Hamming / cosine distance — it must agree, bit for bit,
+        // with the built-in definition on a few probe pairs before the call and on a sample of the pairs the device
+        // returned (plus random ones) after it; any disagreement restores the indices and runs the host loop over the
+        // virtual, as the reference does.  A distance that differs from the built-in one only on inputs none of those
+        // checks meets is not detected: set this to false to always honour the virtual on the host.
+        bool kAllowDeviceOffload = true;
     };
 
 public:
@@ -100,6 +109,16 @@ private:
     // True when DescriptorType is a packed float vector and ComputeDistance agrees bit for bit with
     // the cosine distance of the reference's SuperPoint / DISK matchers on a handful of pairs.
     bool DistanceIsCosine(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur);
+
+    // After an offloaded call: the caller's ComputeDistance must equal `builtin` (bitwise, or both NaN) on up to 48 of the
+    // returned pairs, evenly spread, and on 16 pseudo-random pairs.
+    template <typename Builtin>
+    bool OffloadAgreesWithVirtual(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,
+                                  const std::vector<int32_t> &index_pairs_in_cur, Builtin &&builtin);
+
+    // The reference's double loop over the virtual distance (pred == nullptr: no window test).
+    void HostLoop(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,
+                  const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur, std::vector<int32_t> &index_pairs_in_cur);
 
     // Shared body of ForceMatch / NearbyMatch (pred == nullptr: no window test).
     bool MatchIndices(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,
@@ -177,24 +196,78 @@ bool DescriptorMatcher<DescriptorType>::MatchIndices(const std::vector<Descripto
     }
 
     if constexpr (std::is_same<DescriptorType, std::vector<bool>>::value) {
-        if (DistanceIsHamming(descriptors_ref, descriptors_cur)) {
-            return device::HammingMatch(descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, options_.kMaxValidDescriptorDistance,
-                                        options_.kMaxValidPredictColDistance, options_.kMaxValidPredictRowDistance, index_pairs_in_cur);
+        if (options_.kAllowDeviceOffload && DistanceIsHamming(descriptors_ref, descriptors_cur)) {
+            const std::vector<int32_t> incoming = index_pairs_in_cur;
+            RETURN_FALSE_IF_FALSE(device::HammingMatch(descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur,
+                                                       options_.kMaxValidDescriptorDistance, options_.kMaxValidPredictColDistance,
+                                                       options_.kMaxValidPredictRowDistance, index_pairs_in_cur));
+            if (OffloadAgreesWithVirtual(descriptors_ref, descriptors_cur, index_pairs_in_cur,
+                                         [](const DescriptorType &a, const DescriptorType &b) { return device::HammingDistance(a, b); })) {
+                return true;
+            }
+            index_pairs_in_cur = incoming;  // the virtual is not the Hamming distance after all: honour it on the host
         }
     }
 
     if constexpr (detail::IsFloatVector<DescriptorType>::value) {
-        if (DistanceIsCosine(descriptors_ref, descriptors_cur)) {
+        if (options_.kAllowDeviceOffload && DistanceIsCosine(descriptors_ref, descriptors_cur)) {
             if (descriptors_ref.empty()) {
                 return true;
             }
-            return device::CosineMatch(descriptors_ref[0].data(), static_cast<int32_t>(descriptors_ref.size()), descriptors_cur[0].data(),
-                                       static_cast<int32_t>(descriptors_cur.size()), static_cast<int32_t>(DescriptorType::size()),
-                                       pixel_uv_pred_in_cur, pixel_uv_cur, options_.kMaxValidDescriptorDistance,
-                                       options_.kMaxValidPredictColDistance, options_.kMaxValidPredictRowDistance, index_pairs_in_cur);
+            const std::vector<int32_t> incoming = index_pairs_in_cur;
+            RETURN_FALSE_IF_FALSE(device::CosineMatch(descriptors_ref[0].data(), static_cast<int32_t>(descriptors_ref.size()), descriptors_cur[0].data(),
+                                                      static_cast<int32_t>(descriptors_cur.size()), static_cast<int32_t>(DescriptorType::size()),
+                                                      pixel_uv_pred_in_cur, pixel_uv_cur, options_.kMaxValidDescriptorDistance,
+                                                      options_.kMaxValidPredictColDistance, options_.kMaxValidPredictRowDistance, index_pairs_in_cur));
+            if (OffloadAgreesWithVirtual(descriptors_ref, descriptors_cur, index_pairs_in_cur, [](const DescriptorType &a, const DescriptorType &b) {
+                    return 0.5f - a.dot(b) / a.norm() / b.norm() * 0.5f;
+                })) {
+                return true;
+            }
+            index_pairs_in_cur = incoming;
         }
     }
 
+    HostLoop(descriptors_ref, descriptors_cur, pixel_uv_pred_in_cur, pixel_uv_cur, index_pairs_in_cur);
+    return true;
+}
+
+template <typename DescriptorType>
+template <typename Builtin>
+bool DescriptorMatcher<DescriptorType>::OffloadAgreesWithVirtual(const std::vector<DescriptorType> &descriptors_ref,
+                                                                 const std::vector<DescriptorType> &descriptors_cur,
+                                                                 const std::vector<int32_t> &index_pairs_in_cur, Builtin &&builtin) {
+    const size_t n_ref = descriptors_ref.size(), n_cur = descriptors_cur.size();
+    if (n_ref == 0 || n_cur == 0) {
+        return true;
+    }
+    auto same = [&](size_t i, size_t j) {
+        const float got = ComputeDistance(descriptors_ref[i], descriptors_cur[j]);
+        const float expect = builtin(descriptors_ref[i], descriptors_cur[j]);
+        return got == expect || (got != got && expect != expect);
+    };
+    const size_t stride = n_ref > 48 ? n_ref / 48 : 1;
+    for (size_t i = 0; i < n_ref; i += stride) {
+        const int32_t j = index_pairs_in_cur[i];
+        if (j >= 0 && static_cast<size_t>(j) < n_cur) {
+            RETURN_FALSE_IF(!same(i, static_cast<size_t>(j)));
+        }
+    }
+    uint32_t state = 0x9E3779B9u ^ static_cast<uint32_t>(n_ref * 2654435761u + n_cur);
+    for (int k = 0; k < 16; ++k) {
+        state = state * 1664525u + 1013904223u;
+        const size_t i = (state >> 8) % n_ref;
+        state = state * 1664525u + 1013904223u;
+        const size_t j = (state >> 8) % n_cur;
+        RETURN_FALSE_IF(!same(i, j));
+    }
+    return true;
+}
+
+template <typename DescriptorType>
+void DescriptorMatcher<DescriptorType>::HostLoop(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,
+                                                 const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur,
+                                                 std::vector<int32_t> &index_pairs_in_cur) {
     // Generic host loop over the caller's virtual distance: strict '<' against a running minimum
     // that starts at the threshold, so the lowest index wins ties.
     const size_t n_ref = descriptors_ref.size(), n_cur = descriptors_cur.size();
@@ -216,7 +289,6 @@ bool DescriptorMatcher<DescriptorType>::MatchIndices(const std::vector<Descripto
             BREAK_IF(pixel_uv_pred_in_cur != nullptr && distance == 0);
         }
     }
-    return true;
 }
 
 template <typename DescriptorType>

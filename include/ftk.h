@@ -15,8 +15,12 @@
  *   - 2x2 matrices (prior) are row-major [m00, m01, m10, m11].
  *   - every function returns FTK_OK (0) or a negative FTK_E_* code; ftk_last_error() gives text.
  *     There is NO CPU fallback: without a usable HIP device every compute call fails.
- *   - a context is bound to one device and one HIP stream; it is not thread-safe (neither is the
- *     reference: optical_flow.h:91-111 keeps mutable scratch in the tracker object).
+ *   - a context is bound to one device and one HIP stream.  Calls on ONE context may come from several
+ *     threads: every entry point holds the context's lock for its duration (the context-owned scratch,
+ *     pinned staging and workspaces are reused by every call), so they are serialised, not concurrent —
+ *     separate tracker / matcher objects sharing a context stay independent, as in the reference.
+ *     For concurrency use one context per thread.  ftk_last_error() text is valid until the next call
+ *     on that context.
  */
 #ifndef FTK_H_
 #define FTK_H_
@@ -212,7 +216,8 @@ void ftk_default_direct_options(ftk_direct_options *opt);
  * The sums of the normal equations keep the scalar loop's order (feature by feature, pixel by pixel),
  * so pose, pixels and iteration counts are those of the scalar code.  The world-frame overload
  * (:8-33) is host-side quaternion algebra around this call and lives in the C++ class.
- * At most 3072 tracked features per problem (the per-feature projections live in LDS).
+ * Any number of tracked features: up to 3072 their per-iteration projections live in LDS, above that in a
+ * context-owned device buffer (same arithmetic, same order of the sums).
  */
 int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *K,
                      const float *p_c_in_ref, const float *ref_uv, float *cur_uv, int32_t n, float *q_rc_wxyz, float *p_rc, uint8_t *status,
@@ -241,7 +246,9 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
  * Replaces DescriptorMatcher<BriefType>::ForceMatch (descriptor_matcher.h:55-79) and
  * ::NearbyMatch (:90-124) for the per-bit Hamming distance of
  * test/test_descriptor_matcher_brief.cpp:33-45.  Descriptors are bit-packed: n_words uint32
- * per descriptor, bit i of the descriptor in bit (i % 32) of word i / 32, unused high bits 0.
+ * per descriptor (any n_words >= 1: widths other than 1, 2, 4, 8, 16 words are zero-padded on the device
+ * or take a generic scan — same indices), bit i of the descriptor in bit (i % 32) of word i / 32, unused
+ * high bits 0.
  * n_bits == 0 reproduces ComputeDistance's "empty descriptor" answer (kMaxInt32).
  * pred_uv == NULL selects ForceMatch; otherwise NearbyMatch with the window test
  * |pred.u - cur.u| > max_col_distance || |pred.v - cur.v| > max_row_distance -> skip.

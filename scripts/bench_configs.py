@@ -190,7 +190,7 @@ def float_matcher_case(name, n_ref, n_cur, dim, nearby, torch, F, D, synth, orac
         ok, cidx = oracle.match_float(ref[:rows], cur, 0.1)
     cpu_s = time.perf_counter() - t0
     gpu_ms = float(np.median(times))
-    flops = 2.0 * n_ref * n_cur * dim * 2  # two fp16 MFMA passes over all pairs
+    flops = 2.0 * n_ref * n_cur * dim  # ONE fp16 MFMA walk over all pairs (the default single-walk kernel); per CALL, prep / recheck included in the time
     return {
         "case": name, "mode": "nearby" if nearby else "force", "n_ref": n_ref, "n_cur": n_cur, "dim": dim, "gpu_call_ms": gpu_ms,
         "gpu_pairs_per_s": n_ref * n_cur / gpu_ms * 1e3, "mfma_TFLOPs": flops / (gpu_ms * 1e-3) / 1e12, "cpu_sample_rows": rows,

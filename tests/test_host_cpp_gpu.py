@@ -250,3 +250,47 @@ def test_real_images_python_vs_oracle(ftk, oracle):
             ok2, oc, os_, oit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=6)
             assert np.array_equal(s, os_), (model, method)
             assert np.array_equal(c.view(np.uint32), oc.view(np.uint32)), (model, method)
+
+
+def test_cpp_image_pyramid_built_on_device_lazy_host_levels_and_threads():
+    """ImagePyramid::CreateImagePyramid (inside the reference's timed region, test_optical_flow.cpp:69-73) builds levels >= 1 in
+    HBM from one upload of level 0; host copies appear only when read and equal the box mean; a frame written in place into the
+    aliased level-0 buffer is noticed; two threads with their own trackers on shared const pyramids get the serial result."""
+    exe = os.path.join(BUILD, "pyramid_cli")
+    assert os.path.exists(exe), "host layer not built"
+    res = subprocess.run([exe, os.path.join(DATA, "ref_image.png"), os.path.join(DATA, "cur_image.png"), "4"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = dict(l.split() for l in res.stdout.strip().splitlines() if len(l.split()) == 2)
+    for key in ("built_on_device", "tracked_without_host_levels", "levels_equal_box_mean", "same_after_host_read", "in_place_overwrite_noticed",
+                "two_threads_equal_serial"):
+        assert out.get(key) == "1", res.stdout
+    assert res.stdout.strip().endswith("PASS")
+
+
+@pytest.mark.parametrize("variant", ["nearmiss", "nooffload"])
+def test_cpp_matcher_honours_a_virtual_distance_that_only_looks_like_hamming(tmp_path, oracle, variant):
+    """DescriptorMatcher offloads only a RECOGNISED distance.  'nearmiss' agrees with Hamming on random pairs (the probe) and
+    answers 1000 where fewer than 25 bits differ — i.e. exactly on the true matches; the reference would call the virtual
+    for every pair, find nothing under the threshold for those rows, and so must this.  'nooffload' turns the offload off."""
+    ref, cur, perm = synth.make_descriptors(300, 420, flips=20)
+    rs = np.random.RandomState(4)
+    cur_uv = np.stack([rs.uniform(0, 640, 420), rs.uniform(0, 480, 420)], axis=1).astype(np.float32)
+    ref_uv = np.stack([rs.uniform(0, 640, 300), rs.uniform(0, 480, 300)], axis=1).astype(np.float32)
+    write_descriptors(tmp_path / "d.txt", ref, cur, ref_uv, cur_uv)
+    exe = os.path.join(BUILD, "match_cli")
+    res = subprocess.run([exe, "force", "60", "50", "40", str(tmp_path / "d.txt"), variant], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0] == "ok 1"
+    idx = np.array([int(l.split()[0]) for l in lines[2:]], np.int32)
+    ok, hamming_idx = oracle.force_match(ref, cur, 60.0)
+    if variant == "nooffload":
+        assert np.array_equal(idx, hamming_idx)
+    else:
+        # host semantics of the near-miss distance: pairs closer than 25 bits are worth 1000 (> threshold); every other pair of
+        # this set differs in ~128 bits, so nothing matches — while the plain Hamming answer matches almost every row
+        d = (ref[:, None, :] != cur[None, :, :]).sum(axis=2).astype(np.float32)
+        d[d < 25] = 1000.0
+        want = np.where((d < 60).any(axis=1), d.argmin(axis=1), -1).astype(np.int32)
+        assert np.array_equal(idx, want)
+        assert (hamming_idx >= 0).sum() > 250 and (idx == -1).all()

@@ -86,9 +86,11 @@ b, e = FD.shard_bounds(n, world, rank)
 cap = FD.shard_capacity(n, world)
 # stand-in for the device kernel on this rank's shard: the oracle (this is a test of the sharding / exchange path)
 class OracleTracker:
-    def track(self, ref_uv, cur_in, st_in, cur_out, st_out, iters):
+    max_track_points = n
+    def track(self, ref_uv, cur_in, st_in, cur_out, st_out, iters, max_track_points=None):
+        cap = self.max_track_points if max_track_points is None else max_track_points
         ok, c, st, it = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, ref_uv.numpy(), cur_in.numpy(), st_in.numpy(),
-                                                     method="fast", half=4, max_points=n)
+                                                     method="fast", half=4, max_points=cap)
         cur_out.copy_(torch.from_numpy(c)); st_out.copy_(torch.from_numpy(st))
 sharded = FD.ShardedKlt(OracleTracker(), n, "cpu", world, rank)
 assert (sharded.begin, sharded.end) == (b, e)
@@ -97,6 +99,13 @@ guv, gst = sharded.track(t_uv, t_uv.clone(), torch.zeros(n, dtype=torch.uint8))
 ok, c_all, st_all, _ = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="fast", half=4, max_points=n)
 assert np.array_equal(guv.numpy().view(np.uint32), c_all.view(np.uint32)), "gathered uv differs from the unsharded run"
 assert np.array_equal(gst.numpy(), st_all)
+# kMaxTrackPointsNumber is a GLOBAL cap (basic_klt.cpp:9): with cap < n only features [0, cap) are tracked, whichever rank holds them
+for cap in (0, 30, 60, 100):
+    capped = OracleTracker(); capped.max_track_points = cap
+    guv, gst = FD.ShardedKlt(capped, n, "cpu", world, rank).track(t_uv, t_uv.clone(), torch.zeros(n, dtype=torch.uint8))
+    ok, c_cap, st_cap, _ = oracle_lib.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="fast", half=4, max_points=cap)
+    assert np.array_equal(guv.numpy().view(np.uint32), c_cap.view(np.uint32)) and np.array_equal(gst.numpy(), st_cap), f"global cap {cap}"
+    assert (gst.numpy()[cap:] == 0).all() and np.array_equal(guv.numpy()[cap:], uv[cap:])
 # descriptor matcher: ref rows sharded, candidates replicated, one all-gather of the index shards
 ref_bits, cur_bits, _ = synth.make_descriptors(53, 40, n_bits=64, flips=5)
 fref, fcur, _ = synth.make_float_descriptors(53, 40, dim=32)
