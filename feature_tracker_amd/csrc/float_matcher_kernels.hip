@@ -37,6 +37,8 @@
 // maximum.  The rr kernel also writes the accumulator element's index into the 5 low mantissa bits of the
 // score (so a maximum names its own element): a perturbation of at most 31 ulp < 2e-6 of the cosine, i.e.
 // 1e-6 on the distance — eps stays below 5.6e-4 and 2 * eps below kMargin with > 25 % to spare.
+#include <limits.h>
+
 #include "ftk_device.h"
 
 namespace ftk {
@@ -1307,6 +1309,7 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
     const float pu = nearby ? p.pred_uv[2 * row] : 0.0f, pv = nearby ? p.pred_uv[2 * row + 1] : 0.0f;
     float best_d = __uint_as_float(0x7F800000u);
     int best_j = -1;
+    int zero_j = INT_MAX;  // NearbyMatch: lowest in-window j whose distance is exactly 0 — where the reference's scan stops (:119)
     auto consider = [&](int j) {  // whole octet, same j
         const float dot = eigen_dot_octet(x, p.cur + (size_t)j * p.dim, p.dim, c, base);
         const float d = 0.5f - dot / na / p.cur_norm[j] * 0.5f;
@@ -1314,15 +1317,24 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
             best_d = d;
             best_j = j;
         }
+        if (nearby && d == 0.0f && j < zero_j) {
+            zero_j = j;
+        }
     };
     auto outside = [&](int j) { return nearby && (fabsf(pu - p.cur_uv[2 * j]) > p.max_col || fabsf(pv - p.cur_uv[2 * j + 1]) > p.max_row); };
-    if (scan_all) {
-        for (int j = 0; j < p.n_cur; ++j) {
-            if (!outside(j)) {
-                consider(j);
+    // minimum over the row's candidates with j <= j_limit (octet-uniform)
+    auto scan = [&](int j_limit) {
+        best_d = __uint_as_float(0x7F800000u);
+        best_j = -1;
+        if (scan_all) {
+            const int j_end = j_limit < p.n_cur - 1 ? j_limit + 1 : p.n_cur;
+            for (int j = 0; j < j_end; ++j) {
+                if (!outside(j)) {
+                    consider(j);
+                }
             }
+            return;
         }
-    } else {
         // eight list entries per round, one per lane: the filters (score, window) run in parallel and only the survivors —
         // one or two per row — cost an exact distance; a serial walk pays the load latency once per entry instead
         const int n_cand = (int)cnt, n_all = (int)(cnt + n_irr);
@@ -1337,7 +1349,7 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
             } else if (t < n_all) {
                 j = p.irregular_list[t - n_cand];
             }
-            if (j >= 0 && outside(j)) {
+            if (j >= 0 && (j > j_limit || outside(j))) {
                 j = -1;
             }
             unsigned live_mask = (unsigned)((__ballot(j >= 0) >> base) & 0xFFull);
@@ -1347,6 +1359,14 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
                 consider(__shfl(j, base + k));
             }
         }
+    };
+    scan(INT_MAX);
+    // NearbyMatch stops scanning a row at the first in-window candidate at distance exactly 0 (descriptor_matcher.h:119), so
+    // candidates behind it never compete.  Nothing beats a zero except a NEGATIVE distance (a cosine rounded above 1); only
+    // when the global minimum is such a candidate and lies behind the stop is the minimum taken again over j <= stop.  Every
+    // zero-distance candidate is in the list (its score is the row maximum to within the margin), so the stop is exact.
+    if (nearby && best_d < 0.0f && best_j > zero_j) {
+        scan(zero_j);
     }
     // strict '<' against a running minimum that starts at the threshold (descriptor_matcher.h:68-75, :114-117)
     if (c == 0 && best_j >= 0 && best_d < p.max_distance) {

@@ -323,3 +323,40 @@ def test_large_set_properties(ftk):
     far = pred_uv + np.float32(10000.0)
     ok, idx = matcher(ftk, 0.1, col=3, row=3).NearbyMatch(ref, cur, far, cur_uv)
     assert ok and (idx == -1).all()
+
+
+@pytest.mark.parametrize("dim", [128, 256])
+def test_nearby_scan_stops_at_the_first_exact_zero_distance(ftk, oracle, dim):
+    """NearbyMatch leaves a row's scan at the first in-window candidate whose distance is exactly 0 (descriptor_matcher.h:119).
+    A float distance can be slightly NEGATIVE (a cosine rounded above 1), so a later scaled duplicate with d < 0 would win a
+    global argmin although the reference never visits it — while an earlier one does win.  Scaled copies of the ref row with
+    d == 0 and with d < 0 (found with the oracle's own distance) are placed in every order around each other."""
+    rs = np.random.RandomState(dim)
+    n_ref, n_cur = 96, 400
+    ref = rs.standard_normal((n_ref, dim)).astype(np.float32)
+    cur = rs.standard_normal((n_cur, dim)).astype(np.float32)
+    cases = 0
+    for i in range(n_ref):
+        zero, neg = [], []
+        for k in range(300):
+            s = np.float32(0.5 + k * 0.0037)
+            d = oracle.cosine_distance(ref[i], (ref[i] * s).astype(np.float32))
+            (zero if d == 0 else neg if d < 0 else []).append(s)
+        if not zero or not neg:
+            continue
+        cases += 1
+        slots = np.sort(rs.choice(n_cur, size=4, replace=False))
+        order = [(zero, neg, neg, zero), (neg, zero, neg, zero), (zero, zero, neg, neg), (neg, neg, zero, neg)][i % 4]
+        for slot, pool in zip(slots, order):
+            cur[slot] = ref[i] * pool[rs.randint(len(pool))]
+    assert cases > n_ref // 2
+    uv = np.zeros((n_ref, 2), np.float32)
+    cuv = np.zeros((n_cur, 2), np.float32)  # every candidate inside every window
+    for thr in (0.05, 0.6):
+        ok_g, idx_g = matcher(ftk, thr).NearbyMatch(ref, cur, uv, cuv)
+        ok_c, idx_c = oracle.match_float(ref, cur, thr, uv, cuv)
+        assert ok_g and ok_c and np.array_equal(idx_g, idx_c), np.flatnonzero(idx_g != idx_c)[:10]
+        okf, idx_f = matcher(ftk, thr).ForceMatch(ref, cur)
+        okc, idx_fc = oracle.match_float(ref, cur, thr)
+        assert np.array_equal(idx_f, idx_fc)
+    assert (idx_g != idx_f).any()  # the stop changes the answer for some rows, so the case is exercised
