@@ -182,6 +182,8 @@ def main():
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
                          "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
     ap.add_argument("--features", type=int, default=0, help="experiment knob: override the workload's feature count (the reported config says so)")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.0,
+                    help="experiment knob: keep the device busy with untimed steps for this long before the W warmup steps (clock ramp study)")
     args = ap.parse_args()
 
     import torch
@@ -254,6 +256,12 @@ def main():
         stream.synchronize()
         iters = d_iters.cpu().numpy().astype(np.uint32)
         status = d_st_out.cpu().numpy()
+        if args.prewarm_seconds > 0:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.prewarm_seconds:
+                for _ in range(100):
+                    step()
+                stream.synchronize()
         for _ in range(args.warmup):
             step()
         stream.synchronize()

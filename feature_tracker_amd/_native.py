@@ -29,7 +29,10 @@ EXPORTS = [
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
     "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_ldlt6_solve", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
     "ftk_brief_compute", "ftk_brief_compute_device", "ftk_harris_detect", "ftk_harris_response",
+    "ftk_shard_bounds", "ftk_klt_shard_bytes", "ftk_comm_unique_id", "ftk_comm_create", "ftk_comm_destroy", "ftk_comm_rank", "ftk_comm_world",
+    "ftk_klt_track_sharded_device", "ftk_klt_track_sharded", "ftk_klt_track_shard_device", "ftk_klt_unpack_shards_device", "ftk_hamming_match_sharded_device",
 ]
+UNIQUE_ID_BYTES = 128
 
 
 class FtkError(RuntimeError):
@@ -141,6 +144,21 @@ def lib() -> C.CDLL:
     l.ftk_brief_compute_device.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp]
     l.ftk_harris_detect.argtypes = [vp, vp, i32, i32, i32, C.c_float, vp, C.POINTER(C.c_int32)]
     l.ftk_harris_response.argtypes = [vp, vp, i32, vp]
+    l.ftk_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    l.ftk_shard_bounds.restype = None
+    l.ftk_klt_shard_bytes.argtypes = [i32, i32]
+    l.ftk_klt_shard_bytes.restype = C.c_size_t
+    l.ftk_comm_unique_id.argtypes = [vp]
+    l.ftk_comm_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    l.ftk_comm_destroy.argtypes = [vp]
+    l.ftk_comm_destroy.restype = None
+    l.ftk_comm_rank.argtypes = [vp]
+    l.ftk_comm_world.argtypes = [vp]
+    l.ftk_klt_track_sharded_device.argtypes = [vp, vp, C.c_int, C.POINTER(KltOptions), vp, vp, vp, vp, vp, vp, vp, i32, vp, C.c_int, C.c_int, vp]
+    l.ftk_klt_track_sharded.argtypes = [vp, vp, C.c_int, C.POINTER(KltOptions), vp, vp, vp, vp, vp, i32, vp, C.c_int, C.c_int, vp]
+    l.ftk_klt_track_shard_device.argtypes = [vp, i32, i32, C.c_int, C.POINTER(KltOptions), vp, vp, vp, vp, vp, i32, vp, C.c_int, C.c_int, vp, vp]
+    l.ftk_klt_unpack_shards_device.argtypes = [vp, vp, i32, i32, vp, vp]
+    l.ftk_hamming_match_sharded_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp]
     _lib = l
     return l
 

@@ -15,58 +15,13 @@
 #include <vector>
 
 #include "ftk_device.h"
+#include "ftk_internal.h"
 
 using ftk::DevImage;
 
-struct ftk_context {
-    // Every entry point that takes a context holds this lock for its whole duration: the scratch / pinned / workspace
-    // buffers below are reused (and regrown) by every call, so calls on ONE context from several threads — e.g. the
-    // left and right tracker objects of a stereo front end, which share the process-wide context of the C++ classes —
-    // are serialised here instead of racing on them.  Recursive: the host-buffer wrappers call the *_device entries.
-    std::recursive_mutex lock;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = false;
-    std::string error;
-    // cached device scratch for the host-buffer entry points
-    void *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    unsigned long long *match_keys = nullptr;
-    size_t match_keys_count = 0;
-    float *match_boxes = nullptr;  // NearbyMatch bounding boxes (4 floats each)
-    size_t match_boxes_count = 0;
-    // workspace of the float-descriptor matcher (fp16 copies, norms, candidate lists)
-    void *cosine_ws = nullptr;
-    size_t cosine_ws_bytes = 0;
-    // problem table of the direct-method launches
-    void *direct_table = nullptr;
-    size_t direct_table_bytes = 0;
-    // per-feature projection tables of direct-method problems too large for LDS (16 B per tracked feature)
-    void *direct_feat = nullptr;
-    size_t direct_feat_bytes = 0;
-    // zero-padded copies of descriptors whose width is not a power of two (device-resident matcher entry)
-    void *match_pad = nullptr;
-    size_t match_pad_bytes = 0;
-    // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
-    void *pinned = nullptr;
-    size_t pinned_bytes = 0;
-    // BRIEF sampling pattern resident on the device, cached per (n_bits, half)
-    int8_t *brief_pattern = nullptr;
-    int32_t brief_bits = 0, brief_half = 0;
-};
-
-struct ftk_pyramid {
-    int device = 0;
-    int32_t n_levels = 0;
-    DevImage levels[FTK_MAX_LEVELS];
-    uint8_t *owned = nullptr;  // single allocation holding every owned level
-};
-
-namespace {
-
 thread_local std::string g_create_error;
 
-int fail(ftk_context *ctx, int code, const char *fmt, ...) {
+int ftk_fail(ftk_context *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -80,15 +35,9 @@ int fail(ftk_context *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
-#define FTK_HIP(ctx, expr)                                                                                   \
-    do {                                                                                                     \
-        hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess) {                                                                              \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? FTK_E_OUT_OF_MEMORY : FTK_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-        }                                                                                                    \
-    } while (0)
+namespace {
 
-size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+size_t align_up(size_t x, size_t a) { return ftk_align_up(x, a); }
 
 int ensure_scratch(ftk_context *ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) {
@@ -167,8 +116,10 @@ int ensure_cosine_ws(ftk_context *ctx, size_t bytes) {
     return FTK_OK;
 }
 
+}  // namespace
+
 // Grows a context-owned device buffer (stream-synchronising first: earlier launches may still read the old one).
-int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) {
+int ftk_ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) {
     if (bytes <= *have) {
         return FTK_OK;
     }
@@ -184,7 +135,9 @@ int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t byte
     return FTK_OK;
 }
 
-#define FTK_LOCK(ctx) std::lock_guard<std::recursive_mutex> ftk_lock_guard_((ctx)->lock)
+namespace {
+
+int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) { return ftk_ensure_device_buffer(ctx, buf, have, bytes); }
 
 uint32_t div_magic(int32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 

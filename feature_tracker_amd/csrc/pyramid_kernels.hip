@@ -102,6 +102,31 @@ __global__ void __launch_bounds__(64) extract_patch_kernel(DevImage ref, float u
     }
 }
 
+
+// Multi-GPU result exchange (ftk_comm.cpp): the gathered buffer holds `world` packed shards ([u, v] pairs of `cap` features, then
+// `cap` status bytes, `shard_bytes` apart); feature i of the global list lives in the shard of the rank whose block contains it
+// (blocks as ftk_shard_bounds: the first n % world ranks hold one feature more).
+__global__ void __launch_bounds__(kBlock) unpack_klt_shards_kernel(const uint8_t *__restrict__ gathered, int n, int world, int cap, long long shard_bytes,
+                                                                   float2 *__restrict__ uv_out, uint8_t *__restrict__ status_out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const int base = n / world, extra = n % world;
+    const int big = extra * (base + 1);  // features held by the ranks with base + 1 of them
+    int rank, local;
+    if (i < big) {
+        rank = i / (base + 1);
+        local = i - rank * (base + 1);
+    } else {
+        rank = extra + (i - big) / (base > 0 ? base : 1);
+        local = (i - big) - (rank - extra) * base;
+    }
+    const uint8_t *shard = gathered + shard_bytes * rank;
+    uv_out[i] = reinterpret_cast<const float2 *>(shard)[local];
+    status_out[i] = shard[(long long)cap * 8 + local];
+}
+
 }  // namespace
 
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream) {
@@ -118,6 +143,16 @@ hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream) {
     hipLaunchKernelGGL(extract_patch_kernel, dim3(1), dim3(64), 0, stream, ref, u, v, ex_rows, ex_cols, d_patch, d_valid, d_count);
+    return hipGetLastError();
+}
+
+hipError_t unpack_klt_shards_launch(const uint8_t *d_gathered, int32_t n, int32_t world, int32_t cap, int64_t shard_bytes, float *d_uv_out,
+                                   uint8_t *d_status_out, hipStream_t stream) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(unpack_klt_shards_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, d_gathered, n, world, cap,
+                       (long long)shard_bytes, reinterpret_cast<float2 *>(d_uv_out), d_status_out);
     return hipGetLastError();
 }
 

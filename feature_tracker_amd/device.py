@@ -91,6 +91,48 @@ class DeviceKlt:
         """kMaxTrackPointsNumber of this tracker's options (the GLOBAL cap when the feature list is sharded)."""
         return int(self.opt.max_track_points)
 
+    def _args(self, ref_uv, cur_uv_in, status_in):
+        return (C.c_void_p(ref_uv.data_ptr()), C.c_void_p(cur_uv_in.data_ptr()), C.c_void_p(status_in.data_ptr()))
+
+    def track_sharded(self, comm: "Comm", ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None):
+        """ftk_klt_track_sharded_device: this rank's block of the (full-length) buffers, RCCL all-gather, scatter — every rank's
+        out tensors hold all n results afterwards (stream-ordered)."""
+        r, c, s = self._args(ref_uv, cur_uv_in, status_in)
+        rc = N.lib().ftk_klt_track_sharded_device(
+            self.ctx.handle, comm.handle, self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, r, c, C.c_void_p(cur_uv_out.data_ptr()),
+            s, C.c_void_p(status_out.data_ptr()), ref_uv.shape[0], None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single,
+            None if iters is None else C.c_void_p(iters.data_ptr()))
+        N.check(rc, self.ctx.handle)
+
+    def bind_sharded(self, comm: "Comm", ref_uv, cur_uv_in, status_in, cur_uv_out, status_out):
+        """Pre-marshalled track_sharded on fixed buffers (launch-rate-sensitive loops, HIP-graph capture)."""
+        r, c, s = self._args(ref_uv, cur_uv_in, status_in)
+        fn = N.lib().ftk_klt_track_sharded_device
+        args = (self.ctx.handle, comm.handle, self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, r, c, C.c_void_p(cur_uv_out.data_ptr()), s,
+                C.c_void_p(status_out.data_ptr()), ref_uv.shape[0], None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single, None)
+        keep = (comm, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out)
+        handle = self.ctx.handle
+
+        def launch(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc != 0:
+                N.check(rc, handle)
+
+        return launch
+
+    def track_shard(self, rank: int, world: int, ref_uv, cur_uv_in, status_in, packed_shard, iters=None):
+        """ftk_klt_track_shard_device: rank's block tracked into its packed shard (for callers with their own collective)."""
+        r, c, s = self._args(ref_uv, cur_uv_in, status_in)
+        rc = N.lib().ftk_klt_track_shard_device(
+            self.ctx.handle, int(rank), int(world), self.model, C.byref(self.opt), self.ref_pyr.handle, self.cur_pyr.handle, r, c, s, ref_uv.shape[0],
+            None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single, C.c_void_p(packed_shard.data_ptr()),
+            None if iters is None else C.c_void_p(iters.data_ptr()))
+        N.check(rc, self.ctx.handle)
+
+    def unpack_shards(self, gathered, n: int, world: int, cur_uv_out, status_out):
+        N.check(N.lib().ftk_klt_unpack_shards_device(self.ctx.handle, C.c_void_p(gathered.data_ptr()), int(n), int(world), C.c_void_p(cur_uv_out.data_ptr()),
+                                                     C.c_void_p(status_out.data_ptr())), self.ctx.handle)
+
     def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters=None, max_track_points=None):
         """``max_track_points`` overrides the options' cap for this launch (a shard's share of the global cap)."""
         n = ref_uv.shape[0]
@@ -104,6 +146,57 @@ class DeviceKlt:
             C.c_void_p(status_out.data_ptr()), n, None if self.prior is None else self.prior.ctypes.data_as(C.c_void_p), self.lum, self.single,
             None if iters is None else C.c_void_p(iters.data_ptr()))
         N.check(rc, self.ctx.handle)
+
+
+class Comm:
+    """ftk_comm: the communicator of the native multi-GPU path (one process per GPU; RCCL all-gather issued by libftk_hip.so on
+    the context's stream).  ``unique_id`` (128 bytes from ``Comm.unique_id()`` on rank 0, handed to the other ranks by any
+    means) is required for world > 1; world == 1 with no id needs no RCCL."""
+
+    def __init__(self, ctx: Context, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        out = C.c_void_p()
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), N.UNIQUE_ID_BYTES)
+        N.check(N.lib().ftk_comm_create(ctx.handle, self.rank, self.world, buf, C.byref(out)), ctx.handle)
+        self._handle = out
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(N.UNIQUE_ID_BYTES)
+        N.check(N.lib().ftk_comm_unique_id(buf), None)
+        return buf.raw
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def close(self):
+        if self._handle:
+            N.lib().ftk_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """ftk_shard_bounds: the native twin of feature_tracker_amd.dist.shard_bounds."""
+    b, e = C.c_int32(), C.c_int32()
+    N.lib().ftk_shard_bounds(n, world, rank, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def hamming_match_sharded_device(ctx: Context, comm: Comm, ref_words, cur_words, n_bits: int, max_distance: float, index_pairs, pred_uv=None,
+                                 cur_uv=None, max_col: int = 40, max_row: int = 40):
+    """ftk_hamming_match_sharded_device on torch tensors: every rank passes ALL reference rows; index_pairs is complete everywhere."""
+    rc = N.lib().ftk_hamming_match_sharded_device(
+        ctx.handle, comm.handle, C.c_void_p(ref_words.data_ptr()), ref_words.shape[0], C.c_void_p(cur_words.data_ptr()), cur_words.shape[0],
+        ref_words.shape[1], int(n_bits), float(max_distance), None if pred_uv is None else C.c_void_p(pred_uv.data_ptr()),
+        None if cur_uv is None else C.c_void_p(cur_uv.data_ptr()), int(max_col), int(max_row), C.c_void_p(index_pairs.data_ptr()))
+    N.check(rc, ctx.handle)
 
 
 def hamming_match_device(ctx: Context, ref_words, cur_words, n_bits: int, max_distance: float, index_pairs, pred_uv=None, cur_uv=None,

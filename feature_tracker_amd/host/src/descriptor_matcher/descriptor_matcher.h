@@ -246,7 +246,7 @@ bool DescriptorMatcher<DescriptorType>::OffloadAgreesWithVirtual(const std::vect
         const float expect = builtin(descriptors_ref[i], descriptors_cur[j]);
         return got == expect || (got != got && expect != expect);
     };
-    const size_t stride = n_ref > 48 ? n_ref / 48 : 1;
+    const size_t stride = (n_ref + 47) / 48;  // at most 48 rows
     for (size_t i = 0; i < n_ref; i += stride) {
         const int32_t j = index_pairs_in_cur[i];
         if (j >= 0 && static_cast<size_t>(j) < n_cur) {

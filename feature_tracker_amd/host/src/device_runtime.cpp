@@ -1,8 +1,11 @@
 #include "device_runtime.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 namespace feature_tracker {
 namespace device {
@@ -13,8 +16,26 @@ ftk_context *g_ctx = nullptr;
 bool g_tried = false;  // a failed creation (no device) is not retried on every call
 std::string g_error;
 
+ftk_comm *g_comm = nullptr;
+bool g_comm_tried = false;
+
+int EnvInt(const char *primary, const char *secondary, int fallback) {
+    for (const char *name : {primary, secondary}) {
+        if (name != nullptr) {
+            if (const char *v = std::getenv(name)) {
+                return std::atoi(v);
+            }
+        }
+    }
+    return fallback;
+}
+
 struct ContextReaper {
     ~ContextReaper() {
+        if (g_comm != nullptr) {
+            ftk_comm_destroy(g_comm);
+            g_comm = nullptr;
+        }
         if (g_ctx != nullptr) {
             ftk_context_destroy(g_ctx);
             g_ctx = nullptr;
@@ -27,11 +48,17 @@ ftk_context *SharedContext(std::string *error) {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_ctx == nullptr && !g_tried) {
         g_tried = true;
-        int dev = 0;
-        if (const char *env = std::getenv("FTK_DEVICE")) {
-            dev = std::atoi(env);
-        }
+        const int dev = EnvInt("FTK_DEVICE", "LOCAL_RANK", 0);
+        // Bringing up the HIP runtime must not disturb the caller's std::rand() / random() stream (the runtime's own
+        // initialisation draws from it): CreateImagePyramid now reaches this point BEFORE a caller like
+        // test/test_direct_method.cpp:45-49 picks its features with std::rand(), and the reference's own pyramid
+        // code consumes no random numbers.  glibc keeps rand() and random() in one state: park it, restore it.
+        char scratch_state[256];
+        char *callers_state = initstate(1u, scratch_state, sizeof(scratch_state));
         const int rc = ftk_context_create(dev, nullptr, &g_ctx);
+        if (callers_state != nullptr) {
+            setstate(callers_state);
+        }
         if (rc != FTK_OK) {
             g_ctx = nullptr;
             g_error = ftk_last_error(nullptr);
@@ -41,6 +68,58 @@ ftk_context *SharedContext(std::string *error) {
         *error = g_error;
     }
     return g_ctx;
+}
+
+ftk_comm *SharedComm(ftk_context *ctx, std::string *error) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_comm != nullptr || g_comm_tried) {
+        if (g_comm == nullptr && !g_error.empty() && error != nullptr) {
+            *error = g_error;
+        }
+        return g_comm;
+    }
+    g_comm_tried = true;
+    const int world = EnvInt("FTK_WORLD_SIZE", "WORLD_SIZE", 1), rank = EnvInt("FTK_RANK", "RANK", 0);
+    const char *id_file = std::getenv("FTK_COMM_ID_FILE");
+    if (world <= 1 && id_file == nullptr) {
+        return nullptr;  // a single process: the plain calls
+    }
+    unsigned char id[FTK_UNIQUE_ID_BYTES];
+    if (id_file == nullptr) {
+        g_error = "FTK_WORLD_SIZE > 1 needs FTK_COMM_ID_FILE (a path every rank can read) to hand out the RCCL unique id";
+    } else if (rank == 0) {
+        // written under a temporary name and renamed, so that a reader never sees a partial id
+        const std::string tmp = std::string(id_file) + ".tmp";
+        FILE *f = nullptr;
+        if (ftk_comm_unique_id(id) != FTK_OK) {
+            g_error = ftk_last_error(nullptr);
+        } else if ((f = std::fopen(tmp.c_str(), "wb")) == nullptr || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 ||
+                   std::rename(tmp.c_str(), id_file) != 0) {
+            g_error = std::string("cannot write the RCCL unique id to ") + id_file;
+        }
+    } else {
+        bool got = false;
+        for (int attempt = 0; attempt < 1200 && !got; ++attempt) {  // up to two minutes for rank 0 to come up
+            if (FILE *f = std::fopen(id_file, "rb")) {
+                got = std::fread(id, 1, sizeof(id), f) == sizeof(id);
+                std::fclose(f);
+            }
+            if (!got) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+        }
+        if (!got) {
+            g_error = std::string("timed out waiting for the RCCL unique id in ") + id_file;
+        }
+    }
+    if (g_error.empty() && ftk_comm_create(ctx, rank, world, id, &g_comm) != FTK_OK) {
+        g_comm = nullptr;
+        g_error = ftk_last_error(ctx);
+    }
+    if (g_comm == nullptr && error != nullptr) {
+        *error = g_error;
+    }
+    return g_comm;
 }
 
 namespace {
@@ -93,6 +172,10 @@ ftk_pyramid *PyramidTwin(ftk_context *ctx, const ImagePyramid &pyramid, std::str
 
 // ImagePyramid::CreateImagePyramid (datatype_image_pyramid.h): level 0 goes up once, levels >= 1 are built in HBM.
 bool BuildPyramidOnDevice(const ImagePyramid &pyramid) {
+    static const bool host_pyramid = std::getenv("FTK_HOST_PYRAMID") != nullptr && std::atoi(std::getenv("FTK_HOST_PYRAMID")) != 0;
+    if (host_pyramid) {
+        return false;  // experiment switch: levels >= 1 by the host loop, all levels uploaded at the first TrackFeatures
+    }
     std::string error;
     ftk_context *ctx = SharedContext(&error);
     if (ctx == nullptr) {

@@ -18,6 +18,13 @@ namespace device {
 // Returns the shared context, creating it on first use; nullptr (and *error filled) when no HIP
 // device is usable.  There is no CPU fallback: callers report the error and return false.
 ftk_context *SharedContext(std::string *error);
+// One process per GPU: when FTK_WORLD_SIZE (default 1) says this process is one rank of several — or FTK_COMM_ID_FILE is set,
+// which exercises the same path at world size 1 — the trackers shard their feature list over the ranks and every process
+// receives the complete result (ftk_klt_track_sharded: RCCL all-gather issued by libftk_hip.so).  Environment: FTK_RANK,
+// FTK_WORLD_SIZE (RANK / WORLD_SIZE of a torchrun-style launcher are honoured too), FTK_DEVICE (default: LOCAL_RANK, else 0) and
+// FTK_COMM_ID_FILE, a path all ranks can read: rank 0 writes the 128-byte RCCL unique id there, the others wait for it.
+// Returns nullptr (and no error) for a single process; nullptr with *error filled when the communicator cannot be made.
+ftk_comm *SharedComm(ftk_context *ctx, std::string *error);
 // Text of the last failure on the shared context.
 std::string LastError();
 // Device twin of a host ImagePyramid: uploaded once per generation of the host object, then reused by

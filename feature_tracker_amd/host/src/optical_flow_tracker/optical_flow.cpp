@@ -110,8 +110,20 @@ bool OpticalFlow::TrackOnDevice(int model, const ImagePyramid *ref_pyramid, cons
 
     const int32_t n = static_cast<int32_t>(ref_pixel_uv.size());
     last_iterations_.assign(n, 0u);
-    const int rc = ftk_klt_track(ctx, model, &opt, ref_dev, cur_dev, ref_pixel_uv[0].data(), cur_pixel_uv[0].data(), status.data(), n, prior,
-                                 consider_luminance ? 1 : 0, single_level ? 1 : 0, last_iterations_.data());
+    // One rank of several (device_runtime.h, SharedComm): the feature list is sharded over the ranks' GPUs and one RCCL all-gather
+    // hands every process the complete result, identical to the single-GPU one (features do not interact, basic_klt.cpp:13-54).
+    std::string comm_error;
+    ftk_comm *comm = device::SharedComm(ctx, &comm_error);
+    if (comm == nullptr && !comm_error.empty()) {
+        last_error_ = comm_error;
+        ReportError("[OpticalFlow] " << OpticalFlowMethodName() << ": " << last_error_);
+        return false;
+    }
+    const int rc = comm != nullptr
+                       ? ftk_klt_track_sharded(ctx, comm, model, &opt, ref_dev, cur_dev, ref_pixel_uv[0].data(), cur_pixel_uv[0].data(), status.data(), n,
+                                               prior, consider_luminance ? 1 : 0, single_level ? 1 : 0, last_iterations_.data())
+                       : ftk_klt_track(ctx, model, &opt, ref_dev, cur_dev, ref_pixel_uv[0].data(), cur_pixel_uv[0].data(), status.data(), n, prior,
+                                       consider_luminance ? 1 : 0, single_level ? 1 : 0, last_iterations_.data());
     if (rc != FTK_OK) {
         last_error_ = ftk_last_error(ctx);
         ReportError("[OpticalFlow] " << OpticalFlowMethodName() << ": " << last_error_);

@@ -25,6 +25,7 @@
 #ifndef FTK_H_
 #define FTK_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -239,6 +240,60 @@ typedef struct ftk_direct_problem {
     uint32_t *d_iterations; /* may be NULL */
 } ftk_direct_problem;
 int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *opt, const ftk_direct_problem *problems, int32_t n_problems);
+
+/* ---- features sharded over the GPUs of one node ------------------------ */
+
+/*
+ * The reference has no parallelism of any kind; what shards is the independence of its units: every feature's
+ * computation reads the two pyramids and its own (ref_uv, cur_uv, status) only (basic_klt.cpp:13-54, affine_klt.cpp:12-56,
+ * lssd_klt.cpp:13-58), every reference descriptor's scan is its own (descriptor_matcher.h:67-76).  One process per GPU;
+ * rank r of `world` works on the contiguous block ftk_shard_bounds(n, world, r) with both pyramids (or all candidates)
+ * replicated, and ONE all-gather of the packed result shards — RCCL ncclAllGather over xGMI, issued from this library on the
+ * context's stream right behind the kernel — gives every rank the complete result in the original order, identical to the
+ * single-GPU result.  kMaxTrackPointsNumber stays a cap on the GLOBAL feature index (basic_klt.cpp:9).
+ *
+ * Bootstrap: rank 0 calls ftk_comm_unique_id and hands the 128 bytes to the other ranks by any means (a file, MPI,
+ * torch.distributed ...); every rank then calls ftk_comm_create.  RCCL is bound at run time (dlopen): without it these
+ * calls fail with FTK_E_UNSUPPORTED and everything else keeps working.  world == 1 with a NULL id needs no RCCL at all.
+ */
+typedef struct ftk_comm ftk_comm;
+#define FTK_UNIQUE_ID_BYTES 128
+/* [begin, end) of rank's block: the first n % world ranks hold one unit more. */
+void ftk_shard_bounds(int32_t n, int32_t world, int32_t rank, int32_t *begin, int32_t *end);
+/* Bytes of ONE rank's packed tracker shard: ceil(n / world) * (8 B (u, v) + 1 B status), rounded up to 16 B. */
+size_t ftk_klt_shard_bytes(int32_t n, int32_t world);
+int ftk_comm_unique_id(void *id_out /* FTK_UNIQUE_ID_BYTES */);
+int ftk_comm_create(ftk_context *ctx, int32_t rank, int32_t world, const void *unique_id, ftk_comm **out);
+void ftk_comm_destroy(ftk_comm *comm);
+int ftk_comm_rank(const ftk_comm *comm);
+int ftk_comm_world(const ftk_comm *comm);
+
+/*
+ * ftk_klt_track_device over the ranks of `comm`.  Every rank passes the SAME full-length device buffers (n features);
+ * on return (asynchronously, stream-ordered) every rank's d_cur_uv_out / d_status_out hold all n results.
+ * Launches: the tracker kernel on this rank's block, ncclAllGather of the packed shards, one scatter kernel.
+ * d_iters (optional, n entries) receives only this rank's block.
+ */
+int ftk_klt_track_sharded_device(ftk_context *ctx, ftk_comm *comm, int model, const ftk_klt_options *opt, const ftk_pyramid *ref,
+                                 const ftk_pyramid *cur, const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out,
+                                 const uint8_t *d_status_in, uint8_t *d_status_out, int32_t n, const float *prior, int consider_luminance,
+                                 int single_level, uint32_t *d_iters);
+/* Host-buffer form (synchronous; cur_uv / status in/out as in ftk_klt_track): what the C++ OpticalFlow classes call when the
+ * process is one rank of several.  iters (optional) is filled for this rank's block only, 0 elsewhere. */
+int ftk_klt_track_sharded(ftk_context *ctx, ftk_comm *comm, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur,
+                          const float *ref_uv, float *cur_uv, uint8_t *status, int32_t n, const float *prior, int consider_luminance, int single_level,
+                          uint32_t *iters);
+/* The two halves of the call above for callers that bring their own collective (e.g. torch.distributed): rank's block
+ * tracked into its packed shard (ftk_klt_shard_bytes(n, world) bytes), and the scatter of `world` gathered shards. */
+int ftk_klt_track_shard_device(ftk_context *ctx, int32_t rank, int32_t world, int model, const ftk_klt_options *opt, const ftk_pyramid *ref,
+                               const ftk_pyramid *cur, const float *d_ref_uv, const float *d_cur_uv_in, const uint8_t *d_status_in, int32_t n,
+                               const float *prior, int consider_luminance, int single_level, void *d_packed_shard, uint32_t *d_iters);
+int ftk_klt_unpack_shards_device(ftk_context *ctx, const void *d_gathered, int32_t n, int32_t world, float *d_cur_uv_out, uint8_t *d_status_out);
+/* ftk_hamming_match_device with the reference rows sharded over the ranks (candidates replicated); d_index_pairs (n_ref
+ * entries, in/out as in the single-GPU call) is complete on every rank afterwards. */
+int ftk_hamming_match_sharded_device(ftk_context *ctx, ftk_comm *comm, const uint32_t *d_ref_words, int32_t n_ref, const uint32_t *d_cur_words,
+                                     int32_t n_cur, int32_t n_words, int32_t n_bits, float max_distance, const float *d_pred_uv,
+                                     const float *d_cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *d_index_pairs);
 
 /* ---- descriptor matcher ------------------------------------------------------------------ */
 

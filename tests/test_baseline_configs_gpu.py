@@ -59,7 +59,7 @@ def test_config4_lssd_fast_tracker(ftk, oracle, luminance):
     uv = synth.make_features(cfg["n"], cfg["width"], cfg["height"], half=cfg["half"])
     gpu, cpu = _track_both(ftk, oracle, cfg, uv, ref_levels, cur_levels, luminance=luminance)
     assert_parity(gpu, cpu, f"config4 lssd/fast luminance={luminance}")
-    assert (cpu[2] == 1).mean() > 0.9
+    assert (cpu[2] == 1).mean() > (0.6 if luminance else 0.9)  # the luminance scaling (with its mismatched means, sic) loses more features
 
 
 def test_config4_brief256_force_match_10000(ftk, oracle):

@@ -332,7 +332,7 @@ def test_nearby_scan_stops_at_the_first_exact_zero_distance(ftk, oracle, dim):
     global argmin although the reference never visits it — while an earlier one does win.  Scaled copies of the ref row with
     d == 0 and with d < 0 (found with the oracle's own distance) are placed in every order around each other."""
     rs = np.random.RandomState(dim)
-    n_ref, n_cur = 96, 400
+    n_ref, n_cur = 96, 2000
     ref = rs.standard_normal((n_ref, dim)).astype(np.float32)
     cur = rs.standard_normal((n_cur, dim)).astype(np.float32)
     cases = 0

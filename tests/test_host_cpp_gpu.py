@@ -33,7 +33,7 @@ def write_features(path, uv, pred=None, status=None):
             f.write(line + "\n")
 
 
-def run_track_cli(tmp_path, model, method, levels, half, ref, cur, uv, pred=None, status=None, max_points=100000, prior=None, lum=False):
+def run_track_cli(tmp_path, model, method, levels, half, ref, cur, uv, pred=None, status=None, max_points=100000, prior=None, lum=False, env=None):
     exe = os.path.join(BUILD, "track_cli")
     assert os.path.exists(exe), "host layer not built (python -c 'import __graft_entry__ as g; g.build()')"
     write_pgm(tmp_path / "ref.pgm", ref)
@@ -43,10 +43,12 @@ def run_track_cli(tmp_path, model, method, levels, half, ref, cur, uv, pred=None
            str(tmp_path / "f.txt"), str(max_points)]
     pr = np.eye(2, dtype=np.float32) if prior is None else np.asarray(prior, np.float32)
     cmd += [float(x).hex() for x in pr.reshape(4)] + [str(int(lum))]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=None if env is None else dict(os.environ, **env))
     assert res.returncode == 0, res.stdout + res.stderr
     lines = res.stdout.strip().splitlines()
-    assert lines[0].startswith("ok 1"), res.stdout[:500]
+    while lines and not lines[0].startswith("ok "):  # RCCL prints a version banner on stdout when a communicator is made
+        lines.pop(0)
+    assert lines and lines[0].startswith("ok 1"), res.stdout[:500]
     rows = [l.split() for l in lines[1:]]
     uvb = np.array([[int(r[0], 16), int(r[1], 16)] for r in rows], dtype=np.uint32)
     return uvb.view(np.float32), np.array([int(r[2]) for r in rows], np.uint8), np.array([int(r[3]) for r in rows], np.uint32), lines[0]
@@ -294,3 +296,17 @@ def test_cpp_matcher_honours_a_virtual_distance_that_only_looks_like_hamming(tmp
         want = np.where((d < 60).any(axis=1), d.argmin(axis=1), -1).astype(np.int32)
         assert np.array_equal(idx, want)
         assert (hamming_idx >= 0).sum() > 250 and (idx == -1).all()
+
+
+@pytest.mark.parametrize("model,method", [("basic", "inverse"), ("lssd", "fast")])
+def test_cpp_tracker_as_one_rank_of_a_communicator(tmp_path, oracle, model, method):
+    """The C++ OpticalFlow classes pick the multi-GPU path up from the environment (device_runtime.h, SharedComm): with
+    FTK_COMM_ID_FILE set this process creates the RCCL communicator (world size 1 here: one GPU per test box), tracks its block
+    and goes through ncclAllGather + the scatter; the result must be the single-GPU one, bit for bit, incl. a global cap."""
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    uv = scenes.features(203, 320, 240, half=5)
+    env = {"FTK_WORLD_SIZE": "1", "FTK_RANK": "0", "FTK_COMM_ID_FILE": str(tmp_path / "rccl_id.bin")}
+    c, s, it, head = run_track_cli(tmp_path, model, method, 3, 5, ref_levels[0], cur_levels[0], uv, max_points=150, env=env)
+    assert os.path.getsize(tmp_path / "rccl_id.bin") == 128  # rank 0 published the unique id
+    ok, oc, os_, oit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=5, max_points=150)
+    assert np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and np.array_equal(it, oit)
