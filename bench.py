@@ -171,6 +171,79 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         dist.destroy_process_group()
 
 
+def run_native_comm(args, cfg, world, rank, local_rank, dev):
+    """The contractual weak-scaling workload (cfg['n'] features per GPU) through the NATIVE multi-GPU entry point: every step is
+    ONE ftk_klt_track_sharded_device call — tracker kernel on this rank's block, RCCL ncclAllGather issued by libftk_hip.so on the
+    context stream, scatter kernel.  torch.distributed is used only to hand the RCCL unique id from rank 0 to the others."""
+    import torch
+    import torch.distributed as dist
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+
+    n_local, w, h, levels, half = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
+    n = n_local * world
+    ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))
+    ref_levels, cur_levels = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+    # the global feature list, the same on every rank: rank r's block is the list the torch.distributed path gives rank r
+    uv = np.concatenate([synth.make_features(n_local, w, h, seed=12345 + r, half=half) for r in range(world)], axis=0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, local_rank)
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(D.Comm.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        stream.synchronize()
+        comm = D.Comm(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+        opt = F.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = cfg["method"], half, half, n
+        klt = D.DeviceKlt(cfg["model"], opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_in, d_st = d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev)
+        d_out, d_sto = torch.empty_like(d_ref), torch.empty_like(d_st)
+        launch = klt.bind_sharded(comm, d_ref, d_in, d_st, d_out, d_sto)
+        for _ in range(max(1, args.warmup)):
+            launch()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            launch()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        # result check: this rank's block of the gathered result == its own unsharded launch on that block
+        b, e = D.shard_bounds(n, world, rank)
+        d_chk, d_chk_st = torch.empty(e - b, 2, dtype=torch.float32, device=dev), torch.empty(e - b, dtype=torch.uint8, device=dev)
+        klt.track(d_ref[b:e], d_in[b:e], d_st[b:e], d_chk, d_chk_st, None)
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(d_out[b:e].view(torch.int32), d_chk.view(torch.int32)) and torch.equal(d_sto[b:e], d_chk_st))
+        assert ok, "gathered block differs from the local launch"
+        tracked = float((d_sto == 1).float().mean().item())
+        comm.close()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": n * args.steps / elapsed, "unit": "tracked features/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['model']} KLT {cfg['method']}, {n_local} features/GPU, {w}x{h}, {levels}-level pyramid, "
+                                   f"{2 * half + 1}x{2 * half + 1} patch",
+                       "parallelism": f"features sharded x{world}, pyramids replicated, one ncclAllGather of packed (uv,status) per step issued by "
+                                      "libftk_hip.so (ftk_klt_track_sharded_device) + scatter kernel; plain per-step loop",
+                       "tracked_fraction": tracked, "gathered_block_equals_local_launch": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +255,9 @@ def main():
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
                          "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
     ap.add_argument("--features", type=int, default=0, help="experiment knob: override the workload's feature count (the reported config says so)")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="N > 1 (or N = 1 for a rehearsal): every step through ftk_klt_track_sharded_device — RCCL issued by the C ABI — instead "
+                         "of torch.distributed's all_gather_into_tensor; same workload, same metric ($FTK_BENCH_NATIVE_COMM=1 selects it too)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.0,
                     help="experiment knob: keep the device busy with untimed steps for this long before the W warmup steps (clock ramp study)")
     args = ap.parse_args()
@@ -214,6 +290,8 @@ def main():
         cfg["n"] = args.features
     if args.shard_total > 0:
         return run_sharded(args, cfg, world, rank, local_rank, dev, use_dist)
+    if args.native_comm or os.environ.get("FTK_BENCH_NATIVE_COMM") == "1":
+        return run_native_comm(args, cfg, world, rank, local_rank, dev)
     n, w, h, levels, half = cfg["n"], cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
     if cfg["model"] == "basic":
         ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))
