@@ -1057,8 +1057,11 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     // Split the candidate range finely (a workgroup covers 512 reference descriptors — two per thread,
     // matcher_kernels.hip — and as few as 64 candidates): measured at 10 000 x 10 000, 40 / 80 / 160
     // splits take 85 / 74 / 69 us; the scan is pure VALU work and small workgroups even out the tail.
-    const int row_blocks = (n_ref + 511) / 512;
+    const int row_blocks = (n_ref + ftk::kMatchRowsPerBlock - 1) / ftk::kMatchRowsPerBlock;
     int splits = (4096 + row_blocks - 1) / row_blocks;
+    if (const char *env = getenv("FTK_MATCH_WGS")) {
+        splits = (atoi(env) + row_blocks - 1) / row_blocks;  // experiment: target number of workgroups
+    }
     if (const char *env = getenv("FTK_MATCH_SPLITS")) {
         splits = atoi(env);  // experiment override
     }
@@ -1070,7 +1073,9 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         splits = 1;
     }
     int per = (n_cur + splits - 1) / splits;
-    per = (per + 63) / 64 * 64;
+    if (!(getenv("FTK_MATCH_ANY_PER") && atoi(getenv("FTK_MATCH_ANY_PER")) == 1)) {
+        per = (per + 63) / 64 * 64;
+    }
     p.cur_per_block = per;
     // NearbyMatch from a few thousand candidates on: bounding boxes for the early exit of workgroups whose candidates
     // cannot reach any window of their rows (matcher_kernels.hip)
@@ -1084,8 +1089,33 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         }
         p.boxes = reinterpret_cast<float4 *>(ctx->match_boxes);
     }
+#ifdef FTK_MATCH_STAMPS
+    {
+        // diagnostic build: per-workgroup {start, loaded, end} (s_memrealtime, 100 MHz) + HW_ID, dumped to $FTK_MATCH_STAMPS_DUMP
+        const int n_splits = (n_cur + per - 1) / per;
+        const size_t n_wg = (size_t)row_blocks * n_splits;
+        unsigned long long *d_st = nullptr;
+        FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_st), sizeof(unsigned long long) * 4 * n_wg));
+        FTK_HIP(ctx, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 4 * n_wg, ctx->stream));
+        p.stamps = d_st;
+        FTK_HIP(ctx, ftk::match_launch(p, ctx->stream));
+        std::vector<unsigned long long> h(4 * n_wg);
+        FTK_HIP(ctx, hipMemcpyAsync(h.data(), d_st, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (const char *dump = getenv("FTK_MATCH_STAMPS_DUMP")) {
+            if (FILE *f = fopen(dump, "wb")) {
+                fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_st);
+        return FTK_OK;
+    }
+#else
+    p.stamps = nullptr;
     FTK_HIP(ctx, ftk::match_launch(p, ctx->stream));
     return FTK_OK;
+#endif
 }
 
 int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref, const uint32_t *cur_words, int32_t n_cur, int32_t n_words,

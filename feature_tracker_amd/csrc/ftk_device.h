@@ -65,6 +65,14 @@ hipError_t ldlt6_launch(const float *d_a, const float *d_b, float *d_x, int n, h
 size_t klt_basic_pipelined_lds_bytes(const KltParams &p);
 hipError_t klt_basic_pipelined_launch(const KltParams &p, hipStream_t stream);
 
+// Reference descriptors a thread of the register-tiled Hamming scan keeps in registers (a 256-thread workgroup covers
+// 256 * kMatchRefs reference rows); the host sizes its grid and its NearbyMatch boxes with the same number.
+#ifndef FTK_MATCH_REFS
+#define FTK_MATCH_REFS 2
+#endif
+constexpr int kMatchRefs = FTK_MATCH_REFS;
+constexpr int kMatchRowsPerBlock = 256 * kMatchRefs;
+
 struct MatchParams {
     const uint32_t *ref_words;
     const uint32_t *cur_words;
@@ -77,6 +85,7 @@ struct MatchParams {
     float max_col, max_row;
     int32_t cur_per_block;  // candidates scanned by one workgroup
     int32_t keys_clean;     // keys already hold "no match" (context-owned workspace: the epilogue leaves it that way)
+    unsigned long long *stamps;  // diagnostic build (-DFTK_MATCH_STAMPS) only: {start, end} s_memrealtime + HW_ID per workgroup; else null
     float4 *boxes;          // NearbyMatch, optional: ceil(n_ref / 512) prediction boxes, then one candidate box per split
                             // ({u min, u max, v min, v max}; hamming_box_kernel fills them, the scan leaves early on them)
 };

@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(kBlock) hamming_box_kernel(const MatchParams p
     bool unordered = false;
     const bool pred = (int)blockIdx.x < row_blocks;
     const float *uv = pred ? p.pred_uv : p.cur_uv;
-    const int first = pred ? (int)blockIdx.x * kBlock * 2 : ((int)blockIdx.x - row_blocks) * p.cur_per_block;
-    const int last = pred ? min(first + kBlock * 2, p.n_ref) : min(first + p.cur_per_block, p.n_cur);
+    const int first = pred ? (int)blockIdx.x * kBlock * kMatchRefs : ((int)blockIdx.x - row_blocks) * p.cur_per_block;
+    const int last = pred ? min(first + kBlock * kMatchRefs, p.n_ref) : min(first + p.cur_per_block, p.n_cur);
     for (int i = first + (int)threadIdx.x; i < last; i += kBlock) {
         const float u = uv[2 * i], v = uv[2 * i + 1];
         if (isnan(u) || isnan(v)) {
@@ -191,15 +191,31 @@ __global__ void __launch_bounds__(kBlock) hamming_box_kernel(const MatchParams p
 // per pair — the minimum of that key is the smallest distance and, among equals, the lowest j, which
 // is what the reference's strict '<' scan returns.  Tiles are visited in ascending j and a later tile
 // replaces the best only with a strictly smaller distance.  18 VALU per pair (8 xor, 8 bcnt, 2 key).
-constexpr int kRefs = 2;
+constexpr int kRefs = kMatchRefs;
 
 template <int NW, bool kNearby>
 __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const MatchParams p) {
     __shared__ __attribute__((aligned(16))) uint32_t tile_words[kTile * NW];
     __shared__ float2 tile_uv[kTile];
 
-    const int i_base = (blockIdx.x * kBlock + threadIdx.x) * kRefs;
+#ifdef FTK_MATCH_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
+#endif
+    // A workgroup that starts while older ones are in their popcount loops is the youngest on its SIMDs and gets only the
+    // issue slots the others leave (oldest first): its descriptor loads went out 10 us late (stamps build).  Raised priority
+    // until the descriptors are in registers lets it get its memory requests in flight at once.
+    __builtin_amdgcn_s_setprio(3);
+    // thread t owns rows t, t + 256, ... of the workgroup's block: a wave's 16-byte loads of one row segment then walk the
+    // descriptors with a 32-byte stride (half of every fetched line is used by this load, the other half by the next one),
+    // where rows 2t, 2t + 1 would stride 64 bytes — measured with the stamps build: the descriptor load of a workgroup
+    // took 8 us (median) of its 30 us that way
+    const int i_base = blockIdx.x * kBlock * kRefs + threadIdx.x;
     const int j_begin = blockIdx.y * p.cur_per_block;
+#ifdef FTK_MATCH_STAMPS
+    asm volatile("" ::"s"(j_begin));
+    const unsigned long long stamp_args = __builtin_amdgcn_s_memrealtime();  // kernel arguments have arrived
+#endif
     const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
     if (kNearby && p.boxes != nullptr) {
         // NearbyMatch: when the bounding box of this workgroup's 512 predictions and the bounding box of its candidates
@@ -218,16 +234,41 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
     float pred_u[kRefs], pred_v[kRefs];
 #pragma unroll
     for (int r = 0; r < kRefs; ++r) {
-        const int i = i_base + r;
+        const int i = i_base + r * kBlock;
         const bool active = i < p.n_ref;
+        // unconditional wide loads from a clamped row (a per-word `active ? load : 0` compiles to one exec-masked 4-byte load per
+        // word: 16 scattered dword loads per thread — the stamps build showed the descriptor load at 8 us of a 30-us workgroup)
+        const uint32_t *row = p.ref_words + (long long)(active ? i : p.n_ref - 1) * NW;
+        if (NW % 4 == 0) {
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            ref[r][w] = active ? p.ref_words[(long long)i * NW + w] : 0u;
+            for (int w = 0; w < NW; w += 4) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(row + w);
+                ref[r][w] = q.x;
+                ref[r][w + 1] = q.y;
+                ref[r][w + 2] = q.z;
+                ref[r][w + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                ref[r][w] = row[w];
+            }
+        }
+        if (!active) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                ref[r][w] = 0u;
+            }
         }
         pred_u[r] = (kNearby && active) ? p.pred_uv[2 * i] : 0.0f;
         pred_v[r] = (kNearby && active) ? p.pred_uv[2 * i + 1] : 0.0f;
     }
 
+#ifdef FTK_MATCH_STAMPS
+    asm volatile("" ::"v"(ref[0][0]));
+    const unsigned long long stamp_after_load = __builtin_amdgcn_s_memrealtime();
+#endif
+    __builtin_amdgcn_s_setprio(0);
     uint32_t best_d[kRefs];
     int best_j[kRefs];
 #pragma unroll
@@ -286,9 +327,20 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
             }
         }
     }
+#ifdef FTK_MATCH_STAMPS
+    if (threadIdx.x == 0 && p.stamps) {
+        unsigned long long *st = p.stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        st[0] = stamp_t0;
+        st[1] = __builtin_amdgcn_s_memtime() - stamp_c0;  // shader-clock ticks over the workgroup's life
+        (void)stamp_after_load;
+        st[2] = __builtin_amdgcn_s_memrealtime();
+        st[3] = ((stamp_args - stamp_t0) << 40) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 11) | 20) & 0xF) << 32) |
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < kRefs; ++r) {
-        const int i = i_base + r;
+        const int i = i_base + r * kBlock;
         // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
         if (i < p.n_ref && best_j[r] >= 0 && (float)best_d[r] < p.max_distance) {
             const unsigned long long packed = ((unsigned long long)best_d[r] << 32) | (unsigned)best_j[r];
