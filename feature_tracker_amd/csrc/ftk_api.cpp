@@ -230,6 +230,17 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         waves = atoi(env);  // experiment override
     }
     p.waves_per_feature = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    // One-wave features are packed several to a workgroup (no barrier between them): the 16 workgroups a CU admits would
+    // otherwise cap it at 16 resident features = 4 waves per SIMD, below what the registers allow.
+    p.features_per_group = 1;
+    const bool pipelined_candidate = model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.patch_rows <= 64 && p.patch_cols <= 64;
+    if (p.waves_per_feature == 1 && pipelined_candidate) {
+        int group = 1;  // measured (config 5): 2 / 4 per workgroup buy nothing — the SIMDs are already saturated at 4 waves
+        if (const char *env = getenv("FTK_KLT_GROUP")) {
+            group = atoi(env);  // experiment override
+        }
+        p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
+    }
     // Basic KLT inverse runs the pipelined kernel (klt_basic_kernels.hip) when its single-wave table
     // builders can hold the patch (<= 64 rows / columns) and coordinates stay exact integers in fp32.
     p.pb_enabled = 0;
@@ -240,6 +251,9 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         }
         const char *env = getenv("FTK_KLT_PIPELINED");
         p.pb_enabled = (small && !(env && atoi(env) == 0)) ? 1 : 0;
+    }
+    if (!p.pb_enabled) {
+        p.features_per_group = 1;  // the generic kernel's workgroup is one feature
     }
     p.pb_rwin_rows = p.patch_rows + 4;
     p.pb_rwin_cols = (p.patch_cols + 4 + 3) & ~3;
@@ -256,6 +270,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         };
         p.pb_cap_r = p.patch_rows + 2 + extras(p.patch_rows);
         p.pb_cap_c = p.patch_cols + 2 + extras(p.patch_cols);
+        if (const char *env = getenv("FTK_PB_EXTRAS_TIMING_ONLY")) {  // TIMING experiment: a capacity below the provable maximum gives wrong results
+            p.pb_cap_r = p.patch_rows + 2 + atoi(env);
+            p.pb_cap_c = p.patch_cols + 2 + atoi(env);
+        }
     }
     const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
     if (lds == 0 || lds > 160 * 1024) {

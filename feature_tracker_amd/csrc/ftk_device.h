@@ -47,6 +47,9 @@ struct KltParams {
     uint32_t magic_rwc, magic_cwc;  // division by window cols
     uint32_t magic_rwq, magic_cwq;  // division by window cols / 4
     int32_t waves_per_feature;  // workgroup = 64 * waves_per_feature lanes
+    int32_t features_per_group; // > 1 (only with waves_per_feature == 1): that many one-wave features share a workgroup, without
+                                // meeting at a barrier (lifts the 16-workgroups-per-CU cap on resident one-wave features)
+    int32_t group_lds_stride;   // bytes between the LDS carves of the features of a group (filled by the launcher)
     // pipelined Basic-KLT inverse kernel (klt_basic_kernels.hip); pb_enabled = 0 selects the generic kernel
     int32_t pb_enabled;
     int32_t pb_rwin_rows, pb_rwin_cols;  // reference window incl. the rounding row / column: 2h+5 (cols padded to 4)

@@ -336,15 +336,46 @@ __device__ __forceinline__ uint32_t magic20(int d) {
 #define FTK_WAVES_PER_EU 4
 #endif
 
+// Workgroup barrier — or, for one-wave features packed several to a workgroup (solo), only a compiler fence: LDS operations of
+// one wave execute in program order, and the other waves of the group work on other features.
+__device__ __forceinline__ void pb_sync(bool solo) {
+    if (solo) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// SOLO: one wave per feature, p.features_per_group features per workgroup (compile-time, so that the one-wave code carries none
+// of the producer / consumer split).
+template <bool SOLO>
 __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
-    b.tid = threadIdx.x;
-    b.nt = blockDim.x;
-    b.lane = b.tid & (kWave - 1);
-    b.wave = b.tid >> 6;
-    b.nwaves = b.nt >> 6;
-    const uint32_t id = blockIdx.x;
+    uint32_t id;
+    float4 *lds_mine = lds_raw;
+    if (SOLO) {
+        // One wave per feature, several features per workgroup: the waves of the group share nothing but the launch (each has
+        // its own LDS carve and never meets the others at a barrier — pb_sync is a wave-local fence here).  The hardware admits
+        // 16 workgroups per CU; packing lifts the cap of 16 ONE-wave features per CU (4 waves per SIMD) to what the
+        // registers allow.
+        b.tid = b.lane = threadIdx.x & (kWave - 1);
+        b.nt = kWave;
+        b.wave = 0;
+        b.nwaves = 1;
+        const uint32_t slot = threadIdx.x >> 6;
+        id = blockIdx.x * (uint32_t)p.features_per_group + slot;
+        lds_mine = lds_raw + (size_t)slot * (p.group_lds_stride >> 4);
+    } else {
+        b.tid = threadIdx.x;
+        b.nt = blockDim.x;
+        b.lane = b.tid & (kWave - 1);
+        b.wave = b.tid >> 6;
+        b.nwaves = b.nt >> 6;
+        id = blockIdx.x;
+    }
+    constexpr bool solo = SOLO;
     if (id >= (uint32_t)p.n) {
         return;
     }
@@ -366,7 +397,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long stamp_real_t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, common to all CUs
 #endif
-    const PbLds c = pb_carve(lds_raw, p, b.nwaves);
+    const PbLds c = pb_carve(lds_mine, p, b.nwaves);
     const int np = pb_producers(b.nwaves);
     const bool producer = (b.nwaves == 1) || b.wave > 0;
     const bool consumer = b.wave == 0;
@@ -403,6 +434,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         const DevImage ref = p.ref[level];
         const DevImage cur = p.cur[level];
         set_level_priority(level);
+#ifdef FTK_PB_CHAIN_PRIO
+        if (b.nwaves > 1) {
+            // the exact-order chain is the feature's critical path: its wave outranks the producers sharing the SIMD
+            if (consumer) {
+                __builtin_amdgcn_s_setprio(3);
+            } else if (level >= 2) {
+                __builtin_amdgcn_s_setprio(2);
+            } else if (level == 1) {
+                __builtin_amdgcn_s_setprio(1);
+            } else {
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+#endif
         // ---- level entry: issue the window loads, build the node tables meanwhile ----
         Win rw, cw;
         rw.data = c.ref_win + buf * c.ref_win_stride;
@@ -446,7 +491,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 build_nodes_pass(lane, ac, none);
             }
         }
-        __syncthreads();  // B1: node tables (and this level's reference window) visible
+        pb_sync(solo);  // B1: node tables (and this level's reference window) visible
         FTK_STAMP_END(b, 0);
         // ---- lattice: one bilinear per node pair ----
         const int n_r = (int)c.slots[0], n_c = (int)c.slots[1];
@@ -472,7 +517,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 stage_any(opaque_blk(b), p.ref[level - 1], c.ref_win + (buf ^ 1) * c.ref_win_stride, nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
             }
         }
-        __syncthreads();  // B2: lattice and windows visible
+        pb_sync(solo);  // B2: lattice and windows visible
         FTK_STAMP_END(b, 1);
 
         // ---- Gauss-Newton iterations (TrackOneFeature, basic_klt.cpp:88-116) ----
@@ -489,7 +534,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     cw.r_lo = wadd(need_r, -p.cwin_margin);
                     cw.c_lo = wadd(need_c, -p.cwin_margin);
                     stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
-                    __syncthreads();
+                    pb_sync(solo);
                 }
             }
             FTK_STAMP_END(b, 2);
@@ -510,7 +555,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                         c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;
                     }
                 }
-                __syncthreads();
+                pb_sync(solo);
                 if (consumer && b.lane < kTerms) {
                     for (int q = 0; q < np; ++q) {
                         if (s * np + q < n_chunks) {
@@ -534,7 +579,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     c.sol[1] = sol[1];
                 }
             }
-            __syncthreads();  // B3: solution and valid counts visible
+            pb_sync(solo);  // B3: solution and valid counts visible
             FTK_STAMP_END(b, 5);
             uint32_t n_valid = 0;
             for (int w = (b.nwaves == 1 ? 0 : 1); w < b.nwaves; ++w) {
@@ -601,18 +646,39 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 
 }  // namespace
 
-size_t klt_basic_pipelined_lds_bytes(const KltParams &p) { return pb_lds_bytes(p, p.waves_per_feature); }
+size_t klt_basic_pipelined_lds_bytes(const KltParams &p) {
+    const size_t one = pb_lds_bytes(p, p.waves_per_feature);
+    return p.features_per_group > 1 ? one * (size_t)p.features_per_group : one;
+}
 
-hipError_t klt_basic_pipelined_launch(const KltParams &p, hipStream_t stream) {
+hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream) {
+    KltParams p = p_in;
+    if (p.waves_per_feature == 1) {
+        if (p.features_per_group < 1) {
+            p.features_per_group = 1;
+        }
+        p.group_lds_stride = (int32_t)pb_lds_bytes(p, 1);  // a multiple of 16
+    } else {
+        p.features_per_group = 1;
+    }
     const size_t lds = klt_basic_pipelined_lds_bytes(p);
-    auto kernel = klt_basic_inverse_pipelined_kernel;
+    const bool solo = p.features_per_group > 1 || p.waves_per_feature == 1;
+    if (solo && p.features_per_group < 1) {
+        p.features_per_group = 1;
+    }
+    auto kernel = solo ? klt_basic_inverse_pipelined_kernel<true> : klt_basic_inverse_pipelined_kernel<false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             return e;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds, stream, p);
+    if (solo) {
+        const unsigned groups = (unsigned)((p.n + p.features_per_group - 1) / p.features_per_group);
+        hipLaunchKernelGGL(kernel, dim3(groups), dim3(kWave * p.features_per_group), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds, stream, p);
+    }
     return hipGetLastError();
 }
 

@@ -48,11 +48,22 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 // Thread coordinates inside the feature's workgroup.
 struct Blk {
     int tid, nt, lane, wave, nwaves;
+    bool solo = false;  // compile-time true in the one-wave instantiations: no workgroup barrier anywhere, cross-wave exchanges fold away
 #ifdef FTK_STAMPS
     mutable unsigned long long stamp_t0 = 0;
     mutable unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 };
+
+// Workgroup barrier; for a one-wave feature only a compiler fence (LDS operations of one wave execute in program order).
+__device__ __forceinline__ void blk_sync(const Blk &b) {
+    if (b.solo) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
 
 // Returns x behind an optimisation barrier: per-thread index math derived from it is recomputed where
 // it is used instead of being hoisted out of the level loop and held in VGPRs for the whole kernel.

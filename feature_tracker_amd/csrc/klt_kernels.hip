@@ -87,15 +87,19 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
 // Workgroup-wide sum of the per-wave valid-pixel counts.  The leading barrier also publishes the
 // terms written in phase A; the trailing one lets the slots be reused.
 __device__ __forceinline__ uint32_t block_total(const Blk &b, uint32_t wave_sum, uint32_t *slots) {
+    if (b.solo) {
+        blk_sync(b);  // keeps the "terms are published" ordering the callers rely on
+        return wave_sum;
+    }
     if (b.lane == 0) {
         slots[b.wave] = wave_sum;
     }
-    __syncthreads();
+    blk_sync(b);
     uint32_t total = 0;
     for (int w = 0; w < b.nwaves; ++w) {
         total += slots[w];
     }
-    __syncthreads();
+    blk_sync(b);
     return total;
 }
 
@@ -113,10 +117,14 @@ __device__ __forceinline__ void publish_count(const Blk &b, uint32_t wave_sum, u
 // barrier in between (0 / 1: iteration parity, 2 / 3: level setup fast / slow pass).
 __device__ __forceinline__ bool block_any(const Blk &b, bool flag, uint32_t *slots, uint32_t bank) {
     const bool wave_any = __ballot(flag) != 0ull;
+    if (b.solo) {
+        blk_sync(b);
+        return wave_any;
+    }
     if (b.lane == 0) {
         slots[8 + bank * 4 + b.wave] = wave_any ? 1u : 0u;
     }
-    __syncthreads();
+    blk_sync(b);
     uint32_t any = 0;
     for (int w = 0; w < b.nwaves; ++w) {
         any |= slots[8 + bank * 4 + w];
@@ -134,12 +142,12 @@ __device__ __forceinline__ uint32_t collect_count(const Blk &b, const uint32_t *
 
 __device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int K, int Ppad, float *sums, bool leading_barrier = false) {
     if (leading_barrier) {
-        __syncthreads();  // phase A's terms (and published counts) become visible
+        blk_sync(b);  // phase A's terms (and published counts) become visible
     }
     if (b.wave == 0 && b.lane < K) {
         sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
     }
-    __syncthreads();
+    blk_sync(b);
 }
 
 // Phase B + C on wave 0 only: after its chain lanes have published the K sums, wave 0 runs
@@ -149,7 +157,7 @@ __device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int
 template <typename F>
 __device__ __forceinline__ void chain_then(const Blk &b, const float *terms, int K, int Ppad, float *sums, bool leading_barrier, F &&wave0_work) {
     if (leading_barrier) {
-        __syncthreads();  // phase A's terms (and published counts) become visible
+        blk_sync(b);  // phase A's terms (and published counts) become visible
     }
     if (b.wave == 0) {
         if (b.lane < K) {
@@ -157,7 +165,7 @@ __device__ __forceinline__ void chain_then(const Blk &b, const float *terms, int
         }
         wave0_work();
     }
-    __syncthreads();
+    blk_sync(b);
 }
 
 __device__ __forceinline__ void zero_term_padding(const Blk &b, float *terms, int K, const KltParams &p) {
@@ -220,7 +228,7 @@ __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParam
         stage_any(b, ref, c.ref_win, rw.r_lo, rw.c_lo, rw.rows, rw.cols, p.magic_rwc, p.magic_rwq);
         stage_any(b, cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
     }
-    __syncthreads();
+    blk_sync(b);
 }
 
 // Makes sure the current-image window covers the footprint of a patch centred at (u, v); restages
@@ -239,7 +247,7 @@ __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams 
         w.cols = p.cwin_cols;
         w.data = c.cur_win;
         stage_any(b, cur, c.cur_win, w.r_lo, w.c_lo, w.rows, w.cols, p.magic_cwc, p.magic_cwq);
-        __syncthreads();
+        blk_sync(b);
         staged = true;
     }
 }
@@ -511,7 +519,7 @@ __device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, co
         if (block_any(b, miss, c.wave_cnt, iter & 1u)) {
             n_valid = phase_a(std::true_type{}, miss);
             publish_count(b, n_valid, c.wave_cnt, iter);
-            __syncthreads();
+            blk_sync(b);
         }
         FTK_STAMP_END(b, 4);
         chain_then(b, c.terms, 5, p.Ppad, c.sums, false, [&]() {
@@ -574,7 +582,7 @@ __device__ __forceinline__ void basic_level_fast(const Blk &b, const KltParams &
         c.terms[1 * p.Ppad + pxi] = dx * dy;
         c.terms[2 * p.Ppad + pxi] = dy * dy;
     }
-    __syncthreads();
+    blk_sync(b);
     chain_sums(b, c.terms, 3, p.Ppad, c.sums);
     const float h00 = c.sums[0], h01 = c.sums[1], h11 = c.sums[2];
 
@@ -822,7 +830,7 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
         const float y = (float)(prow - p.half_rows) + s.cur_v;
         affine_hessian_terms(p, c.terms, pxi, has_gradient, x, y, dx, dy);
     }
-    __syncthreads();
+    blk_sync(b);
     // The Hessian is fixed for the level (affine_klt_fast.cpp:71-138), so it is FACTORISED once here — rows on
     // lanes 0..5 of wave 0 — and every iteration below only runs the two triangular solves (same arithmetic as
     // factorising each time: the factorisation is a pure function of H).
@@ -1016,7 +1024,7 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
         const float ref_average = c.sums[0] / (float)n_valid;
         const float cur_average = c.sums[1] / (float)n_valid;
         const float grad_average = (METHOD == FTK_METHOD_INVERSE) ? ref_average : cur_average;
-        __syncthreads();  // sums[] is rewritten by the second chain below
+        blk_sync(b);  // sums[] is rewritten by the second chain below
 
         // pass 2 (:186-247): mean-normalised Jacobian and residual
         for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
@@ -1035,14 +1043,14 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
             const float residual = icur[pxi] / cur_average - c.a3[pxi] / ref_average;
             lssd_terms(p, c.terms, pxi, ok, j0, j1, j2, residual);
         }
-        __syncthreads();
+        blk_sync(b);
         if (n_valid == 0) {
             break;
         }
         chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
         float v[3];
         const bool solved = lssd_solve_and_update(c.sums, s, v, status);
-        __syncthreads();  // sums[] is rewritten by the first chain of the next iteration
+        blk_sync(b);  // sums[] is rewritten by the first chain of the next iteration
         if (!solved) {
             break;
         }
@@ -1078,7 +1086,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         // interior of the extended patch in row-major order == the P patch pixels
         c.terms[pxi] = ex[(prow + 1) * p.ex_cols + pcol + 1];
     }
-    __syncthreads();
+    blk_sync(b);
     if (p.consider_luminance) {
         // :27-46 — numerator: interior of the extended patch; denominator: valid count of the WHOLE extended patch
         chain_sums(b, c.terms, 1, p.Ppad, c.sums);
@@ -1090,7 +1098,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         for (int i = b.tid; i < p.E; i += b.nt) {
             ex[i] /= ref_average;
         }
-        __syncthreads();
+        blk_sync(b);
     }
 
     status = FTK_LARGE_RESIDUAL;
@@ -1153,7 +1161,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
             chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
             float v[3];
             const bool solved = lssd_solve_and_update(c.sums, s, v, status);
-            __syncthreads();
+            blk_sync(b);
             if (!solved) {
                 break;
             }
@@ -1200,7 +1208,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
             for (int i = b.tid; i < p.P; i += b.nt) {
                 curp[i] /= cur_average;
             }
-            __syncthreads();
+            blk_sync(b);
         }
 
         // ComputeHessianAndBias (:197-229)
@@ -1231,7 +1239,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
         float v[3];
         const bool solved = lssd_solve_and_update(c.sums, s, v, status);
-        __syncthreads();  // sums[] may be rewritten by the luminance chain of the next iteration
+        blk_sync(b);  // sums[] may be rewritten by the luminance chain of the next iteration
         if (!solved) {
             break;
         }
@@ -1271,16 +1279,19 @@ constexpr int kMaxWaves = 4;
 
 // The direct affine variant (6x6 LDLT + 24 chains + five current-image taps in registers) does not fit 128 VGPRs
 // without spilling; it runs at 3 waves per SIMD instead.
-template <int MODEL, int METHOD>
+// SOLO: the one-wave-per-feature instantiation (workgroup = one wavefront): compile-time, so that no barrier and no cross-wave
+// exchange is left in it.
+template <int MODEL, int METHOD, bool SOLO>
 __global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && METHOD == FTK_METHOD_DIRECT) ? 3 : FTK_WAVES_PER_EU)))
 __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
+    b.solo = SOLO;
     b.tid = threadIdx.x;
-    b.nt = blockDim.x;
+    b.nt = SOLO ? kWave : (int)blockDim.x;
     b.lane = b.tid & (kWave - 1);
-    b.wave = b.tid >> 6;
-    b.nwaves = b.nt >> 6;
+    b.wave = SOLO ? 0 : b.tid >> 6;
+    b.nwaves = SOLO ? 1 : b.nt >> 6;
     const uint32_t id = blockIdx.x;
     if (id >= (uint32_t)p.n) {
         return;
@@ -1336,7 +1347,7 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     for (int level = p.n_levels - 1; level > -1; --level) {
         const DevImage ref = p.ref[level];
         const DevImage cur = p.cur[level];
-        __syncthreads();  // the previous level's readers of the LDS windows / arrays are done
+        blk_sync(b);  // the previous level's readers of the LDS windows / arrays are done
         const Blk b = opaque_blk(b0);  // per-thread index math stays inside the level (see opaque())
         set_level_priority(level);
         if (MODEL == FTK_MODEL_BASIC) {
@@ -1411,7 +1422,7 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
 
 template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = klt_track_kernel<MODEL, METHOD>;
+    auto kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true> : klt_track_kernel<MODEL, METHOD, false>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {

@@ -6,10 +6,11 @@ TAG=$1; EXTRA=${2:-}
 cd "$(dirname "$0")/../feature_tracker_amd/csrc"
 T=$(mktemp -d)
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero $EXTRA"
-for f in klt_kernels klt_basic_kernels matcher_kernels float_matcher_kernels direct_kernels pyramid_kernels feature_kernels; do hipcc $F -c -o $T/$f.o $f.hip & done
-hipcc $F -x hip -c -o $T/ftk_api.o ftk_api.cpp &
+pids=""
+for f in klt_kernels klt_basic_kernels matcher_kernels float_matcher_kernels direct_kernels pyramid_kernels feature_kernels; do hipcc $F -c -o $T/$f.o $f.hip & pids="$pids $!"; done
+hipcc $F -x hip -c -o $T/ftk_api.o ftk_api.cpp & pids="$pids $!"
 hipcc $F -x hip -c -o $T/ftk_comm.o ftk_comm.cpp
-wait
+for p in $pids; do wait $p; done  # a failed compile fails the script (set -e)
 mkdir -p diag
 hipcc -shared -fPIC --offload-arch=gfx950 -o diag/libftk_hip_$TAG.so $T/*.o -ldl
 rm -rf $T
