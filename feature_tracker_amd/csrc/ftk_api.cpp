@@ -252,8 +252,25 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         const char *env = getenv("FTK_KLT_PIPELINED");
         p.pb_enabled = (small && !(env && atoi(env) == 0)) ? 1 : 0;
     }
+    // LSSD fast, one wave per feature, no luminance scaling: the chunked sweep / chain variant (a 64-pixel ring instead of all
+    // P products of all nine chains in LDS; config 4: 304 -> 242 us)
+    p.terms_floats = 0;
+    p.lssd_chunked = 0;
+    const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
+    const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
+    if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && !p.consider_luminance && !(chunk_env && atoi(chunk_env) == 0)) {
+        p.lssd_chunked = 1;
+        p.terms_floats = 9 * 68;
+    }
     if (!p.pb_enabled) {
-        p.features_per_group = 1;  // the generic kernel's workgroup is one feature
+        p.features_per_group = 1;  // the generic kernel's workgroup is one feature ...
+        if (p.waves_per_feature == 1) {
+            int group = 1;  // ... or, one-wave variants, a few features that never meet (measured on config 4: 2-4 buy nothing)
+            if (const char *env = getenv("FTK_KLT_GROUP")) {
+                group = atoi(env);  // experiment override
+            }
+            p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
+        }
     }
     p.pb_rwin_rows = p.patch_rows + 4;
     p.pb_rwin_cols = (p.patch_cols + 4 + 3) & ~3;

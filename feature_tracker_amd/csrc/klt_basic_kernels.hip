@@ -296,33 +296,6 @@ __device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltPara
     return ok;
 }
 
-// 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave), 16 terms per batch in two
-// ping-pong register sets.  The compiler hoists every ds_read of the unrolled chunk to its top if it may (64 VGPRs
-// of terms live at once — the difference between 4 and 5-6 waves per SIMD for this kernel); sched_barrier does not
-// stop that, a data dependency does: the address of batch k + 2 is tied to the accumulator after batch k, so its
-// reads issue exactly when their registers are free, one batch (16 dependent adds) ahead of their use.
-__device__ __forceinline__ int chain_tie(float acc) {
-    int zero = 0;
-    asm volatile("" : "+v"(zero) : "v"(acc));
-    return zero;
-}
-
-__device__ __forceinline__ float chain_chunk(float acc, const float *row) {
-    static_assert(kChainRound == 4 && kChunk == 64, "chain_chunk is written for 4 batches of 16 terms");
-    const float4 *t = reinterpret_cast<const float4 *>(row);
-    float4 qa[kChainRound], qb[kChainRound];
-    chain_load(qa, t);
-    chain_load(qb, t + kChainRound);
-    acc = chain_consume_all(acc, qa);
-    chain_load(qa, t + 2 * kChainRound + chain_tie(acc));
-    acc = chain_consume_all(acc, qb);
-    chain_load(qb, t + 3 * kChainRound + chain_tie(acc));
-    acc = chain_consume_all(acc, qa);
-    acc = chain_consume_all(acc, qb);
-    return acc;
-}
-
-
 // Exact ceil(2^20 / d) for 1 <= d <= 4096: q = (i * m) >> 20 equals i / d for i < 2^20 / d... (i * d < 2^20)
 __device__ __forceinline__ uint32_t magic20(int d) {
     uint32_t m = (uint32_t)(1048576.0f / (float)d);

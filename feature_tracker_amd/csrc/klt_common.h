@@ -147,6 +147,25 @@ __device__ __forceinline__ float bilinear(const DevImage &im, const Win &w, floa
     return w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
 }
 
+// bilinear() for coordinates the caller knows to be inside the image with room for the +1 neighbours (0 <= row <= rows - 2,
+// 0 <= col <= cols - 2, finite): truncation is floor there and no index needs clamping, so the same values come out of fewer
+// instructions.
+__device__ __forceinline__ float bilinear_inside(const DevImage &im, const Win &w, float row, float col) {
+    const int r0 = (int)row;
+    const int c0 = (int)col;
+    const float sub_row = row - (float)r0;
+    const float sub_col = col - (float)c0;
+    const float inv_sub_row = 1.0f - sub_row;
+    const float inv_sub_col = 1.0f - sub_col;
+    const float w_tl = inv_sub_row * inv_sub_col;
+    const float w_tr = inv_sub_row * sub_col;
+    const float w_bl = sub_row * inv_sub_col;
+    const float w_br = sub_row * sub_col;
+    float p00, p01, p10, p11;
+    fetch4(im, w, r0, c0, p00, p01, p10, p11);
+    return w_tl * p00 + w_tr * p01 + w_bl * p10 + w_br * p11;
+}
+
 // GrayImage::GetPixelValue(row, col, *value): closed-rectangle validity, NaN invalid.  Inside the
 // rectangle truncation equals floor, so the fractions need no floor fix-up.
 __device__ __forceinline__ bool sample(const DevImage &im, const Win &w, float row, float col, float &value) {
@@ -393,6 +412,104 @@ __device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N]
     }
 }
 
+// ldlt_solve<3> written out for the symmetric 3x3 system of the LSSD trackers (lssd_klt.cpp:107, lssd_klt_fast.cpp:87): the
+// same operations in the same order — Eigen's LDLT is left-looking, so the pivot search of step k sees ORIGINAL diagonal
+// entries (moved by the swaps) and the two transpositions can be decided up front; only the lower triangle is ever read.
+// ~40 % of the instructions of the generic unrolled form (no 3x3 array with predicated swaps of every element).
+__device__ __forceinline__ void ldlt3_solve(float a00, float a10, float a20, float a11, float a21, float a22, const float (&b)[3], float (&x)[3]) {
+    // step 0: pivot = first maximum of |a00|, |a11|, |a22|
+    float m00 = a00, m10 = a10, m20 = a20, m11 = a11, m21 = a21, m22 = a22;
+    const float d0 = fabsf(m00), d1 = fabsf(m11), d2 = fabsf(m22);
+    int p0 = 0;
+    float biggest = d0;
+    if (d1 > biggest) {
+        biggest = d1;
+        p0 = 1;
+    }
+    if (d2 > biggest) {
+        p0 = 2;
+    }
+    if (p0 == 1) {  // rows / columns 0 <-> 1 of the lower triangle: m[2][0] <-> m[2][1], the diagonals
+        swap_values(m20, m21);
+        swap_values(m00, m11);
+    } else if (p0 == 2) {  // 0 <-> 2: the diagonals, m[1][0] <-> m[2][1]
+        swap_values(m00, m22);
+        swap_values(m10, m21);
+    }
+    const bool valid0 = fabsf(m00) > 0.0f;
+    const bool degenerate = !valid0;  // a zero first pivot: Eigen stops, the transpositions become the identity
+    int p1 = 1;
+    if (!degenerate) {
+        m10 /= m00;
+        m20 /= m00;
+        // step 1: pivot among the remaining diagonals
+        if (fabsf(m22) > fabsf(m11)) {
+            p1 = 2;
+            swap_values(m10, m20);
+            swap_values(m11, m22);
+        }
+        {
+            const float temp0 = m00 * m10;
+            const float dot = m10 * temp0;
+            m11 -= dot;
+            const float s = m20 * temp0;
+            m21 -= s;
+        }
+        if (fabsf(m11) > 0.0f) {
+            m21 /= m11;
+        }
+        // step 2
+        {
+            const float temp0 = m00 * m20, temp1 = m11 * m21;
+            float dot = m20 * temp0;
+            dot += m21 * temp1;
+            m22 -= dot;
+        }
+    } else {
+        p0 = 0;
+    }
+    // y = P b
+    float y0 = b[0], y1 = b[1], y2 = b[2];
+    if (p0 == 1) {
+        swap_values(y0, y1);
+    } else if (p0 == 2) {
+        swap_values(y0, y2);
+    }
+    if (p1 == 2) {
+        swap_values(y1, y2);
+    }
+    // L^-1
+    y1 -= m10 * y0;
+    {
+        float s = m20 * y0;
+        s += m21 * y1;
+        y2 -= s;
+    }
+    // D^+
+    y0 = (fabsf(m00) > 1.17549435e-38f) ? y0 / m00 : 0.0f;
+    y1 = (fabsf(m11) > 1.17549435e-38f) ? y1 / m11 : 0.0f;
+    y2 = (fabsf(m22) > 1.17549435e-38f) ? y2 / m22 : 0.0f;
+    // L^-T
+    y1 -= m21 * y2;
+    {
+        float s = m10 * y1;
+        s += m20 * y2;
+        y0 -= s;
+    }
+    // P^T
+    if (p1 == 2) {
+        swap_values(y1, y2);
+    }
+    if (p0 == 1) {
+        swap_values(y0, y1);
+    } else if (p0 == 2) {
+        swap_values(y0, y2);
+    }
+    x[0] = y0;
+    x[1] = y1;
+    x[2] = y2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same 6x6 LDLT, rows spread over lanes (affine trackers, direct method).
 //
@@ -602,6 +719,36 @@ __device__ __forceinline__ float chain_lane(const float *row, int Ppad) {
     acc = chain_consume(acc, qb, rem - kChainRound);
     return acc;
 }
+
+// 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave), 16 terms per batch in two
+// ping-pong register sets.  The compiler hoists every ds_read of the unrolled chunk to its top if it may (64 VGPRs
+// of terms live at once — the difference between 4 and 5-6 waves per SIMD for this kernel); sched_barrier does not
+// stop that, a data dependency does: the address of batch k + 2 is tied to the accumulator after batch k, so its
+// reads issue exactly when their registers are free, one batch (16 dependent adds) ahead of their use.
+__device__ __forceinline__ int chain_tie(float acc) {
+    int zero = 0;
+    asm volatile("" : "+v"(zero) : "v"(acc));
+    return zero;
+}
+
+__device__ __forceinline__ float chain_chunk(float acc, const float *row) {
+    static_assert(kChainRound == 4, "chain_chunk is written for 4 batches of 16 terms (a 64-pixel chunk)");
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    float4 qa[kChainRound], qb[kChainRound];
+    chain_load(qa, t);
+    chain_load(qb, t + kChainRound);
+    acc = chain_consume_all(acc, qa);
+    chain_load(qa, t + 2 * kChainRound + chain_tie(acc));
+    acc = chain_consume_all(acc, qb);
+    chain_load(qb, t + 3 * kChainRound + chain_tie(acc));
+    acc = chain_consume_all(acc, qa);
+    acc = chain_consume_all(acc, qb);
+    return acc;
+}
+
+
+constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked sweep / chain loops = one wave round
+constexpr int kChunkRow = kChunkPixels + 4;   // ring row pitch in floats: the chain lanes' 16-byte reads of different rows hit different banks
 
 __device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow, int &pcol) {
     prow = (p.patch_cols == 1) ? pxi : (int)__umulhi((unsigned)pxi, p.magic_pc);

@@ -62,7 +62,7 @@ __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 
 __host__ __device__ inline size_t carve_bytes(int K, const KltParams &p) {
     const size_t epad = (size_t)pad4(p.E);
-    const size_t floats = (size_t)K * p.Ppad + (size_t)p.a0_floats + 3 * (size_t)p.Ppad + 72 + 24;
+    const size_t floats = (size_t)(p.terms_floats > 0 ? p.terms_floats : K * p.Ppad) + (size_t)p.a0_floats + 3 * (size_t)p.Ppad + 72 + 24;
     const size_t shorts = (size_t)pad4(p.rwin_rows * p.rwin_cols) + (size_t)pad4(p.cwin_rows * p.cwin_cols);
     return sizeof(float) * floats + sizeof(uint16_t) * shorts + epad + (size_t)p.Ppad;
 }
@@ -71,7 +71,7 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
     Carve c;
     const int epad = pad4(p.E);
     c.terms = base;
-    c.a0 = c.terms + K * p.Ppad;
+    c.a0 = c.terms + (p.terms_floats > 0 ? p.terms_floats : K * p.Ppad);
     c.a1 = c.a0 + p.a0_floats;
     c.a2 = c.a1 + p.Ppad;
     c.a3 = c.a2 + p.Ppad;
@@ -953,10 +953,9 @@ __device__ __forceinline__ void lssd_terms(const KltParams &p, float *terms, int
 // Wave 0: solves the 3x3 system from the nine chain sums and publishes v in sums[16..18].
 __device__ __forceinline__ void lssd_solve(float *sums) {
     const float h00 = sums[0], h01 = sums[1], h02 = sums[2], h11 = sums[3], h12 = sums[4], h22 = sums[5];
-    float m[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, h22}};
     const float bb[3] = {sums[6], sums[7], sums[8]};
     float sol[3];
-    ldlt_solve<3>(m, bb, sol);
+    ldlt3_solve(h00, h01, h02, h11, h12, h22, bb, sol);
     sums[16] = sol[0];
     sums[17] = sol[1];
     sums[18] = sol[2];
@@ -1249,6 +1248,132 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
     }
 }
 
+// TrackOneFeatureFast (lssd_klt_fast.cpp:7-229) for a ONE-WAVE feature without the luminance scaling: the sweep and the chain
+// alternate over 64-pixel chunks through a one-slot ring in LDS (9 rows x 64 products) instead of laying all P products of all
+// nine chains out first — 2.4 KB of LDS instead of 6.2 KB at 13 x 13, which is what caps the resident features per CU for this
+// variant — and the nine sums stay in the chain lanes' registers (broadcast by v_readlane, no round trip through LDS).  Same
+// per-pixel expressions, same row-major order of every sum as lssd_level_fast: bit-identical.
+__device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                        float ref_v, LssdState &s, uint8_t &status, uint32_t &iters, Carve &c) {
+    float *ex = c.a0, *dxs = c.a1, *dys = c.a2;
+    uint8_t *exv = c.flagsE;
+    float *ring = c.terms;  // [9][kChunkRow]
+    Win rw, cw;
+    float level_centre_u, level_centre_v;
+    se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
+    bool cw_staged = true;
+    const uint32_t ref_valid_num = extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c);
+    if (ref_valid_num == 0) {
+        status = FTK_OUTSIDE;
+        return;
+    }
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        float dx, dy;
+        ex_gradient(p, ex, exv, prow, pcol, dx, dy);
+        dxs[pxi] = dx;
+        dys[pxi] = dy;
+    }
+    blk_sync(b);
+
+    status = FTK_LARGE_RESIDUAL;
+    float last_squared_step = INFINITY;
+    uint32_t large_step_cnt = 0;
+    const int n_chunks = (p.P + kChunkPixels - 1) / kChunkPixels;
+    for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
+        ++iters;
+        float centre_u, centre_v;
+        se2_apply(s, ref_u, ref_v, centre_u, centre_v);
+        ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
+        const int min_row = wadd(f2i(centre_v), -p.patch_rows);
+        const int min_col = wadd(f2i(centre_u), -p.patch_cols);
+        const int max_row = wadd(min_row, p.patch_rows * 2);
+        const int max_col = wadd(min_col, p.patch_cols * 2);
+        const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
+        uint32_t cur_valid_num = 0, n_valid = 0;
+        float acc = 0.0f;
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int pxi = chunk * kChunkPixels + b.lane;
+            const bool in = pxi < p.P;
+            const int pp = in ? pxi : 0;
+            int prow, pcol;
+            pixel_rc(p, pp, prow, pcol);
+            const float row_i = (float)(prow - p.half_rows) + ref_v;
+            const float col_i = (float)(pcol - p.half_cols) + ref_u;
+            float row_j, col_j;
+            se2_apply(s, col_i, row_i, col_j, row_j);
+            float value = 0.0f;
+            bool ok_cur;
+            if (partly_outside) {
+                ok_cur = sample(cur, cw, row_j, col_j, value);
+                if (!ok_cur) {
+                    value = 0.0f;
+                }
+            } else {
+                // the unchecked bilinear (lssd_klt_fast.cpp:189); when every lane's sample lies inside the image with room for
+                // its +1 neighbours (the normal case: a rotation moves a pixel less than the conservative window above allows
+                // for) the cheaper form gives the same values
+                const bool roomy = row_j >= 0.0f && col_j >= 0.0f && row_j <= (float)(cur.rows - 2) && col_j <= (float)(cur.cols - 2);
+                if (__ballot(!roomy) == 0ull) {
+                    value = bilinear_inside(cur, cw, row_j, col_j);
+                } else {
+                    value = bilinear(cur, cw, row_j, col_j);
+                }
+                ok_cur = true;
+            }
+            ok_cur = ok_cur && in;
+            const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+            const bool ok = exv[ei] != 0 && ok_cur;
+            const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
+            const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
+            // An unused pixel contributes exact zeros to every sum (lssd_terms): zeroing the four factors does it with four
+            // selects instead of nine — the products are then +0 or -0, and x + (+-0) == x for every x a sum can hold (the
+            // sums start at +0 and +0 + (-0) == +0).
+            const float dx = ok ? dxs[pp] : 0.0f, dy = ok ? dys[pp] : 0.0f;
+            const float j0 = ok ? dxs[pp] * s0 + dys[pp] * s1 : 0.0f;
+            const float residual = ok ? value - ex[ei] : 0.0f;
+            ring[0 * kChunkRow + b.lane] = j0 * j0;
+            ring[1 * kChunkRow + b.lane] = j0 * dx;
+            ring[2 * kChunkRow + b.lane] = j0 * dy;
+            ring[3 * kChunkRow + b.lane] = dx * dx;
+            ring[4 * kChunkRow + b.lane] = dx * dy;
+            ring[5 * kChunkRow + b.lane] = dy * dy;
+            ring[6 * kChunkRow + b.lane] = -(j0 * residual);
+            ring[7 * kChunkRow + b.lane] = -(dx * residual);
+            ring[8 * kChunkRow + b.lane] = -(dy * residual);
+            cur_valid_num += (uint32_t)__popcll(__ballot(ok_cur));
+            n_valid += (uint32_t)__popcll(__ballot(ok));
+            blk_sync(b);  // one wave: LDS operations run in program order; this keeps the compiler from reordering across
+            if (b.lane < 9) {
+                acc = chain_chunk(acc, ring + b.lane * kChunkRow);
+            }
+            blk_sync(b);
+        }
+        if (cur_valid_num == 0 || n_valid == 0) {
+            break;  // lssd_klt_fast.cpp:60-63 / :80-83
+        }
+        // the nine sums sit in lanes 0..8: broadcast and solve (lssd_solve on registers)
+        const int acc_bits = __float_as_int(acc);
+        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
+        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
+        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5));
+        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7)),
+                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8))};
+        float v[3];
+        ldlt3_solve(h00, h01, h02, h11, h12, h22, bb, v);
+        if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
+            status = FTK_NUMERIC_ERROR;
+            break;
+        }
+        se2_update(s, v);
+        if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
+            break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-feature driver: TrackMultipleLevel / TrackSingleLevel of the three trackers
 // (basic_klt.cpp:7-86, affine_klt.cpp:6-91, lssd_klt.cpp:7-94).
@@ -1287,12 +1412,13 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
     b.solo = SOLO;
-    b.tid = threadIdx.x;
+    b.tid = SOLO ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
     b.nt = SOLO ? kWave : (int)blockDim.x;
     b.lane = b.tid & (kWave - 1);
     b.wave = SOLO ? 0 : b.tid >> 6;
     b.nwaves = SOLO ? 1 : b.nt >> 6;
-    const uint32_t id = blockIdx.x;
+    // SOLO: p.features_per_group one-wave features share a workgroup without ever meeting (own LDS carve, no barrier)
+    const uint32_t id = SOLO ? blockIdx.x * (uint32_t)p.features_per_group + (threadIdx.x >> 6) : blockIdx.x;
     if (id >= (uint32_t)p.n) {
         return;
     }
@@ -1315,8 +1441,14 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int K = ChainCount<MODEL>::value;
-    Carve c = carve_lds(reinterpret_cast<float *>(lds_raw), K, p);
-    zero_term_padding(b, c.terms, K, p);
+    float *lds_mine = reinterpret_cast<float *>(lds_raw);
+    if (SOLO && p.features_per_group > 1) {
+        lds_mine += (size_t)(threadIdx.x >> 6) * (p.group_lds_stride >> 2);
+    }
+    Carve c = carve_lds(lds_mine, K, p);
+    if (!(SOLO && p.lssd_chunked)) {
+        zero_term_padding(b, c.terms, K, p);
+    }
 
     const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
     const float scale = p.single_level ? 1.0f : (float)(1 << (p.n_levels - 1));
@@ -1364,7 +1496,11 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
             }
         } else {
             if (METHOD == FTK_METHOD_FAST) {
-                lssd_level_fast(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
+                if (SOLO && p.lssd_chunked) {
+                    lssd_level_fast_chunked(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
+                } else {
+                    lssd_level_fast(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
+                }
             } else {
                 lssd_level<METHOD>(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
             }
@@ -1429,7 +1565,12 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
             return e;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds_bytes, stream, p);
+    if (p.waves_per_feature == 1) {
+        const int group = p.features_per_group < 1 ? 1 : p.features_per_group;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((p.n + group - 1) / group)), dim3(kWave * group), lds_bytes, stream, p);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds_bytes, stream, p);
+    }
     return hipGetLastError();
 }
 
@@ -1452,7 +1593,8 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p) {
     if (k == 0) {
         return 0;
     }
-    return (carve_bytes(k, p) + 15) & ~(size_t)15;
+    const size_t one = (carve_bytes(k, p) + 15) & ~(size_t)15;
+    return (p.waves_per_feature == 1 && p.features_per_group > 1) ? one * (size_t)p.features_per_group : one;
 }
 
 namespace {
@@ -1495,12 +1637,19 @@ hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t str
         return klt_basic_pipelined_launch(p, stream);
     }
     const size_t lds = klt_lds_bytes(model, method, p);
+    KltParams pg = p;
+    if (pg.waves_per_feature == 1) {
+        if (pg.features_per_group < 1) {
+            pg.features_per_group = 1;
+        }
+        pg.group_lds_stride = (int32_t)(lds / (size_t)pg.features_per_group);  // a multiple of 16
+    }
     const int m = (method == FTK_METHOD_INVERSE || method == FTK_METHOD_DIRECT) ? method : FTK_METHOD_FAST;
 #define FTK_DISPATCH(MODEL)                                                               \
     switch (m) {                                                                          \
-        case FTK_METHOD_INVERSE: return launch_variant<MODEL, FTK_METHOD_INVERSE>(p, lds, stream); \
-        case FTK_METHOD_DIRECT: return launch_variant<MODEL, FTK_METHOD_DIRECT>(p, lds, stream);   \
-        default: return launch_variant<MODEL, FTK_METHOD_FAST>(p, lds, stream);                    \
+        case FTK_METHOD_INVERSE: return launch_variant<MODEL, FTK_METHOD_INVERSE>(pg, lds, stream); \
+        case FTK_METHOD_DIRECT: return launch_variant<MODEL, FTK_METHOD_DIRECT>(pg, lds, stream);   \
+        default: return launch_variant<MODEL, FTK_METHOD_FAST>(pg, lds, stream);                    \
     }
     switch (model) {
         case FTK_MODEL_BASIC: FTK_DISPATCH(FTK_MODEL_BASIC)
