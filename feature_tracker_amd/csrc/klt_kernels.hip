@@ -732,41 +732,90 @@ __device__ __forceinline__ void affine_apply_step(AffineState &s, const float (&
 }
 
 // TrackOneFeature, affine_klt.cpp:93-273.
+//
+// Work split of one iteration when the patch has more pixels than the workgroup has lanes (W = 2 at 13 x 13: 169 > 128): all waves
+// produce the products of the first 64 W pixels together; then wave 0 starts the exact-order chains on those while the other
+// waves produce the remaining pixels, and continues over the rest after one more barrier — the chain (the iteration's longest
+// dependent stretch) no longer waits for a second, mostly empty, round of sampling.  Same products, same row-major order.
 template <int METHOD>
 __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u, float ref_v,
                                              AffineState &s, uint8_t &status, uint32_t &iters, Carve &c) {
     Win rw, cw;
+    FTK_STAMP_BEGIN(b);
     stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw, (METHOD == FTK_METHOD_INVERSE) ? 3 : 1);
     bool cw_staged = true;
+    FTK_STAMP_END(b, 0);
     nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
+    FTK_STAMP_END(b, 1);
+    const bool staged = !b.solo && b.nwaves > 1 && p.P > b.nt;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        FTK_STAMP_BEGIN(b);
         ensure_cur_window(b, p, cur, s.cur_u, s.cur_v, c, cw, cw_staged);
-        uint32_t n_valid = 0;
         bool miss_unused = false;
-        for (int base = 0; base < p.P; base += b.nt) {
-            const int pxi = base + b.tid;
-            bool ok = false;
-            if (pxi < p.P) {
-                int prow, pcol;
-                pixel_rc(p, pxi, prow, pcol);
-                const float dcol = (float)(pcol - p.half_cols);
-                const float drow = (float)(prow - p.half_rows);
-                const float warped_x = s.a00 * dcol + s.a01 * drow;
-                const float warped_y = s.a10 * dcol + s.a11 * drow;
-                const float row_j = warped_y + s.cur_v;
-                const float col_j = warped_x + s.cur_u;
-                float dx, dy, i_ref, i_cur;
-                ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
-                const float dt = i_cur - i_ref;
-                affine_hessian_terms(p, c.terms, pxi, ok, col_j, row_j, dx, dy);
-                affine_bias_terms(p, c.terms, A_B0, pxi, ok, dt, col_j, row_j, dx, dy);
+        // the 24 products of one patch pixel -> terms[k][pxi]; returns whether the pixel is used
+        auto produce = [&](int pxi) -> bool {
+            int prow, pcol;
+            pixel_rc(p, pxi, prow, pcol);
+            const float dcol = (float)(pcol - p.half_cols);
+            const float drow = (float)(prow - p.half_rows);
+            const float warped_x = s.a00 * dcol + s.a01 * drow;
+            const float warped_y = s.a10 * dcol + s.a11 * drow;
+            const float row_j = warped_y + s.cur_v;
+            const float col_j = warped_x + s.cur_u;
+            float dx, dy, i_ref, i_cur;
+            const bool ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
+            const float dt = i_cur - i_ref;
+            affine_hessian_terms(p, c.terms, pxi, ok, col_j, row_j, dx, dy);
+            affine_bias_terms(p, c.terms, A_B0, pxi, ok, dt, col_j, row_j, dx, dy);
+            return ok;
+        };
+        uint32_t n_valid = 0;
+        float acc = 0.0f;
+        if (!staged) {
+            for (int base = 0; base < p.P; base += b.nt) {
+                const int pxi = base + b.tid;
+                const bool ok = pxi < p.P ? produce(pxi) : false;
+                n_valid += (uint32_t)__popcll(__ballot(ok));
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            publish_count(b, n_valid, c.wave_cnt, iter);
+            blk_sync(b);  // the terms (and the published counts) are visible
+            FTK_STAMP_END(b, 3);
+            if (b.wave == 0 && b.lane < A_COUNT) {
+                acc = chain_lane(c.terms + b.lane * p.Ppad, p.Ppad);
+            }
+        } else {
+            {
+                const bool ok = produce(b.tid);  // P > nt: every lane has a pixel
+                n_valid += (uint32_t)__popcll(__ballot(ok));
+            }
+            blk_sync(b);  // the products of pixels [0, nt) are visible
+            FTK_STAMP_END(b, 3);
+            if (b.wave == 0) {
+                if (b.lane < A_COUNT) {
+                    acc = chain_lane(c.terms + b.lane * p.Ppad, b.nt);
+                }
+            } else {
+                const int step = b.nt - kWave;
+                for (int base = b.nt; base < p.P; base += step) {
+                    const int pxi = base + (b.tid - kWave);
+                    const bool ok = pxi < p.P ? produce(pxi) : false;
+                    n_valid += (uint32_t)__popcll(__ballot(ok));
+                }
+            }
+            publish_count(b, n_valid, c.wave_cnt, iter);
+            blk_sync(b);  // the remaining products and every wave's count are visible
+            if (b.wave == 0 && b.lane < A_COUNT) {
+                acc = chain_lane(c.terms + b.lane * p.Ppad + b.nt, p.Ppad - b.nt, acc);
+            }
         }
-        publish_count(b, n_valid, c.wave_cnt, iter);
-        chain_then(b, c.terms, A_COUNT, p.Ppad, c.sums, true, [&]() {
+        if (b.wave == 0) {
+            if (b.lane < A_COUNT) {
+                c.sums[b.lane] = acc;
+            }
+            FTK_STAMP_END(b, 4);
             // H as a full 6x6 in LDS (sums[32..67]), then the lane-parallel LDLT (klt_common.h): rows on lanes 0..5
+            __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
             float m[6][6];
             affine_fill_matrix(c.sums, m);
             if (b.lane == 0) {
@@ -778,10 +827,13 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
+            __builtin_amdgcn_wave_barrier();
             const Ldlt6 fac = ldlt6_factor(c.sums + 32, b.lane);
             ldlt6_solve(fac, c.sums + A_B0, c.sums + A_COUNT, b.lane);
-        });
+            FTK_STAMP_END(b, 5);
+        }
+        blk_sync(b);  // the solution is visible
+        FTK_STAMP_END(b, 6);
         n_valid = collect_count(b, c.wave_cnt, iter);
         if (n_valid == 0) {
             break;
@@ -1506,6 +1558,11 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
             }
         }
 
+#ifdef FTK_STAMPS
+        for (int k = 0; k < 8; ++k) {
+            b0.stamp_acc[k] = b.stamp_acc[k];  // `b` is this level's copy (opaque_blk): carry its totals over
+        }
+#endif
         if (level == 0) {
             if (MODEL == FTK_MODEL_BASIC) {
                 out_u = bs.cur_u;
