@@ -538,13 +538,31 @@ struct Ldlt6 {
 
 __device__ __forceinline__ float bcast_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
-__device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) {
+// Element (i, j) of the symmetric matrix, wherever it lives: a row-major 6 x 6 in LDS, or a set of sums addressed through a
+// 36-byte index map (the affine trackers keep their 18 distinct Hessian sums and never materialise the matrix).
+struct Ldlt6Dense {
+    const float *a;
+    __device__ __forceinline__ float operator()(int i, int j) const { return a[i * 6 + j]; }
+};
+struct Ldlt6Mapped {
+    const float *values;
+    const uint8_t *map;  // 36 entries, row-major: index into `values`
+    __device__ __forceinline__ float operator()(int i, int j) const { return values[map[i * 6 + j]]; }
+};
+
+template <typename Elem>
+__device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane);
+
+__device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) { return ldlt6_factor_of(Ldlt6Dense{a_lds}, lane); }
+
+template <typename Elem>
+__device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane) {
     // ---- pivot order, replayed on the diagonal ----
     // Distinct, non-NaN magnitudes (the normal case): selection with swaps is then simply the descending order,
     // and lane i finds its own position as the number of larger magnitudes — six broadcasts instead of a serial
     // selection sort.  Ties, NaN or an all-zero diagonal take the literal replay (first maximum, position swaps).
     const int me0 = lane < 6 ? lane : 5;
-    const float my_ad = fabsf(a_lds[me0 * 7]);
+    const float my_ad = fabsf(elem(me0, me0));
     int rank = 0, equal = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -565,7 +583,7 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) {
         float ad[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            ad[i] = fabsf(a_lds[i * 7]);
+            ad[i] = fabsf(elem(i, i));
             pos[i] = i;
         }
 #pragma unroll
@@ -603,7 +621,7 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) {
     float bmat[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        bmat[j] = a_lds[pi * 6 + pos[j]];
+        bmat[j] = elem(pi, pos[j]);
     }
     Ldlt6 f;
     f.perm = pi;

@@ -704,6 +704,58 @@ __device__ __forceinline__ void affine_bias_terms(const KltParams &p, float *ter
     terms[(first_bias_chain + 5) * p.Ppad + pxi] = ok ? -(dt * dy) : 0.0f;
 }
 
+// Chain index of H(i, j), row-major (H(1,2) = H(0,3), H(1,4) = H(0,5), H(3,4) = H(2,3): the aliases of affine_klt.cpp:264-270 and
+// the (sic) of :245): what Ldlt6Mapped reads the 18 sums through.  Five bits per entry, twelve entries per 64-bit word.
+__device__ __forceinline__ uint8_t affine_h_index(int e) {
+    // row 0: 0 1 2 3 4 5 | row 1: 1 6 3 7 5 8 | row 2: 2 3 9 10 11 12 | row 3: 3 7 10 13 10 14 | row 4: 4 5 11 10 15 16 | row 5: 5 8 12 14 16 17
+    constexpr unsigned long long w0 = 0ull | (1ull << 5) | (2ull << 10) | (3ull << 15) | (4ull << 20) | (5ull << 25) | (1ull << 30) | (6ull << 35) | (3ull << 40) |
+                                      (7ull << 45) | (5ull << 50) | (8ull << 55);
+    constexpr unsigned long long w1 = 2ull | (3ull << 5) | (9ull << 10) | (10ull << 15) | (11ull << 20) | (12ull << 25) | (3ull << 30) | (7ull << 35) | (10ull << 40) |
+                                      (13ull << 45) | (10ull << 50) | (14ull << 55);
+    constexpr unsigned long long w2 = 4ull | (5ull << 5) | (11ull << 10) | (10ull << 15) | (15ull << 20) | (16ull << 25) | (5ull << 30) | (8ull << 35) | (12ull << 40) |
+                                      (14ull << 45) | (16ull << 50) | (17ull << 55);
+    const int word = e >= 24 ? 2 : (e >= 12 ? 1 : 0);
+    const unsigned long long w = word == 2 ? w2 : (word == 1 ? w1 : w0);
+    return (uint8_t)((w >> (5 * (e - 12 * word))) & 31ull);
+}
+
+// The 24 products of one pixel of the non-fast affine variants (affine_klt.cpp:229-256).  An unused pixel contributes exact zeros
+// to every sum: zeroing the five factors does that with five selects instead of one per product — every product is then +0 or
+// -0, and x + (+-0) == x for every value a sum can hold (the sums start at +0, and +0 + (-0) == +0).
+__device__ __forceinline__ void affine_all_terms(const KltParams &p, float *terms, int pxi, bool ok, float dt, float x, float y, float dx, float dy) {
+    x = ok ? x : 0.0f;
+    y = ok ? y : 0.0f;
+    dx = ok ? dx : 0.0f;
+    dy = ok ? dy : 0.0f;
+    dt = ok ? dt : 0.0f;
+    const float xx = x * x, yy = y * y, xy = x * y;
+    const float dxdx = dx * dx, dydy = dy * dy, dxdy = dx * dy;
+    terms[A_XX_DXDX * p.Ppad + pxi] = xx * dxdx;
+    terms[A_XX_DXDY * p.Ppad + pxi] = xx * dxdy;
+    terms[A_XY_DXDX * p.Ppad + pxi] = xy * dxdx;
+    terms[A_XY_DXDY * p.Ppad + pxi] = xy * dxdy;
+    terms[A_X_DXDX * p.Ppad + pxi] = x * dxdx;
+    terms[A_X_DXDY * p.Ppad + pxi] = x * dxdy;
+    terms[A_XX_DYDY * p.Ppad + pxi] = xx * dydy;
+    terms[A_XY_DYDY * p.Ppad + pxi] = xy * dydy;
+    terms[A_X_DYDY * p.Ppad + pxi] = x * dydy;
+    terms[A_YY_DXDX * p.Ppad + pxi] = yy * dxdx;
+    terms[A_YY_DXDY * p.Ppad + pxi] = yy * dxdy;
+    terms[A_Y_DXDX * p.Ppad + pxi] = y * dxdx;
+    terms[A_Y_DXDY * p.Ppad + pxi] = y * dxdy;
+    terms[A_YY_DYDY * p.Ppad + pxi] = yy * dydy;
+    terms[A_Y_DYDY * p.Ppad + pxi] = y * dydy;
+    terms[A_DXDX * p.Ppad + pxi] = dxdx;
+    terms[A_DXDY * p.Ppad + pxi] = dxdy;
+    terms[A_DYDY * p.Ppad + pxi] = dydy;
+    terms[(A_B0 + 0) * p.Ppad + pxi] = -(dt * x * dx);
+    terms[(A_B0 + 1) * p.Ppad + pxi] = -(dt * x * dy);
+    terms[(A_B0 + 2) * p.Ppad + pxi] = -(dt * y * dx);
+    terms[(A_B0 + 3) * p.Ppad + pxi] = -(dt * y * dy);
+    terms[(A_B0 + 4) * p.Ppad + pxi] = -(dt * dx);
+    terms[(A_B0 + 5) * p.Ppad + pxi] = -(dt * dy);
+}
+
 __device__ __forceinline__ void affine_fill_matrix(const float *sums, float (&m)[6][6]) {
     const float h00 = sums[A_XX_DXDX], h01 = sums[A_XX_DXDY], h02 = sums[A_XY_DXDX], h03 = sums[A_XY_DXDY];
     const float h04 = sums[A_X_DXDX], h05 = sums[A_X_DXDY], h11 = sums[A_XX_DYDY], h13 = sums[A_XY_DYDY];
@@ -748,6 +800,9 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
     nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
     FTK_STAMP_END(b, 1);
     const bool staged = !b.solo && b.nwaves > 1 && p.P > b.nt;
+    if (b.tid < 36) {
+        reinterpret_cast<uint8_t *>(c.sums + 32)[b.tid] = affine_h_index(b.tid);  // visible to wave 0 after the first barrier below
+    }
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
         FTK_STAMP_BEGIN(b);
@@ -766,8 +821,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             float dx, dy, i_ref, i_cur;
             const bool ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
             const float dt = i_cur - i_ref;
-            affine_hessian_terms(p, c.terms, pxi, ok, col_j, row_j, dx, dy);
-            affine_bias_terms(p, c.terms, A_B0, pxi, ok, dt, col_j, row_j, dx, dy);
+            affine_all_terms(p, c.terms, pxi, ok, dt, col_j, row_j, dx, dy);
             return ok;
         };
         uint32_t n_valid = 0;
@@ -814,21 +868,10 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
                 c.sums[b.lane] = acc;
             }
             FTK_STAMP_END(b, 4);
-            // H as a full 6x6 in LDS (sums[32..67]), then the lane-parallel LDLT (klt_common.h): rows on lanes 0..5
+            // the lane-parallel LDLT (klt_common.h: rows on lanes 0..5) reads H(i, j) straight from the 18 sums through the index
+            // map in sums[32..] (written once per level below): no 6 x 6 copy is made
             __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
-            float m[6][6];
-            affine_fill_matrix(c.sums, m);
-            if (b.lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        c.sums[32 + i * 6 + j] = m[i][j];
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const Ldlt6 fac = ldlt6_factor(c.sums + 32, b.lane);
+            const Ldlt6 fac = ldlt6_factor_of(Ldlt6Mapped{c.sums, reinterpret_cast<const uint8_t *>(c.sums + 32)}, b.lane);
             ldlt6_solve(fac, c.sums + A_B0, c.sums + A_COUNT, b.lane);
             FTK_STAMP_END(b, 5);
         }
