@@ -450,6 +450,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (next_async) {
             issue_quads(qn, b, p.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
         }
+#ifdef FTK_STAMPS_FINE
+        FTK_STAMP_END(b, 0);  // fine: footprints + issuing the window loads
+#endif
         if (b.wave == 0) {
             // both axes' node tables in one pass of wave 0 (two passes when the patch has more than 64 rows + columns)
             AxisSpec ar = {p.patch_rows, p.half_rows, ref.rows - 1, rw.r_lo, rw.rows - 1, rw.cols, p.pb_cap_r, ref_v, c.rnodes, c.ridx, &c.slots[0]};
@@ -464,8 +467,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 build_nodes_pass(lane, ac, none);
             }
         }
+#ifdef FTK_STAMPS_FINE
+        FTK_STAMP_END(b, 1);  // fine: node tables (wave 0)
+        pb_sync(solo);
+        FTK_STAMP_END(b, 2);  // fine: wait at B1
+#else
         pb_sync(solo);  // B1: node tables (and this level's reference window) visible
         FTK_STAMP_END(b, 0);
+#endif
         // ---- lattice: one bilinear per node pair ----
         const int n_r = (int)c.slots[0], n_c = (int)c.slots[1];
         {
@@ -477,6 +486,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 c.lattice[idx] = node_tap(rw.data, rw.cols, c.rnodes[r], c.cnodes[cc]);
             }
         }
+#ifdef FTK_STAMPS_FINE
+        FTK_STAMP_END(b, 3);  // fine: lattice
+#endif
         // ---- consume the prefetched loads ----
         if (cur_async) {
             store_quads(qc, b, c.cur_win, cw.rows, cw.cols, p.magic_cwq);
@@ -490,8 +502,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 stage_any(opaque_blk(b), p.ref[level - 1], c.ref_win + (buf ^ 1) * c.ref_win_stride, nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
             }
         }
+#ifdef FTK_STAMPS_FINE
+        FTK_STAMP_END(b, 5);  // fine: window stores (waits for the global loads)
+        pb_sync(solo);
+        b.stamp_t0 = __builtin_amdgcn_s_memtime();
+#else
         pb_sync(solo);  // B2: lattice and windows visible
         FTK_STAMP_END(b, 1);
+#endif
 
         // ---- Gauss-Newton iterations (TrackOneFeature, basic_klt.cpp:88-116) ----
         for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
@@ -510,7 +528,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     pb_sync(solo);
                 }
             }
+#ifndef FTK_STAMPS_FINE
             FTK_STAMP_END(b, 2);
+#endif
             uint32_t wave_valid = 0;
             float acc = 0.0f;
             if (producer) {
@@ -537,7 +557,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     }
                 }
             }
+#ifndef FTK_STAMPS_FINE
             FTK_STAMP_END(b, 3);
+#endif
             if (consumer) {
                 float m[2][2], bb[2], sol[2];
                 const int acc_bits = __float_as_int(acc);
@@ -553,7 +575,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 }
             }
             pb_sync(solo);  // B3: solution and valid counts visible
+#ifndef FTK_STAMPS_FINE
             FTK_STAMP_END(b, 5);
+#endif
             uint32_t n_valid = 0;
             for (int w = (b.nwaves == 1 ? 0 : 1); w < b.nwaves; ++w) {
                 n_valid += c.slots[4 + 4 * (iter & 1u) + w];
@@ -606,9 +630,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     if (b.tid == 0 && p.stamps) {
         b.stamp_acc[7] = __builtin_amdgcn_s_memtime() - stamp_kernel_t0;
         b.stamp_acc[6] = stamp_real_t0;
+#ifdef FTK_STAMPS_FINE
+        b.stamp_acc[4] = b.stamp_acc[2];  // fine: the B1 wait is reported in the "count" column
+#endif
         b.stamp_acc[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 11) | 20) << 32) |  // XCC_ID (hwreg 20), all bits
                          (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID (hwreg 4): wave, simd, cu, sh, se
+#ifndef FTK_STAMPS_FINE
         b.stamp_acc[4] = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int k = 0; k < 8; ++k) {
             p.stamps[(size_t)id * 8 + k] = b.stamp_acc[k];
         }

@@ -328,3 +328,39 @@ def test_sharded_tracker_on_device_world_size_1(ftk, oracle):
         stream.synchronize()
     ok, c, s, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, method="inverse", half=5, max_points=333)
     assert np.array_equal(guv.cpu().numpy().view(np.uint32), c.view(np.uint32)) and np.array_equal(gst.cpu().numpy(), s)
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 4])
+def test_one_wave_features_packed_into_workgroups(ftk, oracle, monkeypatch, group):
+    """One wave per feature (what large batches use) with 1..4 features per workgroup — the compile-time SOLO instantiations of
+    both kernels, incl. the chunked LSSD-fast level: no barrier, own LDS carve per wave, ragged last group.  Every variant must
+    still equal the oracle bit for bit."""
+    monkeypatch.setenv("FTK_KLT_WAVES", "1")
+    monkeypatch.setenv("FTK_KLT_GROUP", str(group))
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    uv = scenes.features(301, 320, 240, half=6)  # not a multiple of any group size
+    for model in MODELS:
+        for method in METHODS:
+            gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=6)
+            assert_parity(gpu, cpu, f"group={group} {model}/{method}")
+    gpu, cpu = run_pyramid(ftk, oracle, "lssd", "fast", ref_levels, cur_levels, uv, half=6, luminance=True)
+    assert_parity(gpu, cpu, f"group={group} lssd/fast luminance")
+
+
+def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
+    """The chunked one-wave LSSD-fast level (64-pixel ring, sums in registers) against the oracle on border / hard-motion /
+    rectangular-patch inputs, and against the plain level (FTK_LSSD_CHUNKED=0)."""
+    monkeypatch.setenv("FTK_KLT_WAVES", "1")
+    ref_levels, cur_levels = scenes.scene(320, 240, 4, "hard", "similarity")
+    rs = np.random.RandomState(8)
+    uv = np.stack([rs.uniform(-10, 330, 500), rs.uniform(-10, 250, 500)], axis=1).astype(np.float32)
+    th = np.deg2rad(2.0)
+    prior = np.float32([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]) * np.float32(1.3)  # columns longer than 1: samples leave the conservative window
+    for half, half_cols in ((6, None), (3, 9), (10, None), (1, 1)):
+        results = []
+        for chunked in ("1", "0"):
+            monkeypatch.setenv("FTK_LSSD_CHUNKED", chunked)
+            gpu, cpu = run_pyramid(ftk, oracle, "lssd", "fast", ref_levels, cur_levels, uv, half=half, half_cols=half_cols, prior=prior)
+            assert_parity(gpu, cpu, f"chunked={chunked} half={half}x{half_cols}")
+            results.append(gpu)
+        assert np.array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
