@@ -287,10 +287,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         };
         p.pb_cap_r = p.patch_rows + 2 + extras(p.patch_rows);
         p.pb_cap_c = p.patch_cols + 2 + extras(p.patch_cols);
-        if (const char *env = getenv("FTK_PB_EXTRAS_TIMING_ONLY")) {  // TIMING experiment: a capacity below the provable maximum gives wrong results
-            p.pb_cap_r = p.patch_rows + 2 + atoi(env);
-            p.pb_cap_c = p.patch_cols + 2 + atoi(env);
-        }
+#ifdef FTK_PB_EXTRAS_TIMING_ONLY  // diagnostic builds only (scripts/build_variant.sh): a capacity below the provable maximum gives wrong results
+        p.pb_cap_r = p.patch_rows + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
+        p.pb_cap_c = p.patch_cols + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
+#endif
     }
     const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
     if (lds == 0 || lds > 160 * 1024) {

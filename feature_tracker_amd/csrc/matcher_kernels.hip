@@ -190,8 +190,23 @@ __global__ void __launch_bounds__(kBlock) hamming_box_kernel(const MatchParams p
 // integer key (distance << 16 | position in the tile) maintained with one v_lshl_or + one v_min_u32
 // per pair — the minimum of that key is the smallest distance and, among equals, the lowest j, which
 // is what the reference's strict '<' scan returns.  Tiles are visited in ascending j and a later tile
-// replaces the best only with a strictly smaller distance.  18 VALU per pair (8 xor, 8 bcnt, 2 key).
+// replaces the best only with a strictly smaller distance.  18 VALU per pair (8 xor, 8 bcnt, 2 key) on the full path,
+// 13 (6 xor, 6 bcnt, 1 compare) on the early-exit path described in the kernel.
 constexpr int kRefs = kMatchRefs;
+
+// popcount(x) + acc in ONE instruction (v_bcnt_u32_b32 adds its second operand).  Written out because the compiler, left to
+// itself, re-associates the eight counts of a distance into bcnt(x, 0) pairs joined by v_add3_u32 — two more VALU
+// instructions per distance in a loop that is bound by exactly that.
+static __device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+static __device__ __forceinline__ uint32_t popc_first(uint32_t x) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
 
 template <int NW, bool kNearby>
 __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const MatchParams p) {
@@ -271,10 +286,22 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
     __builtin_amdgcn_s_setprio(0);
     uint32_t best_d[kRefs];
     int best_j[kRefs];
+    // A pair matters only when its distance is below BOTH the row's running minimum (strict '<': ties keep the earlier j)
+    // and the threshold (descriptor_matcher.h:68-71, :106-114: min_distance starts AT kMaxValidDescriptorDistance), and a
+    // Hamming distance only grows word by word.  So after kEarly of the NW words, a candidate whose partial count has
+    // already reached the row's limit is dead for that row; when that holds for every row of the wave — the normal case
+    // once each row has met its true match, and from the first candidate on under a threshold well below the ~NW * 16 bits
+    // of unrelated descriptors — the remaining words, the key and the minimum are skipped by one wave-uniform branch.
+    // Exact for any input (the branch only skips work that cannot change the result); `limit` is kept conservative
+    // (>= the true bound), the final comparison against max_distance below is the authoritative one.
+    constexpr int kEarly = NW >= 8 ? (NW * 3) / 4 : NW;
+    uint32_t limit[kRefs];
+    const uint32_t limit0 = (p.max_distance >= 0.0f && p.max_distance < 65000.0f) ? (uint32_t)p.max_distance + 1u : (p.max_distance < 0.0f ? 0u : 0xFFFFu);
 #pragma unroll
     for (int r = 0; r < kRefs; ++r) {
         best_d[r] = 0xFFFFu;  // above any real distance (<= 512)
         best_j[r] = -1;
+        limit[r] = limit0;
     }
     for (int tile_begin = j_begin; tile_begin < j_end; tile_begin += kTile) {
         const int tile_n = min(kTile, j_end - tile_begin);
@@ -291,38 +318,77 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
         for (int r = 0; r < kRefs; ++r) {
             key[r] = 0xFFFFFFFFu;
         }
-#pragma unroll 2
-        for (int t = 0; t < tile_n; ++t) {
-            uint32_t cw[NW];
+        // two candidates per step (indices clamped to the tile's last: seeing a candidate twice changes nothing), their first
+        // kEarly words fetched one step ahead into the other register set so that the LDS latency sits under the previous
+        // pair's popcounts; two steps per trip so that the two sets swap roles without register moves
+        uint32_t cw[2][2][NW];
+        auto fetch = [&](int set, int t) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                cw[w] = tile_words[t * NW + w];
-            }
-            float2 c = make_float2(0.0f, 0.0f);
-            if (kNearby) {
-                c = tile_uv[t];
-            }
+            for (int c = 0; c < 2; ++c) {
+                const int tc = min(t + c, tile_n - 1);
 #pragma unroll
-            for (int r = 0; r < kRefs; ++r) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    d += __popc(ref[r][w] ^ cw[w]);
+                for (int w = 0; w < kEarly; ++w) {
+                    cw[set][c][w] = tile_words[tc * NW + w];
                 }
-                uint32_t k = (d << 16) | (uint32_t)t;
-                if (kNearby) {
-                    // descriptor_matcher.h:108-111: outside the window -> not a candidate
-                    const bool out = (int)(fabsf(pred_u[r] - c.x) > p.max_col) | (int)(fabsf(pred_v[r] - c.y) > p.max_row);
-                    k = out ? 0xFFFFFFFFu : k;
-                }
-                key[r] = min(key[r], k);
             }
+        };
+        auto step = [&](int set, int t) {
+            uint32_t d[2][kRefs];
+            bool alive = false;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int r = 0; r < kRefs; ++r) {
+                    d[c][r] = popc_first(ref[r][0] ^ cw[set][c][0]);
+#pragma unroll
+                    for (int w = 1; w < kEarly; ++w) {
+                        d[c][r] = popc_add(ref[r][w] ^ cw[set][c][w], d[c][r]);
+                    }
+                    alive = alive | (d[c][r] < limit[r]);
+                }
+            }
+            if (kEarly == NW || __builtin_expect(__ballot(alive) != 0ull, 0)) {  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int tc = min(t + c, tile_n - 1);
+#pragma unroll
+                    for (int w = kEarly; w < NW; ++w) {
+                        cw[set][c][w] = tile_words[tc * NW + w];
+                    }
+                    float2 cuv = make_float2(0.0f, 0.0f);
+                    if (kNearby) {
+                        cuv = tile_uv[tc];
+                    }
+#pragma unroll
+                    for (int r = 0; r < kRefs; ++r) {
+#pragma unroll
+                        for (int w = kEarly; w < NW; ++w) {
+                            d[c][r] = popc_add(ref[r][w] ^ cw[set][c][w], d[c][r]);
+                        }
+                        uint32_t k = (d[c][r] << 16) | (uint32_t)tc;
+                        if (kNearby) {
+                            // descriptor_matcher.h:108-111: outside the window -> not a candidate
+                            const bool out = (int)(fabsf(pred_u[r] - cuv.x) > p.max_col) | (int)(fabsf(pred_v[r] - cuv.y) > p.max_row);
+                            k = out ? 0xFFFFFFFFu : k;
+                        }
+                        key[r] = min(key[r], k);
+                        limit[r] = min(limit[r], key[r] >> 16);
+                    }
+                }
+            }
+        };
+        fetch(0, 0);
+        for (int t = 0; t < tile_n; t += 4) {
+            fetch(1, t + 2);
+            step(0, t);
+            fetch(0, t + 4);
+            step(1, t + 2);
         }
 #pragma unroll
         for (int r = 0; r < kRefs; ++r) {
-            const uint32_t d = key[r] >> 16;
-            if (d < best_d[r]) {  // strict: an earlier tile keeps ties
-                best_d[r] = d;
+            const uint32_t dist = key[r] >> 16;
+            if (dist < best_d[r]) {  // strict: an earlier tile keeps ties
+                best_d[r] = dist;
                 best_j[r] = tile_begin + (int)(key[r] & 0xFFFFu);
             }
         }
