@@ -85,6 +85,8 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     return FTK_OK;
 }
 
+constexpr long long kMfmaMinPairs = 1ll << 20;
+
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
     if (count <= ctx->match_boxes_count) {
         return FTK_OK;
@@ -1111,6 +1113,37 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     if (!(getenv("FTK_MATCH_ANY_PER") && atoi(getenv("FTK_MATCH_ANY_PER")) == 1)) {
         per = (per + 63) / 64 * 64;
     }
+    p.matrix_cores = 0;
+    {
+        // Which scan: 256- and 512-bit descriptors with enough pairs go to the matrix cores (matcher_kernels.hip,
+        // hamming_match_mfma_kernel); everything else to the popcount scan with the candidates on the scalar path.
+        // FTK_MATCH_KERNEL=mfma|scalar|lds forces one (experiment switch).
+        const char *env = getenv("FTK_MATCH_KERNEL");
+        p.lds_tiles = (env && !strcmp(env, "lds")) ? 1 : 0;
+        bool mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && (long long)n_ref * n_cur >= kMfmaMinPairs;
+        if (env) {
+            mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && !strcmp(env, "mfma");
+        }
+        if (mfma) {
+            p.matrix_cores = 1;
+            // A workgroup is four independent waves of 64 rows; each scans one split of the candidates in 32-candidate tiles.
+            // Two waves fit a SIMD (registers): one round of at most 512 workgroups, the splits whole tiles and as even as
+            // the tile count allows.
+            const int mfma_row_blocks = (n_ref + 255) / 256;
+            int target = 512;
+            if (const char *wgs = getenv("FTK_MATCH_WGS")) {
+                target = atoi(wgs);
+            }
+            int mfma_splits = target / mfma_row_blocks;
+            mfma_splits = mfma_splits < 1 ? 1 : mfma_splits;
+            const int n_tiles = (n_cur + 31) / 32;
+            int tiles_per_split = (n_tiles + mfma_splits - 1) / mfma_splits;
+            if (tiles_per_split > 1024) {
+                tiles_per_split = 1024;  // the position field of the running keys
+            }
+            per = tiles_per_split * 32;
+        }
+    }
     p.cur_per_block = per;
     // NearbyMatch from a few thousand candidates on: bounding boxes for the early exit of workgroups whose candidates
     // cannot reach any window of their rows (matcher_kernels.hip)
@@ -1128,7 +1161,8 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     {
         // diagnostic build: per-workgroup {start, loaded, end} (s_memrealtime, 100 MHz) + HW_ID, dumped to $FTK_MATCH_STAMPS_DUMP
         const int n_splits = (n_cur + per - 1) / per;
-        const size_t n_wg = (size_t)row_blocks * n_splits;
+        // (the matrix-core scan has 256-row workgroups and writes 8 words per workgroup: twice the rows, twice the words)
+        const size_t n_wg = p.matrix_cores ? (size_t)((n_ref + 255) / 256) * n_splits * 2 : (size_t)row_blocks * n_splits;
         unsigned long long *d_st = nullptr;
         FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_st), sizeof(unsigned long long) * 4 * n_wg));
         FTK_HIP(ctx, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 4 * n_wg, ctx->stream));

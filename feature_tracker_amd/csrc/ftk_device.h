@@ -91,6 +91,8 @@ struct MatchParams {
     int32_t cur_per_block;  // candidates scanned by one workgroup
     int32_t keys_clean;     // keys already hold "no match" (context-owned workspace: the epilogue leaves it that way)
     unsigned long long *stamps;  // diagnostic build (-DFTK_MATCH_STAMPS) only: {start, end} s_memrealtime + HW_ID per workgroup; else null
+    int32_t matrix_cores;   // 1: the scan on the matrix cores (hamming_match_mfma_kernel; n_words 8 / 16)
+    int32_t lds_tiles;      // experiment (FTK_MATCH_KERNEL=lds): candidates staged through LDS tiles instead of the scalar path
     float4 *boxes;          // NearbyMatch, optional: ceil(n_ref / 512) prediction boxes, then one candidate box per split
                             // ({u min, u max, v min, v max}; hamming_box_kernel fills them, the scan leaves early on them)
 };

@@ -415,6 +415,419 @@ __global__ void __launch_bounds__(kBlock) hamming_match_tiled_kernel(const Match
     }
 }
 
+// The same scan with the candidates on the SCALAR path: every lane of a wave compares its own reference rows with the same
+// candidate, so the candidate's words are wave-uniform — they are fetched with s_load_dwordx8 through the scalar cache
+// into SGPRs (constant address space) and feed v_xor_b32 as its scalar operand.  No LDS tile, no staging pass, no barrier,
+// no LDS address arithmetic on the VALU: what is left per pair is 6 xor + 6 bcnt + 1 compare on the early-exit path.
+// The waves of a workgroup never synchronise; a candidate pair's 64 bytes are requested one step ahead of their use.
+typedef const __attribute__((address_space(4))) uint32_t *scalar_words;
+typedef const __attribute__((address_space(4))) float *scalar_floats;
+constexpr int kChunk = 32768;  // candidates per packed-key epoch (position in 16 bits)
+
+template <int NW, bool kNearby>
+__global__ void __launch_bounds__(kBlock) hamming_match_scalar_kernel(const MatchParams p) {
+    __builtin_amdgcn_s_setprio(3);  // see hamming_match_tiled_kernel: get the descriptor loads out at once
+    const int i_base = blockIdx.x * kBlock * kRefs + threadIdx.x;
+    const int j_begin = blockIdx.y * p.cur_per_block;
+    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+    if (kNearby && p.boxes != nullptr) {
+        const float4 pb = p.boxes[blockIdx.x], cb = p.boxes[gridDim.x + blockIdx.y];
+        const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
+        if (cb.x - pb.y > reach_u || pb.x - cb.y > reach_u || cb.z - pb.w > reach_v || pb.z - cb.w > reach_v) {
+            return;  // block-uniform (hamming_match_tiled_kernel explains the box test)
+        }
+    }
+    uint32_t ref[kRefs][NW];
+    float pred_u[kRefs], pred_v[kRefs];
+#pragma unroll
+    for (int r = 0; r < kRefs; ++r) {
+        const int i = i_base + r * kBlock;
+        const bool active = i < p.n_ref;
+        const uint32_t *row = p.ref_words + (long long)(active ? i : p.n_ref - 1) * NW;
+        if (NW % 4 == 0) {
+#pragma unroll
+            for (int w = 0; w < NW; w += 4) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(row + w);
+                ref[r][w] = q.x;
+                ref[r][w + 1] = q.y;
+                ref[r][w + 2] = q.z;
+                ref[r][w + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                ref[r][w] = row[w];
+            }
+        }
+        if (!active) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                ref[r][w] = 0u;
+            }
+        }
+        pred_u[r] = (kNearby && active) ? p.pred_uv[2 * i] : 0.0f;
+        pred_v[r] = (kNearby && active) ? p.pred_uv[2 * i + 1] : 0.0f;
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    constexpr int kEarly = NW >= 8 ? (NW * 3) / 4 : NW;  // see hamming_match_tiled_kernel
+    uint32_t best_d[kRefs], limit[kRefs];
+    int best_j[kRefs];
+    const uint32_t limit0 = (p.max_distance >= 0.0f && p.max_distance < 65000.0f) ? (uint32_t)p.max_distance + 1u : (p.max_distance < 0.0f ? 0u : 0xFFFFu);
+#pragma unroll
+    for (int r = 0; r < kRefs; ++r) {
+        best_d[r] = 0xFFFFu;
+        best_j[r] = -1;
+        limit[r] = limit0;
+    }
+    const scalar_words cur = (scalar_words)p.cur_words;
+    const scalar_floats cur_uv = (scalar_floats)p.cur_uv;
+    for (int chunk_begin = j_begin; chunk_begin < j_end; chunk_begin += kChunk) {
+        const int chunk_end = min(chunk_begin + kChunk, j_end);
+        const int last = chunk_end - 1;
+        uint32_t key[kRefs];
+#pragma unroll
+        for (int r = 0; r < kRefs; ++r) {
+            key[r] = 0xFFFFFFFFu;
+        }
+        // two candidates per step (indices clamped to the chunk's last: seeing a candidate twice changes nothing); two steps per
+        // trip so that the two SGPR sets swap roles without moves
+        uint32_t cw[2][2][NW];
+        auto fetch = [&](int set, int j) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const scalar_words q = cur + (long long)min(j + c, last) * NW;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    cw[set][c][w] = q[w];
+                }
+            }
+        };
+        auto step = [&](int set, int j) {
+            uint32_t d[2][kRefs];
+            bool alive = false;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int r = 0; r < kRefs; ++r) {
+                    d[c][r] = popc_first(ref[r][0] ^ cw[set][c][0]);
+#pragma unroll
+                    for (int w = 1; w < kEarly; ++w) {
+                        d[c][r] = popc_add(ref[r][w] ^ cw[set][c][w], d[c][r]);
+                    }
+                    alive = alive | (d[c][r] < limit[r]);
+                }
+            }
+            if (kEarly == NW || __builtin_expect(__ballot(alive) != 0ull, 0)) {  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int jc = min(j + c, last);
+                    float cu = 0.0f, cv = 0.0f;
+                    if (kNearby) {
+                        cu = cur_uv[2 * (long long)jc];
+                        cv = cur_uv[2 * (long long)jc + 1];
+                    }
+#pragma unroll
+                    for (int r = 0; r < kRefs; ++r) {
+#pragma unroll
+                        for (int w = kEarly; w < NW; ++w) {
+                            d[c][r] = popc_add(ref[r][w] ^ cw[set][c][w], d[c][r]);
+                        }
+                        uint32_t k = (d[c][r] << 16) | (uint32_t)(jc - chunk_begin);
+                        if (kNearby) {
+                            // descriptor_matcher.h:108-111: outside the window -> not a candidate
+                            const bool out = (int)(fabsf(pred_u[r] - cu) > p.max_col) | (int)(fabsf(pred_v[r] - cv) > p.max_row);
+                            k = out ? 0xFFFFFFFFu : k;
+                        }
+                        key[r] = min(key[r], k);
+                        limit[r] = min(limit[r], key[r] >> 16);
+                    }
+                }
+            }
+        };
+        fetch(0, chunk_begin);
+        for (int j = chunk_begin; j < chunk_end; j += 4) {
+            fetch(1, j + 2);
+            step(0, j);
+            fetch(0, j + 4);
+            step(1, j + 2);
+        }
+#pragma unroll
+        for (int r = 0; r < kRefs; ++r) {
+            const uint32_t dist = key[r] >> 16;
+            if (dist < best_d[r]) {  // strict: an earlier chunk keeps ties
+                best_d[r] = dist;
+                best_j[r] = chunk_begin + (int)(key[r] & 0xFFFFu);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRefs; ++r) {
+        const int i = i_base + r * kBlock;
+        // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
+        if (i < p.n_ref && best_j[r] >= 0 && (float)best_d[r] < p.max_distance) {
+            const unsigned long long packed = ((unsigned long long)best_d[r] << 32) | (unsigned)best_j[r];
+            atomicMin(&p.keys[i], packed);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The all-pairs scan on the matrix cores.  Write a reference descriptor's bits as signed bytes a_k = +s_k (bit set) / -s_k (bit
+// clear) and a candidate's bits as bytes b_k = 8 / s_k (bit set) / 0, with s_k one of 8, 4, 2, 1: then
+//     sum_k a_k b_k = 8 (#(both set) - #(candidate set, reference clear)) = 8 (popcount(a) - hamming(a, b)),
+// and that sum for 32 reference rows x 32 candidates x 32 bits is ONE v_mfma_i32_32x32x32_i8.  Started from -8 popcount(a) (the
+// C operand of the first product) the accumulator IS -8 hamming: exact integer arithmetic, the same distances the popcount
+// kernels compute.  The power-of-two scales exist so that a candidate dword needs ONE instruction: (word >> 4 h) & (0x01010101
+// << v) puts bits 4 h + v + 8 j (j = 0..3) into its four bytes with value 2^v.  At 10 000 x 10 000 x 256 bits the popcount scan
+// needs 13 VALU instructions per 64 pairs and is bound by exactly that (44 us); here 64 pairs cost half an MFMA (16 of its 32
+// cycles) and ~2 VALU instructions, most of them issued in the shadow of the MFMAs.
+//
+//   * A wave owns 64 reference rows — two 32-row A tiles, expanded from the bits into registers once — and one split of the
+//     candidates.  Nothing is shared between waves: no LDS, no barrier.  Lane (c = l & 31, h = l >> 5) loads the words of
+//     candidate c of the current 32-candidate tile straight from global memory (one tile ahead of their use) and expands its
+//     half of word m — dwords v = 0..3: bits 4 h + v + 8 j — between the MFMAs that consume them.  MFMA m multiplies word m;
+//     lane (c, h) supplies the same 16 k-slots of row c (A) and candidate c (B), so whatever order the instruction gives its
+//     32 k-slots, A and B agree on it.
+//   * Result layout (C/D of every 32x32 MFMA): the lane is the candidate, the 16 registers are rows (i & 3) + 8 (i >> 2) + 4 h.
+//     Each (lane, register) keeps a running key (-8 distance << 16 | 0xFFFE - position): its signed maximum is the smallest
+//     distance and among equals the earliest candidate, the reference's strict '<'.  The keys start at the threshold
+//     (descriptor_matcher.h:68-71: min_distance starts AT kMaxValidDescriptorDistance) with 0xFFFF in the position field.
+//   * Per tile the 32 results of a lane are folded with v_max3_i32 and compared with the lane's lowest limit: only when some
+//     lane holds a result above it (a match candidate: once per row with a true match, rarely otherwise) does the wave take the
+//     path that compares per row, applies the NearbyMatch window and updates keys and limit.  Exact for any input.
+//   * At the end the keys are reduced over the 32 lanes of each half (the candidates) and merged across splits with the same
+//     64-bit atomicMin as the other scans; match_epilogue_kernel turns them into indices.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int kMfmaRows = 256;  // reference rows per workgroup (four independent waves)
+
+// The rare path of the matrix-core scan: some lane of the wave holds a result above its lowest limit.  The caller folded the 32
+// results into four group maxima (8 registers each); only groups, and in them only registers, in which SOME lane beats its key
+// are looked at (wave-uniform skips: a true match touches one register of one group).  A result that beats the row's key
+// replaces it if the candidate is inside the NearbyMatch window.  Returns the lane's new lowest limit.
+template <bool kNearby>
+static __device__ __forceinline__ int mfma_update_keys(const MatchParams &p, const v16i &acc0, const v16i &acc1, const int (&group_top)[4],
+                                                       int (&key)[32], int lowest, int row0, int h, int cand, int j_begin) {
+    const int inv_pos = 0xFFFE - (cand - j_begin);
+    float cu = 0.0f, cv = 0.0f;
+    if (kNearby) {
+        cu = p.cur_uv[2 * (long long)cand];
+        cv = p.cur_uv[2 * (long long)cand + 1];
+    }
+    bool changed = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (__ballot(group_top[g] > lowest) == 0ull) {
+            continue;  // wave-uniform
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int s = 8 * g + e;
+            const int neg_d8 = s < 16 ? acc0[s & 15] : acc1[s & 15];
+            const bool beats = neg_d8 > (key[s] >> 16);
+            if (__ballot(beats) == 0ull) {
+                continue;  // wave-uniform
+            }
+            if (beats) {
+                bool in_window = true;
+                if (kNearby) {
+                    // descriptor_matcher.h:108-111: outside the window -> not a candidate
+                    const int row = min(row0 + (s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h, p.n_ref - 1);
+                    const float pu = p.pred_uv[2 * (long long)row], pv = p.pred_uv[2 * (long long)row + 1];
+                    in_window = !((fabsf(pu - cu) > p.max_col) | (fabsf(pv - cv) > p.max_row));
+                }
+                if (in_window) {
+                    key[s] = (int)(((unsigned)neg_d8 << 16) | (unsigned)inv_pos);
+                    changed = true;
+                }
+            }
+        }
+    }
+    if (__ballot(changed) != 0ull) {  // keys only grow: the lowest limit moves only when a key did
+        int low = 0x7FFF;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            low = min(low, key[s] >> 16);
+        }
+        lowest = low;
+    }
+    return lowest;
+}
+
+template <int NW, bool kNearby>
+__global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchParams p) {
+    static_assert(NW % 4 == 0, "whole 16-byte loads of a candidate");
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * kMfmaRows + wave * 64;  // this wave's 64 rows
+    const int j_begin = (int)blockIdx.y * p.cur_per_block;
+    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+    const int last = j_end - 1;
+    if (row0 >= p.n_ref) {
+        return;  // wave-uniform; the waves never synchronise
+    }
+    if (kNearby && p.boxes != nullptr) {
+        // block-uniform early exit on the bounding boxes (hamming_match_tiled_kernel); row boxes cover 256 * kMatchRefs rows
+        const int n_row_boxes = (p.n_ref + kBlock * kMatchRefs - 1) / (kBlock * kMatchRefs);
+        const float4 pb = p.boxes[((int)blockIdx.x * kMfmaRows) / (kBlock * kMatchRefs)], cb = p.boxes[n_row_boxes + blockIdx.y];
+        const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
+        if (cb.x - pb.y > reach_u || pb.x - cb.y > reach_u || cb.z - pb.w > reach_v || pb.z - cb.w > reach_v) {
+            return;
+        }
+    }
+#ifdef FTK_MATCH_STAMPS
+    const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_slow = 0, st_slow_n = 0;
+#endif
+    // ---- candidate words: two register sets, the tile after the current one always in flight ----
+    v4i words[2][NW / 4];
+#define FTK_FETCH_WORDS(set_, tile_begin_)                                                                     \
+    {                                                                                                          \
+        const v4i *src_ = reinterpret_cast<const v4i *>(p.cur_words + (long long)min((tile_begin_) + c, last) * NW); \
+        _Pragma("unroll") for (int q_ = 0; q_ < NW / 4; ++q_) {                                                \
+            words[set_][q_] = src_[q_];                                                                        \
+        }                                                                                                      \
+    }
+    FTK_FETCH_WORDS(0, j_begin)
+
+    // ---- the A operand: 64 rows as +-8 / +-4 / +-2 / +-1 bytes, and -8 popcount(row) as the accumulators' start ----
+    v4i a[2][NW];
+    int pop[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = row0 + t * 32 + c;
+        const v4i *src = reinterpret_cast<const v4i *>(p.ref_words + (long long)min(row, p.n_ref - 1) * NW);
+        pop[t] = 0;
+#pragma unroll
+        for (int q = 0; q < NW / 4; ++q) {
+            const v4i four = src[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t w = (uint32_t)four[e];
+                pop[t] += __popc(w);
+                const uint32_t half = w >> (4 * h);
+                // dword v: bits 4 h + v + 8 j of the word -> byte j = +2^(3-v) (set) / -2^(3-v) (clear): v_perm_b32 picks byte 1 / byte 0
+                a[t][4 * q + e][0] = (int)__builtin_amdgcn_perm(0u, 0x000008F8u, half & 0x01010101u);
+                a[t][4 * q + e][1] = (int)__builtin_amdgcn_perm(0u, 0x000004FCu, (half >> 1) & 0x01010101u);
+                a[t][4 * q + e][2] = (int)__builtin_amdgcn_perm(0u, 0x000002FEu, (half >> 2) & 0x01010101u);
+                a[t][4 * q + e][3] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, (half >> 3) & 0x01010101u);
+            }
+        }
+    }
+    v16i start0, start1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * h;  // lane r (and r + 32) holds row r's popcount
+        start0[i] = -8 * __shfl(pop[0], r);
+        start1[i] = -8 * __shfl(pop[1], r);
+    }
+    // d < limit0 is the conservative integer form of `distance < kMaxValidDescriptorDistance`
+    const int limit0 = (p.max_distance >= 0.0f && p.max_distance < 4000.0f) ? (int)p.max_distance + 1 : (p.max_distance < 0.0f ? 0 : 4001);
+    int key[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        key[s] = (int)(((unsigned)(-8 * limit0) << 16) | 0xFFFFu);
+    }
+    int lowest = -8 * limit0;  // min over this lane's 32 rows of the -8 distance a candidate has to exceed
+    const int shift = 4 * h;
+
+#ifdef FTK_MATCH_STAMPS
+#define FTK_SLOW_BEGIN const unsigned long long slow0_ = __builtin_amdgcn_s_memtime();
+#define FTK_SLOW_END                                                \
+    asm volatile("" ::"v"(lowest));                                 \
+    st_slow += __builtin_amdgcn_s_memtime() - slow0_;               \
+    ++st_slow_n;
+#else
+#define FTK_SLOW_BEGIN
+#define FTK_SLOW_END
+#endif
+#define FTK_MFMA_TILE(set_, tile_begin_)                                                                                       \
+    {                                                                                                                          \
+        v16i acc0 = start0, acc1 = start1;                                                                                     \
+        _Pragma("unroll") for (int m_ = 0; m_ < NW; ++m_) {                                                                    \
+            const uint32_t half_ = (uint32_t)words[set_][m_ / 4][m_ % 4] >> shift;                                             \
+            v4i b_;                                                                                                            \
+            b_[0] = (int)(half_ & 0x01010101u);                                                                                \
+            b_[1] = (int)(half_ & 0x02020202u);                                                                                \
+            b_[2] = (int)(half_ & 0x04040404u);                                                                                \
+            b_[3] = (int)(half_ & 0x08080808u);                                                                                \
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][m_], b_, acc0, 0, 0, 0);                                          \
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][m_], b_, acc1, 0, 0, 0);                                          \
+        }                                                                                                                      \
+        int gtop_[4]; /* maxima of registers 0-7 / 8-15 of either accumulator */                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                                     \
+            const v16i &acc_ = g_ < 2 ? acc0 : acc1;                                                                           \
+            const int o_ = 8 * (g_ & 1);                                                                                       \
+            gtop_[g_] = max(max(max(max(acc_[o_], acc_[o_ + 1]), acc_[o_ + 2]), max(acc_[o_ + 3], acc_[o_ + 4])),              \
+                            max(max(acc_[o_ + 5], acc_[o_ + 6]), acc_[o_ + 7]));                                               \
+        }                                                                                                                      \
+        const int top_ = max(max(gtop_[0], gtop_[1]), max(gtop_[2], gtop_[3]));                                                \
+        if (__builtin_expect(__ballot(top_ > lowest) != 0ull, 0)) { /* wave-uniform */                                          \
+            FTK_SLOW_BEGIN                                                                                                     \
+            lowest = mfma_update_keys<kNearby>(p, acc0, acc1, gtop_, key, lowest, row0, h, min((tile_begin_) + c, last), j_begin); \
+            FTK_SLOW_END                                                                                                       \
+        }                                                                                                                      \
+    }
+#ifdef FTK_MATCH_STAMPS
+    const unsigned long long st_prologue = __builtin_amdgcn_s_memtime() - st_c0;
+#endif
+    for (int tile_begin = j_begin; tile_begin < j_end; tile_begin += 64) {
+        FTK_FETCH_WORDS(1, tile_begin + 32)
+        __builtin_amdgcn_sched_barrier(0);  // the loads go out BEFORE the products of the tile in hand (the scheduler sinks them otherwise)
+        FTK_MFMA_TILE(0, tile_begin)
+        if (tile_begin + 32 < j_end) {
+            FTK_FETCH_WORDS(0, tile_begin + 64)
+            __builtin_amdgcn_sched_barrier(0);
+            FTK_MFMA_TILE(1, tile_begin + 32)
+        }
+    }
+#ifdef FTK_MATCH_STAMPS
+    const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the best candidate of every row: maximum over the 32 lanes of the half, then one lane per row merges across splits ----
+    // (a register in which no lane of the wave found anything — nearly all of them under a real threshold — is skipped)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        int k = key[s];
+        if (__ballot((k & 0xFFFF) != 0xFFFF) == 0ull) {
+            continue;  // wave-uniform
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            k = max(k, __shfl_xor(k, off));
+        }
+        if (c == s) {
+            const int row = row0 + (s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
+            const int d = -(k >> 16) / 8;
+            // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
+            if (row < p.n_ref && (k & 0xFFFF) != 0xFFFF && (float)d < p.max_distance) {
+                const unsigned long long packed = ((unsigned long long)(unsigned)d << 32) | (unsigned)(j_begin + 0xFFFE - (k & 0xFFFF));
+                atomicMin(&p.keys[row], packed);
+            }
+        }
+    }
+#ifdef FTK_MATCH_STAMPS
+    if (threadIdx.x == 0 && p.stamps) {
+        unsigned long long *st = p.stamps + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        st[0] = st_rt0;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = st_prologue;
+        st[3] = st_loop_end - st_c0 - st_prologue;  // the tile loop
+        st[4] = st_slow;
+        st[5] = st_slow_n;
+        st[6] = __builtin_amdgcn_s_memtime() - st_loop_end;  // the final reduction
+        st[7] = __builtin_amdgcn_s_memtime() - st_c0;
+    }
+#endif
+}
+
+#undef FTK_FETCH_WORDS
+#undef FTK_MFMA_TILE
+#undef FTK_SLOW_BEGIN
+#undef FTK_SLOW_END
+
 __global__ void __launch_bounds__(kBlock) match_epilogue_kernel(unsigned long long *keys, int32_t *index_pairs, int n_ref) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n_ref) {
@@ -436,13 +849,33 @@ hipError_t launch_nw(const MatchParams &p, hipStream_t stream) {
         return hipGetLastError();
     }
     const int row_blocks = (p.n_ref + kBlock * kRefs - 1) / (kBlock * kRefs);
+    if (p.matrix_cores) {
+        if constexpr (NW >= 8) {
+            if (p.pred_uv && p.boxes) {
+                hipLaunchKernelGGL(hamming_box_kernel, dim3((unsigned)(row_blocks + splits)), dim3(kBlock), 0, stream, p, row_blocks);
+            }
+            const dim3 grid((unsigned)((p.n_ref + kMfmaRows - 1) / kMfmaRows), (unsigned)splits);
+            if (p.pred_uv) {
+                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, true>), grid, dim3(kBlock), 0, stream, p);
+            } else {
+                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, false>), grid, dim3(kBlock), 0, stream, p);
+            }
+            return hipGetLastError();
+        }
+    }
     if (p.pred_uv) {
         if (p.boxes) {
             hipLaunchKernelGGL(hamming_box_kernel, dim3((unsigned)(row_blocks + splits)), dim3(kBlock), 0, stream, p, row_blocks);
         }
-        hipLaunchKernelGGL((hamming_match_tiled_kernel<NW, true>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
-    } else {
+        if (p.lds_tiles) {
+            hipLaunchKernelGGL((hamming_match_tiled_kernel<NW, true>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((hamming_match_scalar_kernel<NW, true>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
+        }
+    } else if (p.lds_tiles) {
         hipLaunchKernelGGL((hamming_match_tiled_kernel<NW, false>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((hamming_match_scalar_kernel<NW, false>), dim3(row_blocks, splits), dim3(kBlock), 0, stream, p);
     }
     return hipGetLastError();
 }
