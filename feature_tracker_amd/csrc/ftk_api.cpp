@@ -85,8 +85,6 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     return FTK_OK;
 }
 
-constexpr long long kMfmaMinPairs = 1ll << 20;
-
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
     if (count <= ctx->match_boxes_count) {
         return FTK_OK;
@@ -1115,22 +1113,22 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     }
     p.matrix_cores = 0;
     {
-        // Which scan: 256- and 512-bit descriptors with enough pairs go to the matrix cores (matcher_kernels.hip,
-        // hamming_match_mfma_kernel); everything else to the popcount scan with the candidates on the scalar path.
-        // FTK_MATCH_KERNEL=mfma|scalar|lds forces one (experiment switch).
+        // Which scan: 256- and 512-bit descriptors go to the matrix cores (matcher_kernels.hip, hamming_match_mfma_kernel:
+        // faster at every size measured, 300 x 300 to 10 000 x 10 000, scripts/match_shapes.py); other widths to the popcount
+        // scan with the candidates on the scalar path.  FTK_MATCH_KERNEL=mfma|scalar|lds forces one (experiment switch).
         const char *env = getenv("FTK_MATCH_KERNEL");
         p.lds_tiles = (env && !strcmp(env, "lds")) ? 1 : 0;
-        bool mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && (long long)n_ref * n_cur >= kMfmaMinPairs;
+        // (the matrix-core scan addresses the candidates with 32-bit byte offsets)
+        bool mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && (long long)n_cur * n_words * 4 < (1ll << 31);
         if (env) {
-            mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && !strcmp(env, "mfma");
+            mfma = mfma && !strcmp(env, "mfma");
         }
         if (mfma) {
             p.matrix_cores = 1;
-            // A workgroup is four independent waves of 64 rows; each scans one split of the candidates in 32-candidate tiles.
-            // Two waves fit a SIMD (registers): one round of at most 512 workgroups, the splits whole tiles and as even as
-            // the tile count allows.
-            const int mfma_row_blocks = (n_ref + 255) / 256;
-            int target = 512;
+            // One wave per workgroup: 64 rows and one split of the candidates, in 32-candidate tiles.  Two waves fit a SIMD
+            // (registers): one round of at most 2048 waves, the splits whole tiles and as even as the tile count allows.
+            const int mfma_row_blocks = (n_ref + 63) / 64;
+            int target = 2048;
             if (const char *wgs = getenv("FTK_MATCH_WGS")) {
                 target = atoi(wgs);
             }
@@ -1161,8 +1159,8 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     {
         // diagnostic build: per-workgroup {start, loaded, end} (s_memrealtime, 100 MHz) + HW_ID, dumped to $FTK_MATCH_STAMPS_DUMP
         const int n_splits = (n_cur + per - 1) / per;
-        // (the matrix-core scan has 256-row workgroups and writes 8 words per workgroup: twice the rows, twice the words)
-        const size_t n_wg = p.matrix_cores ? (size_t)((n_ref + 255) / 256) * n_splits * 2 : (size_t)row_blocks * n_splits;
+        // (the matrix-core scan has 64-row workgroups and writes 8 words per workgroup)
+        const size_t n_wg = p.matrix_cores ? (size_t)((n_ref + 63) / 64) * n_splits * 2 : (size_t)row_blocks * n_splits;
         unsigned long long *d_st = nullptr;
         FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_st), sizeof(unsigned long long) * 4 * n_wg));
         FTK_HIP(ctx, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 4 * n_wg, ctx->stream));

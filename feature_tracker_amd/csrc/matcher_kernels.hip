@@ -600,32 +600,39 @@ __global__ void __launch_bounds__(kBlock) hamming_match_scalar_kernel(const Matc
 //     64-bit atomicMin as the other scans; match_epilogue_kernel turns them into indices.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int kMfmaRows = 256;  // reference rows per workgroup (four independent waves)
+constexpr int kMfmaRows = 64;  // reference rows per workgroup: ONE wave (nothing is shared, so nothing is gained by larger groups,
+                               // and single waves pack the SIMDs' two slots evenly)
 
 // The rare path of the matrix-core scan: some lane of the wave holds a result above its lowest limit.  The caller folded the 32
 // results into four group maxima (8 registers each); only groups, and in them only registers, in which SOME lane beats its key
 // are looked at (wave-uniform skips: a true match touches one register of one group).  A result that beats the row's key
-// replaces it if the candidate is inside the NearbyMatch window.  Returns the lane's new lowest limit.
+// replaces it if the candidate is inside the NearbyMatch window; `lowest` (the minimum of the lane's 32 limits) and the
+// number of registers sitting on it are kept up to date.
 template <bool kNearby>
-static __device__ __forceinline__ int mfma_update_keys(const MatchParams &p, const v16i &acc0, const v16i &acc1, const int (&group_top)[4],
-                                                       int (&key)[32], int lowest, int row0, int h, int cand, int j_begin) {
+static __device__ __forceinline__ void mfma_update_keys(const MatchParams &p, const v16i &acc0, const v16i &acc1, const int (&group_top)[4],
+                                                        int *key, const float2 *pred_rows, int &lowest, int &at_lowest, int h, int cand, int j_begin) {
     const int inv_pos = 0xFFFE - (cand - j_begin);
     float cu = 0.0f, cv = 0.0f;
     if (kNearby) {
         cu = p.cur_uv[2 * (long long)cand];
         cv = p.cur_uv[2 * (long long)cand + 1];
     }
-    bool changed = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (__ballot(group_top[g] > lowest) == 0ull) {
             continue;  // wave-uniform
         }
+        int group_keys[8];  // all eight reads in flight before the first is looked at
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            group_keys[e] = key[64 * (8 * g + e)];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int s = 8 * g + e;
             const int neg_d8 = s < 16 ? acc0[s & 15] : acc1[s & 15];
-            const bool beats = neg_d8 > (key[s] >> 16);
+            const int limit = group_keys[e] >> 16;
+            const bool beats = neg_d8 > limit;
             if (__ballot(beats) == 0ull) {
                 continue;  // wave-uniform
             }
@@ -633,49 +640,36 @@ static __device__ __forceinline__ int mfma_update_keys(const MatchParams &p, con
                 bool in_window = true;
                 if (kNearby) {
                     // descriptor_matcher.h:108-111: outside the window -> not a candidate
-                    const int row = min(row0 + (s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h, p.n_ref - 1);
-                    const float pu = p.pred_uv[2 * (long long)row], pv = p.pred_uv[2 * (long long)row + 1];
-                    in_window = !((fabsf(pu - cu) > p.max_col) | (fabsf(pv - cv) > p.max_row));
+                    const float2 pr = pred_rows[(s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h];
+                    in_window = !((fabsf(pr.x - cu) > p.max_col) | (fabsf(pr.y - cv) > p.max_row));
                 }
                 if (in_window) {
-                    key[s] = (int)(((unsigned)neg_d8 << 16) | (unsigned)inv_pos);
-                    changed = true;
+                    key[64 * s] = (int)(((unsigned)neg_d8 << 16) | (unsigned)inv_pos);
+                    at_lowest -= limit == lowest ? 1 : 0;
                 }
             }
         }
     }
-    if (__ballot(changed) != 0ull) {  // keys only grow: the lowest limit moves only when a key did
-        int low = 0x7FFF;
+    // keys only grow, so the lane's lowest limit moves only once the last register that sat on it has moved: almost never
+    if (__ballot(at_lowest == 0) != 0ull) {
+        if (at_lowest == 0) {
+            int low = 0x7FFF;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            low = min(low, key[s] >> 16);
+            for (int s = 0; s < 32; ++s) {
+                low = min(low, key[64 * s] >> 16);
+            }
+            lowest = low;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                at_lowest += (key[64 * s] >> 16) == low ? 1 : 0;
+            }
         }
-        lowest = low;
     }
-    return lowest;
 }
 
 template <int NW, bool kNearby>
-__global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchParams p) {
-    static_assert(NW % 4 == 0, "whole 16-byte loads of a candidate");
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int row0 = (int)blockIdx.x * kMfmaRows + wave * 64;  // this wave's 64 rows
-    const int j_begin = (int)blockIdx.y * p.cur_per_block;
-    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+static __device__ __forceinline__ void mfma_scan(const MatchParams &p, int lane, int c, int h, int row0, int j_begin, int j_end) {
     const int last = j_end - 1;
-    if (row0 >= p.n_ref) {
-        return;  // wave-uniform; the waves never synchronise
-    }
-    if (kNearby && p.boxes != nullptr) {
-        // block-uniform early exit on the bounding boxes (hamming_match_tiled_kernel); row boxes cover 256 * kMatchRefs rows
-        const int n_row_boxes = (p.n_ref + kBlock * kMatchRefs - 1) / (kBlock * kMatchRefs);
-        const float4 pb = p.boxes[((int)blockIdx.x * kMfmaRows) / (kBlock * kMatchRefs)], cb = p.boxes[n_row_boxes + blockIdx.y];
-        const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
-        if (cb.x - pb.y > reach_u || pb.x - cb.y > reach_u || cb.z - pb.w > reach_v || pb.z - cb.w > reach_v) {
-            return;
-        }
-    }
 #ifdef FTK_MATCH_STAMPS
     const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime();
@@ -685,7 +679,8 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
     v4i words[2][NW / 4];
 #define FTK_FETCH_WORDS(set_, tile_begin_)                                                                     \
     {                                                                                                          \
-        const v4i *src_ = reinterpret_cast<const v4i *>(p.cur_words + (long long)min((tile_begin_) + c, last) * NW); \
+        /* 32-bit byte offset from the uniform base (the host keeps n_cur * NW * 4 below 2^31): two VALU instructions of address */ \
+        const v4i *src_ = reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(p.cur_words) + (uint32_t)min((tile_begin_) + c, last) * (uint32_t)(4 * NW)); \
         _Pragma("unroll") for (int q_ = 0; q_ < NW / 4; ++q_) {                                                \
             words[set_][q_] = src_[q_];                                                                        \
         }                                                                                                      \
@@ -693,20 +688,28 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
     FTK_FETCH_WORDS(0, j_begin)
 
     // ---- the A operand: 64 rows as +-8 / +-4 / +-2 / +-1 bytes, and -8 popcount(row) as the accumulators' start ----
+    // Only the first kEarly words are multiplied on the common path: a distance only grows word by word, so a candidate whose
+    // partial distance has reached the row's limit is dead whatever the other words hold (as in the popcount scans above).
+    constexpr int kEarly = (NW * 3) / 4;
     v4i a[2][NW];
-    int pop[2];
+    int pop_early[2], pop_rest[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int row = row0 + t * 32 + c;
         const v4i *src = reinterpret_cast<const v4i *>(p.ref_words + (long long)min(row, p.n_ref - 1) * NW);
-        pop[t] = 0;
+        pop_early[t] = 0;
+        pop_rest[t] = 0;
 #pragma unroll
         for (int q = 0; q < NW / 4; ++q) {
             const v4i four = src[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t w = (uint32_t)four[e];
-                pop[t] += __popc(w);
+                if (4 * q + e < kEarly) {
+                    pop_early[t] += __popc(w);
+                } else {
+                    pop_rest[t] += __popc(w);
+                }
                 const uint32_t half = w >> (4 * h);
                 // dword v: bits 4 h + v + 8 j of the word -> byte j = +2^(3-v) (set) / -2^(3-v) (clear): v_perm_b32 picks byte 1 / byte 0
                 a[t][4 * q + e][0] = (int)__builtin_amdgcn_perm(0u, 0x000008F8u, half & 0x01010101u);
@@ -716,21 +719,42 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
             }
         }
     }
+    // accumulator starts: -8 popcount of the row's first kEarly words; the popcounts of the remaining words wait, four to a
+    // register (each <= 128), for the rare completion
     v16i start0, start1;
+    uint32_t rest_packed[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rest_packed[t][q] = 0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int r = (i & 3) + 8 * (i >> 2) + 4 * h;  // lane r (and r + 32) holds row r's popcount
-        start0[i] = -8 * __shfl(pop[0], r);
-        start1[i] = -8 * __shfl(pop[1], r);
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * h;  // lane r (and r + 32) holds row r's popcounts
+        start0[i] = -8 * __shfl(pop_early[0], r);
+        start1[i] = -8 * __shfl(pop_early[1], r);
+        rest_packed[0][i >> 2] |= (uint32_t)__shfl(pop_rest[0], r) << (8 * (i & 3));
+        rest_packed[1][i >> 2] |= (uint32_t)__shfl(pop_rest[1], r) << (8 * (i & 3));
     }
     // d < limit0 is the conservative integer form of `distance < kMaxValidDescriptorDistance`
     const int limit0 = (p.max_distance >= 0.0f && p.max_distance < 4000.0f) ? (int)p.max_distance + 1 : (p.max_distance < 0.0f ? 0 : 4001);
-    int key[32];
+    // the running keys live in LDS (register s of lane l at [64 s + l]: conflict-free): only the rare path touches them,
+    // like the predicted positions of the wave's 64 rows (NearbyMatch)
+    __shared__ int key_store[32 * 64];
+    __shared__ float2 pred_rows[64];
+    int *key = &key_store[lane];
+    if (kNearby) {
+        const int row = min(row0 + lane, p.n_ref - 1);
+        pred_rows[lane] = make_float2(p.pred_uv[2 * (long long)row], p.pred_uv[2 * (long long)row + 1]);
+    }
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        key[s] = (int)(((unsigned)(-8 * limit0) << 16) | 0xFFFFu);
+        key[64 * s] = (int)(((unsigned)(-8 * limit0) << 16) | 0xFFFFu);
     }
     int lowest = -8 * limit0;  // min over this lane's 32 rows of the -8 distance a candidate has to exceed
+    int at_lowest = 32;        // how many of the 32 sit on it
     const int shift = 4 * h;
 
 #ifdef FTK_MATCH_STAMPS
@@ -743,16 +767,18 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
 #define FTK_SLOW_BEGIN
 #define FTK_SLOW_END
 #endif
+#define FTK_EXPAND_WORD(set_, m_)                                                         \
+    const uint32_t half_ = (uint32_t)words[set_][(m_) / 4][(m_) % 4] >> shift;           \
+    v4i b_;                                                                              \
+    b_[0] = (int)(half_ & 0x01010101u);                                                  \
+    b_[1] = (int)(half_ & 0x02020202u);                                                  \
+    b_[2] = (int)(half_ & 0x04040404u);                                                  \
+    b_[3] = (int)(half_ & 0x08080808u);
 #define FTK_MFMA_TILE(set_, tile_begin_)                                                                                       \
     {                                                                                                                          \
         v16i acc0 = start0, acc1 = start1;                                                                                     \
-        _Pragma("unroll") for (int m_ = 0; m_ < NW; ++m_) {                                                                    \
-            const uint32_t half_ = (uint32_t)words[set_][m_ / 4][m_ % 4] >> shift;                                             \
-            v4i b_;                                                                                                            \
-            b_[0] = (int)(half_ & 0x01010101u);                                                                                \
-            b_[1] = (int)(half_ & 0x02020202u);                                                                                \
-            b_[2] = (int)(half_ & 0x04040404u);                                                                                \
-            b_[3] = (int)(half_ & 0x08080808u);                                                                                \
+        _Pragma("unroll") for (int m_ = 0; m_ < kEarly; ++m_) {                                                                \
+            FTK_EXPAND_WORD(set_, m_)                                                                                          \
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][m_], b_, acc0, 0, 0, 0);                                          \
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][m_], b_, acc1, 0, 0, 0);                                          \
         }                                                                                                                      \
@@ -766,7 +792,18 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
         const int top_ = max(max(gtop_[0], gtop_[1]), max(gtop_[2], gtop_[3]));                                                \
         if (__builtin_expect(__ballot(top_ > lowest) != 0ull, 0)) { /* wave-uniform */                                          \
             FTK_SLOW_BEGIN                                                                                                     \
-            lowest = mfma_update_keys<kNearby>(p, acc0, acc1, gtop_, key, lowest, row0, h, min((tile_begin_) + c, last), j_begin); \
+            /* complete the distances: the remaining words' popcounts and products (group maxima of the partial results */     \
+            /* stay valid as a filter: a completed result is never larger) */                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                                \
+                acc0[i_] -= 8 * (int)((rest_packed[0][i_ >> 2] >> (8 * (i_ & 3))) & 0xFFu);                                    \
+                acc1[i_] -= 8 * (int)((rest_packed[1][i_ >> 2] >> (8 * (i_ & 3))) & 0xFFu);                                    \
+            }                                                                                                                  \
+            _Pragma("unroll") for (int m_ = kEarly; m_ < NW; ++m_) {                                                           \
+                FTK_EXPAND_WORD(set_, m_)                                                                                      \
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][m_], b_, acc0, 0, 0, 0);                                      \
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1][m_], b_, acc1, 0, 0, 0);                                      \
+            }                                                                                                                  \
+            mfma_update_keys<kNearby>(p, acc0, acc1, gtop_, key, pred_rows, lowest, at_lowest, h, min((tile_begin_) + c, last), j_begin); \
             FTK_SLOW_END                                                                                                       \
         }                                                                                                                      \
     }
@@ -787,25 +824,35 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
     const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     // ---- the best candidate of every row: maximum over the 32 lanes of the half, then one lane per row merges across splits ----
-    // (a register in which no lane of the wave found anything — nearly all of them under a real threshold — is skipped)
+    // A register in which no lane of the wave found anything — nearly all of them under a real threshold — is skipped; with up
+    // to eight finders per register every one of them merges its own key (atomicMin takes the smallest distance, then the
+    // lowest index, whoever sends it); only beyond that is the register first reduced over the lanes.
+    int final_keys[32];  // all reads in flight before the first is looked at
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
-        int k = key[s];
-        if (__ballot((k & 0xFFFF) != 0xFFFF) == 0ull) {
+        final_keys[s] = key[64 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        int k = final_keys[s];
+        const unsigned long long finders = __ballot((k & 0xFFFF) != 0xFFFF);
+        if (finders == 0ull) {
             continue;  // wave-uniform
         }
+        bool send = (k & 0xFFFF) != 0xFFFF;
+        if (__popcll(finders) > 8) {
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            k = max(k, __shfl_xor(k, off));
-        }
-        if (c == s) {
-            const int row = row0 + (s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
-            const int d = -(k >> 16) / 8;
-            // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
-            if (row < p.n_ref && (k & 0xFFFF) != 0xFFFF && (float)d < p.max_distance) {
-                const unsigned long long packed = ((unsigned long long)(unsigned)d << 32) | (unsigned)(j_begin + 0xFFFE - (k & 0xFFFF));
-                atomicMin(&p.keys[row], packed);
+            for (int off = 16; off >= 1; off >>= 1) {
+                k = max(k, __shfl_xor(k, off));
             }
+            send = c == s;
+        }
+        const int row = row0 + (s >> 4) * 32 + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
+        const int d = -(k >> 16) / 8;
+        // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
+        if (send && row < p.n_ref && (k & 0xFFFF) != 0xFFFF && (float)d < p.max_distance) {
+            const unsigned long long packed = ((unsigned long long)(unsigned)d << 32) | (unsigned)(j_begin + 0xFFFE - (k & 0xFFFF));
+            atomicMin(&p.keys[row], packed);
         }
     }
 #ifdef FTK_MATCH_STAMPS
@@ -824,9 +871,31 @@ __global__ void __launch_bounds__(kBlock) hamming_match_mfma_kernel(const MatchP
 }
 
 #undef FTK_FETCH_WORDS
+#undef FTK_EXPAND_WORD
 #undef FTK_MFMA_TILE
 #undef FTK_SLOW_BEGIN
 #undef FTK_SLOW_END
+
+template <int NW, bool kNearby>
+__global__ void __launch_bounds__(64) hamming_match_mfma_kernel(const MatchParams p) {
+    static_assert(NW % 4 == 0, "whole 16-byte loads of a candidate");
+    const int lane = (int)threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * kMfmaRows;  // this wave's 64 rows
+    const int j_begin = (int)blockIdx.y * p.cur_per_block;
+    const int j_end = min(j_begin + p.cur_per_block, p.n_cur);
+    bool out_of_reach = false;
+    if (kNearby && p.boxes != nullptr) {
+        // wave-uniform early exit on the bounding boxes (hamming_match_tiled_kernel); row boxes cover 256 * kMatchRefs rows
+        const int n_row_boxes = (p.n_ref + kBlock * kMatchRefs - 1) / (kBlock * kMatchRefs);
+        const float4 pb = p.boxes[((int)blockIdx.x * kMfmaRows) / (kBlock * kMatchRefs)], cb = p.boxes[n_row_boxes + blockIdx.y];
+        const float reach_u = p.max_col + 1.0f, reach_v = p.max_row + 1.0f;
+        out_of_reach = cb.x - pb.y > reach_u || pb.x - cb.y > reach_u || cb.z - pb.w > reach_v || pb.z - cb.w > reach_v;
+    }
+    if (!out_of_reach) {
+        mfma_scan<NW, kNearby>(p, lane, c, h, row0, j_begin, j_end);
+    }
+}
 
 __global__ void __launch_bounds__(kBlock) match_epilogue_kernel(unsigned long long *keys, int32_t *index_pairs, int n_ref) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -856,9 +925,9 @@ hipError_t launch_nw(const MatchParams &p, hipStream_t stream) {
             }
             const dim3 grid((unsigned)((p.n_ref + kMfmaRows - 1) / kMfmaRows), (unsigned)splits);
             if (p.pred_uv) {
-                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, true>), grid, dim3(kBlock), 0, stream, p);
+                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, true>), grid, dim3(64), 0, stream, p);
             } else {
-                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, false>), grid, dim3(kBlock), 0, stream, p);
+                hipLaunchKernelGGL((hamming_match_mfma_kernel<NW, false>), grid, dim3(64), 0, stream, p);
             }
             return hipGetLastError();
         }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Experiment (GPU box): Hamming matcher 10 000 x 10 000 BRIEF-256 per-call time by scan kernel (FTK_MATCH_KERNEL) and grid.
+# Experiment (GPU box): Hamming matcher 10 000 x 10 000 BRIEF-256 per-call time by scan kernel (FTK_MATCH_KERNEL) and switches.
 #   match_ab.sh [quick]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 run() { echo "== $*"; env "$@" python3 $ROOT/scripts/bench_configs.py --only match --quick 2>&1 | python3 -c "
@@ -9,7 +9,7 @@ for l in sys.stdin:
     except Exception: continue
     print('   ', d['case'], 'gpu_kernel_ms %.4f' % d['gpu_kernel_ms'], 'exact', d['indices_bit_exact_on_sample'])"; }
 run FTK_MATCH_KERNEL=mfma
+run FTK_MATCH_KERNEL=mfma FTK_MATCH_FUSED=0
 run FTK_MATCH_KERNEL=scalar
 [ "$1" = quick ] && exit 0
-run FTK_MATCH_KERNEL=lds
-for wgs in 256 384 768 1024; do run FTK_MATCH_KERNEL=mfma FTK_MATCH_WGS=$wgs; done
+for wgs in 1024 1536 3072 4096; do run FTK_MATCH_KERNEL=mfma FTK_MATCH_WGS=$wgs; done

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for every hot kernel of the path (GPU box, through gpurun from the repo root):
 #   scripts/profile_all.sh <tag> [workloads...]     -> gpurun_out/prof_<tag>/<workload>/{trace,pmc_*}/...
 # Workloads: config2 (headline, klt_basic_inverse_pipelined_kernel), config3 (klt_track_kernel<affine, inverse>),
-# config4 (klt_track_kernel<lssd, fast>), config5_shard, hamming (hamming_match_tiled_kernel, 10 000 x 10 000 BRIEF-256).
+# config4 (klt_track_kernel<lssd, fast>), config5_shard, hamming (hamming_match_mfma_kernel, 10 000 x 10 000 BRIEF-256).
 # One run with --kernel-trace --stats; every PMC group in a run of its own (never combined with tracing).
 # scripts/summarize_profile.py <tag> condenses the result into profiles/.
 set -u

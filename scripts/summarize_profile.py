@@ -18,7 +18,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOT = ("klt_", "hamming_", "match_epilogue", "cosine_", "direct_track", "downsample", "brief_kernel", "harris")
 DOMINANT = {"config2": "klt_basic_inverse_pipelined_kernel", "config5_shard": "klt_basic_inverse_pipelined_kernel", "config1": "klt_basic_inverse_pipelined_kernel",
-            "config3": "klt_", "config4": "klt_", "hamming": "hamming_match_tiled_kernel"}
+            "config3": "klt_", "config4": "klt_", "hamming": "hamming_match_mfma_kernel"}
 
 
 def main(tag):

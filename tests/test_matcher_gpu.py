@@ -159,3 +159,31 @@ def test_nearby_match_in_spatial_order(ftk, oracle, n, n_bits, window):
             ok_c, c = oracle.nearby_match(ref, cur, pred_uv, cur_uv, 70.0, max_col=col, max_row=row)
         assert ok_g and ok_c
         assert np.array_equal(g, c), (col, row, np.flatnonzero(g != c)[:10])
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "scalar", "lds"])
+def test_every_scan_kernel_gives_the_oracle_indices(ftk, oracle, kernel, monkeypatch):
+    """The three Hamming scans behind ftk_hamming_match (matrix cores for 256 / 512 bits, popcount with the candidates on the
+    scalar path, popcount with LDS tiles; FTK_MATCH_KERNEL picks one, read per call) on the same inputs: thresholds below,
+    at and far above the distances that occur (the early exits key on the threshold), duplicates (lowest j wins), a
+    candidate count that is not a multiple of any tile, reference counts around the 64-row and 512-row blocks, NearbyMatch
+    windows with NaN coordinates, and stale indices that must survive."""
+    monkeypatch.setenv("FTK_MATCH_KERNEL", kernel)
+    rs = np.random.RandomState(17)
+    for n_ref, n_cur, n_bits in ((65, 33, 256), (513, 1001, 256), (1500, 2100, 512), (200, 777, 256), (130, 95, 512)):
+        ref, cur, _ = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=n_bits // 12)
+        cur[n_cur // 2] = cur[3]  # a duplicate candidate further down: the lower index must win
+        ref[7] = 0
+        cur[11] = 0              # all-zero descriptors on both sides
+        cur_uv = rs.uniform(0, 300, (n_cur, 2)).astype(np.float32)
+        pred_uv = rs.uniform(0, 300, (n_ref, 2)).astype(np.float32)
+        pred_uv[5, 0] = np.nan   # passes every window test (descriptor_matcher.h:108-111)
+        cur_uv[9, 1] = np.nan
+        stale = np.arange(n_ref, dtype=np.int32) + 7000
+        for thr in (0.0, 12.0, float(n_bits // 12), 60.0, 1000.0):
+            ok_g, idx_g = matcher(ftk, thr).ForceMatch(ref, cur, stale.copy())
+            ok_c, idx_c = oracle.force_match(ref, cur, thr, stale.copy())
+            assert np.array_equal(idx_g, idx_c), (kernel, n_ref, n_cur, n_bits, thr)
+            ok_g, idx_g = matcher(ftk, thr, 35, 80).NearbyMatch(ref, cur, pred_uv, cur_uv, stale.copy())
+            ok_c, idx_c = oracle.nearby_match(ref, cur, pred_uv, cur_uv, thr, 35, 80, stale.copy())
+            assert np.array_equal(idx_g, idx_c), (kernel, n_ref, n_cur, n_bits, thr, "nearby")
