@@ -18,7 +18,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOT = ("klt_", "hamming_", "match_epilogue", "cosine_", "direct_track", "downsample", "brief_kernel", "harris")
 DOMINANT = {"config2": "klt_basic_inverse_pipelined_kernel", "config5_shard": "klt_basic_inverse_pipelined_kernel", "config1": "klt_basic_inverse_pipelined_kernel",
-            "config3": "klt_", "config4": "klt_", "hamming": "hamming_match_mfma_kernel"}
+            "config3": "klt_", "config4": "klt_", "hamming": "hamming_match_mfma_kernel<8, false>"}
 
 
 def main(tag):
@@ -74,6 +74,11 @@ def main(tag):
                     entry["salu_insts_per_launch"] = int(v["SQ_INSTS_SALU"])
                 if "SQ_INSTS_LDS" in v:
                     entry["lds_insts_per_launch"] = int(v["SQ_INSTS_LDS"])
+                if v.get("SQ_INSTS_MFMA"):
+                    entry["mfma_insts_per_launch"] = int(v["SQ_INSTS_MFMA"])
+                    entry["mfma_busy_cycles_per_launch"] = int(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0))
+                if v.get("GRBM_GUI_ACTIVE"):
+                    entry["gui_active_cycles_sum_over_xcds"] = int(v["GRBM_GUI_ACTIVE"])
                 if v.get("SQ_LDS_IDX_ACTIVE"):
                     entry["lds_bank_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]
                 if v.get("SQ_WAVE_CYCLES"):
