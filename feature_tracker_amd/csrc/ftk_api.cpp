@@ -85,6 +85,8 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     return FTK_OK;
 }
 
+constexpr uint32_t kSchedMinFeatures = 4096;  // below this every feature is resident from the start: nothing to order
+
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
     if (count <= ctx->match_boxes_count) {
         return FTK_OK;
@@ -174,6 +176,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.cur[i] = cur->levels[i];
     }
     p.n = n;
+    p.order = nullptr;        // list order unless the caller of this function installs a permutation
+    p.sched_iters = nullptr;
     p.n_track = ((uint32_t)n < opt->max_track_points) ? (uint32_t)n : opt->max_track_points;
     p.max_iteration = opt->max_iteration;
     p.max_large_step = opt->max_tolerance_large_step;
@@ -412,6 +416,14 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->direct_feat) {
         (void)hipFree(ctx->direct_feat);
+    }
+    if (ctx->sched_iters) {
+        (void)hipFree(ctx->sched_iters);
+        (void)hipFree(ctx->sched_order);
+    }
+    if (ctx->sched_flat) {
+        (void)hipHostFree(const_cast<int *>(ctx->sched_flat));
+        (void)hipFree(ctx->sched_skip_dev);
     }
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
@@ -652,6 +664,73 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     p.status_out = d_status_out;
     p.iters = d_iters;
     FTK_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        // Launch order.  A call's time is bulk + tail: features run a data-dependent number of Gauss-Newton iterations
+        // (config 3: mean 6.7, one feature 52), a launch in list order starts the long ones wherever they happen to sit,
+        // and the grid drains while they finish.  Trackers are called frame after frame on (nearly) the same feature list
+        // and a feature that needed many iterations tends to need many again, so from the second call with the same
+        // feature count on the launch slots go through a permutation: longest first by the PREVIOUS call's iteration
+        // counts (klt_order_kernel, one small launch).  Which slot runs a feature changes nothing in its arithmetic.
+        // Only for calls with more features than fit the chip at once (and at most 32 768, what the one-workgroup order kernel
+        // takes); FTK_KLT_SCHED=0 keeps list order.
+        static const bool sched_allowed = !(getenv("FTK_KLT_SCHED") && atoi(getenv("FTK_KLT_SCHED")) == 0);
+        p.order = nullptr;
+        p.sched_iters = nullptr;
+        if (sched_allowed && p.n_track >= kSchedMinFeatures && n <= ftk::kKltOrderMaxFeatures) {
+            if ((size_t)n > ctx->sched_capacity) {
+                FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->sched_iters) {
+                    (void)hipFree(ctx->sched_iters);
+                    (void)hipFree(ctx->sched_order);
+                    ctx->sched_iters = nullptr;
+                    ctx->sched_order = nullptr;
+                }
+                ctx->sched_capacity = 0;
+                ctx->sched_n = 0;
+                const size_t cap = ((size_t)n + 4095) / 4096 * 4096;
+                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_iters), sizeof(uint32_t) * cap));
+                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_order), sizeof(int32_t) * cap));
+                ctx->sched_capacity = cap;
+            }
+            if (!ctx->sched_flat) {
+                int *flag = nullptr;
+                FTK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(int), hipHostMallocMapped));
+                *flag = 0;
+                ctx->sched_flat = flag;
+                FTK_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->sched_flat_dev), flag, 0));
+                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_skip_dev), sizeof(int)));
+                FTK_HIP(ctx, hipMemsetAsync(ctx->sched_skip_dev, 0, sizeof(int), ctx->stream));
+            }
+            // When the order kernel found no tail in the counts (every feature about as long as the others: nothing to gain,
+            // ~10 us to lose) it says so through a host-mapped flag; the next 15 calls then go in list order before it is asked
+            // again.  The flag is read without synchronisation — it may be one call old, which a hint can afford.
+            if (ctx->sched_n != n) {
+                ctx->sched_skip = 0;
+                FTK_HIP(ctx, hipMemsetAsync(ctx->sched_skip_dev, 0, sizeof(int), ctx->stream));
+            } else if (ctx->sched_skip > 0) {
+                --ctx->sched_skip;
+            } else if (*ctx->sched_flat) {
+                *ctx->sched_flat = 0;
+                ctx->sched_skip = 15;
+            }
+            if (ctx->sched_n == n && ctx->sched_skip == 0) {
+                FTK_HIP(ctx, ftk::klt_order_launch(ctx->sched_iters, ctx->sched_order, n, ctx->sched_flat_dev, ctx->sched_skip_dev, ctx->stream));
+                p.order = ctx->sched_order;
+                if (const char *dump = getenv("FTK_KLT_SCHED_DUMP")) {  // diagnostic: the permutation and the counts it came from
+                    std::vector<int32_t> h((size_t)n * 2);
+                    FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+                    FTK_HIP(ctx, hipMemcpyAsync(h.data() + n, ctx->sched_iters, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+                    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (FILE *f = fopen(dump, "wb")) {
+                        fwrite(h.data(), sizeof(int32_t), h.size(), f);
+                        fclose(f);
+                    }
+                }
+            }
+            p.sched_iters = ctx->sched_iters;
+            ctx->sched_n = n;
+        }
+    }
 #ifdef FTK_STAMPS
     // diagnostic build: per-phase cycle totals (s_memtime ticks at 100 MHz) averaged over features, to stderr
     unsigned long long *d_stamps = nullptr;

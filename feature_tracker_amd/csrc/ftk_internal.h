@@ -36,6 +36,15 @@ struct ftk_context {
     void *direct_feat = nullptr;
     size_t direct_feat_bytes = 0;
     // zero-padded copies of descriptors whose width is not a power of two (device-resident matcher entry)
+    // launch order of the generic trackers: the previous call's iteration counts and the permutation made from them
+    uint32_t *sched_iters = nullptr;
+    int32_t *sched_order = nullptr;
+    size_t sched_capacity = 0;  // features both buffers hold
+    int32_t sched_n = 0;        // feature count of the call that wrote sched_iters (0: none)
+    volatile int *sched_flat = nullptr;  // pinned, device-mapped: the order kernel's "no tail in the counts" verdict
+    int *sched_flat_dev = nullptr;
+    int *sched_skip_dev = nullptr;  // device: launches of the order kernel left to skip (its own no-tail verdict)
+    uint32_t sched_skip = 0;    // calls left before the order kernel is tried again after a flat verdict
     void *match_pad = nullptr;
     size_t match_pad_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)

@@ -352,6 +352,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     if (id >= (uint32_t)p.n) {
         return;
     }
+    if (p.order) {
+        id = (uint32_t)p.order[id];  // launch slot -> feature: longest first by the previous call's iteration counts
+    }
     const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
     uint8_t status = p.status_in[id];
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through (basic_klt.cpp:9,15)
@@ -362,6 +365,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             p.status_out[id] = status;
             if (p.iters) {
                 p.iters[id] = 0;
+            }
+            if (p.sched_iters) {
+                p.sched_iters[id] = 0;
             }
         }
         return;
@@ -624,6 +630,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         p.status_out[id] = status;
         if (p.iters) {
             p.iters[id] = iters;
+        }
+        if (p.sched_iters) {
+            p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }
     }
 #ifdef FTK_STAMPS

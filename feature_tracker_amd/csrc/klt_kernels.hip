@@ -1513,10 +1513,12 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     b.wave = SOLO ? 0 : b.tid >> 6;
     b.nwaves = SOLO ? 1 : b.nt >> 6;
     // SOLO: p.features_per_group one-wave features share a workgroup without ever meeting (own LDS carve, no barrier)
-    const uint32_t id = SOLO ? blockIdx.x * (uint32_t)p.features_per_group + (threadIdx.x >> 6) : blockIdx.x;
-    if (id >= (uint32_t)p.n) {
+    // launch slot -> feature: in list order, or through the longest-first permutation of the previous call's iteration counts
+    const uint32_t slot_id = SOLO ? blockIdx.x * (uint32_t)p.features_per_group + (threadIdx.x >> 6) : blockIdx.x;
+    if (slot_id >= (uint32_t)p.n) {
         return;
     }
+    const uint32_t id = p.order ? (uint32_t)p.order[slot_id] : slot_id;
     const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
     uint8_t status = p.status_in[id];
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through
@@ -1527,6 +1529,9 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
             p.status_out[id] = status;
             if (p.iters) {
                 p.iters[id] = 0;
+            }
+            if (p.sched_iters) {
+                p.sched_iters[id] = 0;
             }
         }
         return;
@@ -1644,6 +1649,9 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
         p.status_out[id] = status;
         if (p.iters) {
             p.iters[id] = iters;
+        }
+        if (p.sched_iters) {
+            p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }
     }
 #ifdef FTK_STAMPS

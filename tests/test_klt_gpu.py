@@ -8,6 +8,7 @@ the contractual tolerance next to it.
 import numpy as np
 import pytest
 
+from feature_tracker_amd import synth
 from tests import scenes
 
 pytestmark = pytest.mark.gpu
@@ -364,3 +365,45 @@ def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
             assert_parity(gpu, cpu, f"chunked={chunked} half={half}x{half_cols}")
             results.append(gpu)
         assert np.array_equal(results[0][1].view(np.uint32), results[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("model,method", [("affine", "inverse"), ("lssd", "fast"), ("basic", "inverse")])
+def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model, method, monkeypatch):
+    """From the second call with the same feature count on, the device entry launches the features longest-first by the
+    previous call's iteration counts (ftk_api.cpp, klt_order_kernel; calls of >= 4096 features).  Every call must return
+    what the first one did — the oracle's answer — also when the history comes from DIFFERENT inputs (a stale predictor),
+    when some features are passed through (incoming status, kMaxTrackPointsNumber) and under every experiment mode of the
+    order kernel."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    n = 4600
+    uv = synth.make_features(n, 320, 240, margin=20.0, border_fraction=0.03, half=5)
+    other = uv[::-1].copy()
+    status = (np.arange(n) % 11 == 0).astype(np.uint8) * 3
+    cap = 4400
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = D.context_on_stream(stream, 0)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, 5, 5, cap
+    with torch.cuda.stream(stream):
+        klt = D.DeviceKlt(model, opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_st = torch.from_numpy(status).to(dev)
+
+        def run(points):
+            d_ref = torch.from_numpy(points).to(dev)
+            d_out, d_so = torch.empty_like(d_ref), torch.empty(n, dtype=torch.uint8, device=dev)
+            klt.track(d_ref, d_ref.clone(), d_st, d_out, d_so)
+            stream.synchronize()
+            return d_out.cpu().numpy(), d_so.cpu().numpy()
+
+        first = run(uv)                      # list order (no history)
+        again = [run(uv) for _ in range(2)]  # ordered by the counts of the same inputs
+        run(other)                           # history now comes from other inputs
+        stale = run(uv)
+    ok, c, s, _ = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, uv, status, method=method, half=5, max_points=cap)
+    assert (s == 1).sum() > n // 2
+    for name, (g_uv, g_st) in (("first", first), ("second", again[0]), ("third", again[1]), ("stale history", stale)):
+        assert np.array_equal(g_st, s), name
+        assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32)), name
