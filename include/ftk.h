@@ -140,6 +140,9 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
  * Same computation on device-resident buffers, asynchronous on the context's stream.
  * d_cur_uv_out / d_status_out may alias the *_in buffers (in-place, as the reference) or be
  * separate (repeatable launches for benchmarking).  d_iters may be NULL.
+ * Launch order (performance only, results are independent of it): calls of 4 096 .. 32 768 features keep every feature's
+ * iteration count in the context, and the next call with the same n launches the features longest-first by those counts
+ * (frame-to-frame coherence of a tracker's feature list; environment FTK_KLT_SCHED=0 keeps list order).
  */
 int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur,
                          const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out, const uint8_t *d_status_in,
@@ -305,6 +308,8 @@ int ftk_hamming_match_sharded_device(ftk_context *ctx, ftk_comm *comm, const uin
  * or take a generic scan — same indices), bit i of the descriptor in bit (i % 32) of word i / 32, unused
  * high bits 0.
  * n_bits == 0 reproduces ComputeDistance's "empty descriptor" answer (kMaxInt32).
+ * 256- and 512-bit descriptors (n_words 8 / 16) are compared on the matrix cores (the distances are exact integers out of
+ * int8 MFMAs: same indices as the popcount scans that serve the other widths); the device pointers need 4-byte alignment only.
  * pred_uv == NULL selects ForceMatch; otherwise NearbyMatch with the window test
  * |pred.u - cur.u| > max_col_distance || |pred.v - cur.v| > max_row_distance -> skip.
  * index_pairs is in/out (n_ref entries): written only where a candidate beats the threshold,
