@@ -86,6 +86,7 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
 }
 
 constexpr uint32_t kSchedMinFeatures = 4096;  // below this every feature is resident from the start: nothing to order
+constexpr int32_t kSchedMaxFeatures = 1 << 18;  // the sort block walks the list alone; beyond this it could outlast the launch
 
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
     if (count <= ctx->match_boxes_count) {
@@ -178,6 +179,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.n = n;
     p.order = nullptr;        // list order unless the caller of this function installs a permutation
     p.sched_iters = nullptr;
+    p.sort_iters = nullptr;
+    p.sort_order_out = nullptr;
     p.n_track = ((uint32_t)n < opt->max_track_points) ? (uint32_t)n : opt->max_track_points;
     p.max_iteration = opt->max_iteration;
     p.max_large_step = opt->max_tolerance_large_step;
@@ -417,13 +420,11 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->direct_feat) {
         (void)hipFree(ctx->direct_feat);
     }
-    if (ctx->sched_iters) {
-        (void)hipFree(ctx->sched_iters);
-        (void)hipFree(ctx->sched_order);
-    }
-    if (ctx->sched_flat) {
-        (void)hipHostFree(const_cast<int *>(ctx->sched_flat));
-        (void)hipFree(ctx->sched_skip_dev);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->sched_iters[k]) {
+            (void)hipFree(ctx->sched_iters[k]);
+            (void)hipFree(ctx->sched_order[k]);
+        }
     }
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
@@ -668,58 +669,51 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
         // Launch order.  A call's time is bulk + tail: features run a data-dependent number of Gauss-Newton iterations
         // (config 3: mean 6.7, one feature 52), a launch in list order starts the long ones wherever they happen to sit,
         // and the grid drains while they finish.  Trackers are called frame after frame on (nearly) the same feature list
-        // and a feature that needed many iterations tends to need many again, so from the second call with the same
-        // feature count on the launch slots go through a permutation: longest first by the PREVIOUS call's iteration
-        // counts (klt_order_kernel, one small launch).  Which slot runs a feature changes nothing in its arithmetic.
-        // Only for calls with more features than fit the chip at once (and at most 32 768, what the one-workgroup order kernel
-        // takes); FTK_KLT_SCHED=0 keeps list order.
+        // and a feature that needed many iterations tends to need many again, so the launch slots go through a permutation:
+        // longest first by an EARLIER call's iteration counts.  No launch of its own: call k's tracker launch carries one
+        // extra workgroup (block 0, klt_common.h klt_order_block) that sorts call k - 1's counts while the features of call k
+        // run, and call k + 1 uses the result — so from the third call with the same feature count on, with a predictor two
+        // calls old.  Which slot runs a feature changes nothing in its arithmetic.  Only for calls with more features than
+        // fit the chip at once; FTK_KLT_SCHED=0 keeps list order.
         static const bool sched_allowed = !(getenv("FTK_KLT_SCHED") && atoi(getenv("FTK_KLT_SCHED")) == 0);
-        p.order = nullptr;
-        p.sched_iters = nullptr;
-        if (sched_allowed && p.n_track >= kSchedMinFeatures && n <= ftk::kKltOrderMaxFeatures) {
+        if (sched_allowed && p.n_track >= kSchedMinFeatures && n <= kSchedMaxFeatures) {
             if ((size_t)n > ctx->sched_capacity) {
                 FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->sched_iters) {
-                    (void)hipFree(ctx->sched_iters);
-                    (void)hipFree(ctx->sched_order);
-                    ctx->sched_iters = nullptr;
-                    ctx->sched_order = nullptr;
+                for (int k = 0; k < 2; ++k) {
+                    if (ctx->sched_iters[k]) {
+                        (void)hipFree(ctx->sched_iters[k]);
+                        (void)hipFree(ctx->sched_order[k]);
+                        ctx->sched_iters[k] = nullptr;
+                        ctx->sched_order[k] = nullptr;
+                    }
                 }
                 ctx->sched_capacity = 0;
                 ctx->sched_n = 0;
                 const size_t cap = ((size_t)n + 4095) / 4096 * 4096;
-                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_iters), sizeof(uint32_t) * cap));
-                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_order), sizeof(int32_t) * cap));
+                for (int k = 0; k < 2; ++k) {
+                    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_iters[k]), sizeof(uint32_t) * cap));
+                    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_order[k]), sizeof(int32_t) * cap));
+                }
                 ctx->sched_capacity = cap;
             }
-            if (!ctx->sched_flat) {
-                int *flag = nullptr;
-                FTK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(int), hipHostMallocMapped));
-                *flag = 0;
-                ctx->sched_flat = flag;
-                FTK_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->sched_flat_dev), flag, 0));
-                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_skip_dev), sizeof(int)));
-                FTK_HIP(ctx, hipMemsetAsync(ctx->sched_skip_dev, 0, sizeof(int), ctx->stream));
-            }
-            // When the order kernel found no tail in the counts (every feature about as long as the others: nothing to gain,
-            // ~10 us to lose) it says so through a host-mapped flag; the next 15 calls then go in list order before it is asked
-            // again.  The flag is read without synchronisation — it may be one call old, which a hint can afford.
             if (ctx->sched_n != n) {
-                ctx->sched_skip = 0;
-                FTK_HIP(ctx, hipMemsetAsync(ctx->sched_skip_dev, 0, sizeof(int), ctx->stream));
-            } else if (ctx->sched_skip > 0) {
-                --ctx->sched_skip;
-            } else if (*ctx->sched_flat) {
-                *ctx->sched_flat = 0;
-                ctx->sched_skip = 15;
+                ctx->sched_n = n;
+                ctx->sched_calls = 0;
             }
-            if (ctx->sched_n == n && ctx->sched_skip == 0) {
-                FTK_HIP(ctx, ftk::klt_order_launch(ctx->sched_iters, ctx->sched_order, n, ctx->sched_flat_dev, ctx->sched_skip_dev, ctx->stream));
-                p.order = ctx->sched_order;
-                if (const char *dump = getenv("FTK_KLT_SCHED_DUMP")) {  // diagnostic: the permutation and the counts it came from
+            const uint32_t k = ctx->sched_calls++;
+            p.sched_iters = ctx->sched_iters[k & 1];          // this call's counts
+            if (k >= 1) {                                     // sort the previous call's counts beside this call's features
+                p.sort_iters = ctx->sched_iters[(k - 1) & 1];
+                p.sort_order_out = ctx->sched_order[(k - 1) & 1];
+            }
+            if (k >= 2) {                                     // made during the previous call from the counts before it
+                p.order = ctx->sched_order[k & 1];
+            }
+            if (const char *dump = getenv("FTK_KLT_SCHED_DUMP")) {  // diagnostic: the permutation in use and the counts it came from
+                if (k >= 2) {
                     std::vector<int32_t> h((size_t)n * 2);
-                    FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-                    FTK_HIP(ctx, hipMemcpyAsync(h.data() + n, ctx->sched_iters, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+                    FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_order[k & 1], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+                    FTK_HIP(ctx, hipMemcpyAsync(h.data() + n, ctx->sched_iters[k & 1], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
                     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                     if (FILE *f = fopen(dump, "wb")) {
                         fwrite(h.data(), sizeof(int32_t), h.size(), f);
@@ -727,8 +721,6 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                     }
                 }
             }
-            p.sched_iters = ctx->sched_iters;
-            ctx->sched_n = n;
         }
     }
 #ifdef FTK_STAMPS

@@ -27,8 +27,10 @@ struct KltParams {
     const uint8_t *status_in;
     uint8_t *status_out;
     uint32_t *iters;       // may be null
-    const int32_t *order;  // may be null: launch slot -> feature index (a permutation of [0, n): klt_order_launch)
-    uint32_t *sched_iters; // may be null: iteration counts kept by the context for the next call's order
+    const int32_t *order;  // may be null: launch slot -> feature index (a permutation of [0, n) made by an earlier launch's sort block)
+    uint32_t *sched_iters; // may be null: iteration counts kept by the context for the launch order of later calls
+    const uint32_t *sort_iters;  // may be null: the previous call's counts; one extra workgroup (block 0) sorts them ...
+    int32_t *sort_order_out;     // ... into this permutation, longest first (klt_common.h, klt_order_block)
     int32_t n;             // features in the buffers
     uint32_t n_track;      // min(n, kMaxTrackPointsNumber)
     uint32_t max_iteration;
@@ -61,12 +63,6 @@ struct KltParams {
     int32_t pb_cap_r, pb_cap_c;          // lattice node capacity per axis: len + 2 + provable maximum of extras
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
 };
-
-// order[] = the feature indices sorted by iteration count, longest first (one workgroup: counting sort over min(count, 255))
-constexpr int kKltOrderMaxFeatures = 32768;
-// flat_out (may be null; host-mapped memory): set to 1 when the counts had no tail and the identity was written;
-// skip_calls (device memory, zero at first): after such a verdict the next 15 launches return at once (order[] keeps the identity)
-hipError_t klt_order_launch(const uint32_t *iters, int32_t *order, int32_t n, int *flat_out, int *skip_calls, hipStream_t stream);
 
 // LDS bytes a (model, method) variant needs for the given geometry; 0 if the variant is unknown.
 size_t klt_lds_bytes(int model, int method, const KltParams &p);

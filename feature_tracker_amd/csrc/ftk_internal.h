@@ -36,15 +36,13 @@ struct ftk_context {
     void *direct_feat = nullptr;
     size_t direct_feat_bytes = 0;
     // zero-padded copies of descriptors whose width is not a power of two (device-resident matcher entry)
-    // launch order of the generic trackers: the previous call's iteration counts and the permutation made from them
-    uint32_t *sched_iters = nullptr;
-    int32_t *sched_order = nullptr;
-    size_t sched_capacity = 0;  // features both buffers hold
-    int32_t sched_n = 0;        // feature count of the call that wrote sched_iters (0: none)
-    volatile int *sched_flat = nullptr;  // pinned, device-mapped: the order kernel's "no tail in the counts" verdict
-    int *sched_flat_dev = nullptr;
-    int *sched_skip_dev = nullptr;  // device: launches of the order kernel left to skip (its own no-tail verdict)
-    uint32_t sched_skip = 0;    // calls left before the order kernel is tried again after a flat verdict
+    // launch order of the trackers (ftk_klt_track_device): iteration counts of the last two calls and the permutations the
+    // sort block of the tracker launches makes from them, double-buffered
+    uint32_t *sched_iters[2] = {nullptr, nullptr};
+    int32_t *sched_order[2] = {nullptr, nullptr};
+    size_t sched_capacity = 0;   // features each buffer holds
+    int32_t sched_n = 0;         // feature count of the calls counted in sched_calls
+    uint32_t sched_calls = 0;    // consecutive calls with that feature count so far
     void *match_pad = nullptr;
     size_t match_pad_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)

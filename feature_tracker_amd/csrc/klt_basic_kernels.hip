@@ -328,6 +328,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     Blk b;
     uint32_t id;
     float4 *lds_mine = lds_raw;
+    // block 0 of a launch that carries the previous call's iteration counts sorts them into a later call's launch order
+    // (klt_common.h) beside the feature workgroups; the feature blocks follow it
+    uint32_t block = blockIdx.x;
+    if (p.sort_iters) {
+        if (block == 0) {
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw));
+            return;
+        }
+        block -= 1;
+    }
     if (SOLO) {
         // One wave per feature, several features per workgroup: the waves of the group share nothing but the launch (each has
         // its own LDS carve and never meets the others at a barrier — pb_sync is a wave-local fence here).  The hardware admits
@@ -338,7 +348,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         b.wave = 0;
         b.nwaves = 1;
         const uint32_t slot = threadIdx.x >> 6;
-        id = blockIdx.x * (uint32_t)p.features_per_group + slot;
+        id = block * (uint32_t)p.features_per_group + slot;
         lds_mine = lds_raw + (size_t)slot * (p.group_lds_stride >> 4);
     } else {
         b.tid = threadIdx.x;
@@ -346,7 +356,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         b.lane = b.tid & (kWave - 1);
         b.wave = b.tid >> 6;
         b.nwaves = b.nt >> 6;
-        id = blockIdx.x;
+        id = block;
     }
     constexpr bool solo = SOLO;
     if (id >= (uint32_t)p.n) {
@@ -672,7 +682,11 @@ hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream)
     } else {
         p.features_per_group = 1;
     }
-    const size_t lds = klt_basic_pipelined_lds_bytes(p);
+    size_t lds = klt_basic_pipelined_lds_bytes(p);
+    const unsigned sort_block = p.sort_iters ? 1u : 0u;  // one more workgroup: the sort of a later call's launch order
+    if (sort_block && lds < (size_t)kOrderLdsBytes) {
+        lds = kOrderLdsBytes;
+    }
     const bool solo = p.features_per_group > 1 || p.waves_per_feature == 1;
     if (solo && p.features_per_group < 1) {
         p.features_per_group = 1;
@@ -686,9 +700,9 @@ hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream)
     }
     if (solo) {
         const unsigned groups = (unsigned)((p.n + p.features_per_group - 1) / p.features_per_group);
-        hipLaunchKernelGGL(kernel, dim3(groups), dim3(kWave * p.features_per_group), lds, stream, p);
+        hipLaunchKernelGGL(kernel, dim3(groups + sort_block), dim3(kWave * p.features_per_group), lds, stream, p);
     } else {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds, stream, p);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n + sort_block), dim3(kWave * p.waves_per_feature), lds, stream, p);
     }
     return hipGetLastError();
 }

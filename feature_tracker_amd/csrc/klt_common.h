@@ -877,4 +877,103 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Launch order of a later call, computed by ONE extra workgroup of the tracker launch itself (block 0: it starts first and
+// runs beside the feature workgroups, so the sort costs no launch and no time of its own): the feature indices sorted by the
+// iteration counts of the PREVIOUS call, longest first — a counting sort over min(count, 255) with the workgroup's dynamic LDS
+// as its 2 x 256 bins.  It walks the list in index order, so inside a bin the features keep list order at workgroup
+// granularity.  When the counts have no tail (largest <= 1.5 x the mean of the tracked features) an order would buy nothing
+// and the identity is written.  Any permutation yields the same tracking results; only the schedule differs.
+// ---------------------------------------------------------------------------------------------
+
+// A slot in its bin for every active lane.  One round of "the lowest active lane's bin: ONE LDS atomic for all the lanes that
+// share it" — iteration counts cluster, and a call whose features all took 5 iterations would otherwise serialise thousands
+// of atomics on one address — then one atomic per remaining lane (counts spread over many bins: little contention).
+__device__ __forceinline__ int wave_bin_claim(int *bins, int bin, bool active) {
+    int slot = 0;
+    const unsigned long long todo = __ballot(active);
+    if (todo == 0ull) {
+        return 0;
+    }
+    const int leader = __ffsll((long long)todo) - 1;
+    const int leader_bin = __builtin_amdgcn_readlane(bin, leader);
+    const bool with_leader = active && bin == leader_bin;
+    const unsigned long long same = __ballot(with_leader);
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) {
+        base = atomicAdd(&bins[leader_bin], __popcll(same));
+    }
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (with_leader) {
+        slot = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+    } else if (active) {
+        slot = atomicAdd(&bins[bin], 1);
+    }
+    return slot;
+}
+
+constexpr int kOrderLdsBytes = (256 + 256 + 4) * 4;
+
+__device__ __forceinline__ void klt_order_block(const uint32_t *iters, int32_t *order, int n, int *lds) {
+    int *bin_count = lds, *bin_start = lds + 256, *flat = lds + 512;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    for (int k = tid; k < 256; k += nt) {
+        bin_count[k] = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += nt) {
+        const int i = base + tid;
+        const bool active = i < n;
+        const int bin = active ? 255 - (int)min(iters[i], 255u) : 0;
+        (void)wave_bin_claim(bin_count, bin, active);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // exclusive scan of 256 bins by one wave: four bins per lane; and the no-tail test
+        const int l = tid;
+        const int c0 = bin_count[4 * l], c1 = bin_count[4 * l + 1], c2 = bin_count[4 * l + 2], c3 = bin_count[4 * l + 3];
+        int run = c0 + c1 + c2 + c3;
+        // bin k holds count 255 - k: weighted sum and largest count over the tracked features (count > 0: bins 0..254)
+        long long weighted = (long long)c0 * (255 - 4 * l) + (long long)c1 * (254 - 4 * l) + (long long)c2 * (253 - 4 * l) + (long long)c3 * (252 - 4 * l);
+        int tracked = run - (l == 63 ? c3 : 0);
+        int largest = c0 ? 255 - 4 * l : (c1 ? 254 - 4 * l : (c2 ? 253 - 4 * l : (c3 ? 252 - 4 * l : 0)));
+        for (int off = 32; off >= 1; off >>= 1) {
+            weighted += __shfl_xor(weighted, off);
+            tracked += __shfl_xor(tracked, off);
+            largest = max(largest, __shfl_xor(largest, off));
+        }
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(run, off);
+            if (l >= off) {
+                run += up;
+            }
+        }
+        const int before = run - (c0 + c1 + c2 + c3);
+        bin_start[4 * l] = before;
+        bin_start[4 * l + 1] = before + c0;
+        bin_start[4 * l + 2] = before + c0 + c1;
+        bin_start[4 * l + 3] = before + c0 + c1 + c2;
+        if (l == 0) {
+            *flat = (tracked == 0 || 2ll * largest * tracked <= 3ll * weighted) ? 1 : 0;  // largest <= 1.5 x mean
+        }
+    }
+    __syncthreads();
+    if (*flat) {
+        for (int i = tid; i < n; i += nt) {
+            order[i] = i;
+        }
+        return;
+    }
+    for (int base = 0; base < n; base += nt) {
+        const int i = base + tid;
+        const bool active = i < n;
+        const int bin = active ? 255 - (int)min(iters[i], 255u) : 0;
+        const int slot = wave_bin_claim(bin_start, bin, active);
+        if (active) {
+            order[slot] = i;
+        }
+    }
+}
+
 }  // namespace ftk

@@ -1513,8 +1513,18 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     b.wave = SOLO ? 0 : b.tid >> 6;
     b.nwaves = SOLO ? 1 : b.nt >> 6;
     // SOLO: p.features_per_group one-wave features share a workgroup without ever meeting (own LDS carve, no barrier)
-    // launch slot -> feature: in list order, or through the longest-first permutation of the previous call's iteration counts
-    const uint32_t slot_id = SOLO ? blockIdx.x * (uint32_t)p.features_per_group + (threadIdx.x >> 6) : blockIdx.x;
+    // block 0 of a launch that carries the previous call's iteration counts sorts them into a later call's launch order
+    // (klt_common.h) beside the feature workgroups; the feature blocks follow it
+    uint32_t block = blockIdx.x;
+    if (p.sort_iters) {
+        if (block == 0) {
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw));
+            return;
+        }
+        block -= 1;
+    }
+    // launch slot -> feature: in list order, or through the longest-first permutation of an earlier call's iteration counts
+    const uint32_t slot_id = SOLO ? block * (uint32_t)p.features_per_group + (threadIdx.x >> 6) : block;
     if (slot_id >= (uint32_t)p.n) {
         return;
     }
@@ -1667,6 +1677,10 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
 template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
     auto kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true> : klt_track_kernel<MODEL, METHOD, false>;
+    const unsigned sort_block = p.sort_iters ? 1u : 0u;  // one more workgroup: the sort of a later call's launch order
+    if (sort_block && lds_bytes < (size_t)kOrderLdsBytes) {
+        lds_bytes = kOrderLdsBytes;
+    }
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
@@ -1675,9 +1689,9 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
     }
     if (p.waves_per_feature == 1) {
         const int group = p.features_per_group < 1 ? 1 : p.features_per_group;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)((p.n + group - 1) / group)), dim3(kWave * group), lds_bytes, stream, p);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((p.n + group - 1) / group) + sort_block), dim3(kWave * group), lds_bytes, stream, p);
     } else {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n), dim3(kWave * p.waves_per_feature), lds_bytes, stream, p);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.n + sort_block), dim3(kWave * p.waves_per_feature), lds_bytes, stream, p);
     }
     return hipGetLastError();
 }

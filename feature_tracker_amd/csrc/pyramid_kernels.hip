@@ -6,7 +6,6 @@
 //    output pixels from two 8-byte row segments, so a wave reads 2 x 512 contiguous bytes.
 //  * extract_patch: OpticalFlow::ExtractExtendPatchInReferenceImage (optical_flow.cpp:49-102),
 //    exposed because the reference makes it a public method; one wave per call.
-#include <stdlib.h>
 #include "ftk_device.h"
 
 #include <limits.h>
@@ -129,146 +128,6 @@ __global__ void __launch_bounds__(kBlock) unpack_klt_shards_kernel(const uint8_t
 }
 
 
-// Launch order of the next tracker call: feature indices by iteration count of the previous call, longest first — a counting
-// sort over min(count, 255) in ONE workgroup (wave_bin_claim keeps equal keys from serialising on one LDS address).  The workgroup walks the list in index
-// order, so inside a bin the features keep list order at 1 024-feature granularity (neighbours in the list are usually
-// neighbours in the image).  When the counts have no tail — the largest is within 1.5 x the mean of the tracked features —
-// the order would buy nothing and the identity is written instead.  Any permutation yields the same results; only the
-// schedule differs.
-constexpr int kOrderBlock = 1024;
-
-// A slot in its bin for every active lane.  One round of "the lowest active lane's bin: ONE LDS atomic for all the lanes that
-// share it" — iteration counts cluster, and a call whose features all took 5 iterations would otherwise serialise thousands
-// of atomics on one address — then one atomic per remaining lane (counts spread over many bins: little contention).
-// v_readlane (the leader is wave-uniform), not a shuffle: the round is two ballots, one atomic and two scalar reads.
-__device__ __forceinline__ int wave_bin_claim(int *bins, int bin, bool active) {
-    int slot = 0;
-    const unsigned long long todo = __ballot(active);
-    if (todo == 0ull) {
-        return 0;
-    }
-    const int leader = __ffsll((long long)todo) - 1;
-    const int leader_bin = __builtin_amdgcn_readlane(bin, leader);
-    const bool with_leader = active && bin == leader_bin;
-    const unsigned long long same = __ballot(with_leader);
-    int base = 0;
-    if ((int)(threadIdx.x & 63) == leader) {
-        base = atomicAdd(&bins[leader_bin], __popcll(same));
-    }
-    base = __builtin_amdgcn_readlane(base, leader);
-    if (with_leader) {
-        slot = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-    } else if (active) {
-        slot = atomicAdd(&bins[bin], 1);
-    }
-    return slot;
-}
-
-constexpr int kOrderPerThread = 32;  // features per thread: the kernel orders up to 32 768 features
-__global__ void __launch_bounds__(kOrderBlock) klt_order_kernel(const uint32_t *iters, int32_t *order, int n, int *flat_out, int *skip_calls) {
-    __shared__ int bin_count[256];
-    __shared__ int bin_start[256];
-    __shared__ int flat;
-    // after a no-tail verdict the identity stays in order[] and the next calls' launches of this kernel return at once
-    // (the host cannot know the verdict without synchronising; when it does see it, it stops launching for a while)
-    __shared__ int skipping;
-    if (threadIdx.x == 0) {
-        const int left = *skip_calls;
-        skipping = left;
-        if (left > 0) {
-            *skip_calls = left - 1;
-        }
-    }
-    __syncthreads();
-    if (skipping > 0) {
-        return;
-    }
-    // every count this thread owns (features t, t + 1024, ...) is fetched up front: the loads overlap instead of paying one
-    // memory latency per 1 024 features, twice
-    int bins[kOrderPerThread];
-#pragma unroll
-    for (int k = 0; k < kOrderPerThread; ++k) {
-        const int i = (int)threadIdx.x + k * kOrderBlock;
-        bins[k] = i < n ? 255 - (int)min(iters[i], 255u) : -1;
-    }
-    for (int k = (int)threadIdx.x; k < 256; k += kOrderBlock) {
-        bin_count[k] = 0;
-    }
-    __syncthreads();
-    // counting pass: nothing is read back, so the atomics are fire-and-forget (no round trip per 1 024 features); lanes that
-    // share the lowest active lane's bin still go in as one addition
-#pragma unroll
-    for (int k = 0; k < kOrderPerThread; ++k) {
-        if (k * kOrderBlock < n) {  // block-uniform
-            const bool active = bins[k] >= 0;
-            const unsigned long long todo = __ballot(active);
-            if (todo != 0ull) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int leader_bin = __builtin_amdgcn_readlane(bins[k], leader);
-                const bool with_leader = active && bins[k] == leader_bin;
-                const unsigned long long same = __ballot(with_leader);
-                if ((int)(threadIdx.x & 63) == leader) {
-                    atomicAdd(&bin_count[leader_bin], __popcll(same));
-                } else if (active && !with_leader) {
-                    atomicAdd(&bin_count[bins[k]], 1);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        // exclusive scan of 256 bins by one wave: four bins per lane; and the no-tail test
-        const int l = (int)threadIdx.x;
-        const int c0 = bin_count[4 * l], c1 = bin_count[4 * l + 1], c2 = bin_count[4 * l + 2], c3 = bin_count[4 * l + 3];
-        int run = c0 + c1 + c2 + c3;
-        // bin k holds count 255 - k: weighted sum and largest count over the tracked features (count > 0: bins 0..254)
-        long long weighted = (long long)c0 * (255 - 4 * l) + (long long)c1 * (254 - 4 * l) + (long long)c2 * (253 - 4 * l) + (long long)c3 * (252 - 4 * l);
-        int tracked = run - (l == 63 ? c3 : 0);
-        int largest = c0 ? 255 - 4 * l : (c1 ? 254 - 4 * l : (c2 ? 253 - 4 * l : (c3 ? 252 - 4 * l : 0)));
-        for (int off = 32; off >= 1; off >>= 1) {
-            weighted += __shfl_xor(weighted, off);
-            tracked += __shfl_xor(tracked, off);
-            largest = max(largest, __shfl_xor(largest, off));
-        }
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(run, off);
-            if (l >= off) {
-                run += up;
-            }
-        }
-        const int before = run - (c0 + c1 + c2 + c3);
-        bin_start[4 * l] = before;
-        bin_start[4 * l + 1] = before + c0;
-        bin_start[4 * l + 2] = before + c0 + c1;
-        bin_start[4 * l + 3] = before + c0 + c1 + c2;
-        if (l == 0) {
-            flat = (tracked == 0 || 2ll * largest * tracked <= 3ll * weighted) ? 1 : 0;  // largest <= 1.5 x mean
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && flat) {
-        *skip_calls = 15;
-        if (flat_out) {
-            *flat_out = 1;  // host-mapped: the host reads it, unsynchronised, before a later call (a hint: stale is fine)
-        }
-    }
-    if (flat) {
-        for (int i = (int)threadIdx.x; i < n; i += kOrderBlock) {
-            order[i] = i;
-        }
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < kOrderPerThread; ++k) {
-        if (k * kOrderBlock < n) {  // block-uniform
-            const int slot = wave_bin_claim(bin_start, max(bins[k], 0), bins[k] >= 0);
-            if (bins[k] >= 0) {
-                order[slot] = (int)threadIdx.x + k * kOrderBlock;
-            }
-        }
-    }
-}
-
 }  // namespace
 
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream) {
@@ -285,14 +144,6 @@ hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream) {
     hipLaunchKernelGGL(extract_patch_kernel, dim3(1), dim3(64), 0, stream, ref, u, v, ex_rows, ex_cols, d_patch, d_valid, d_count);
-    return hipGetLastError();
-}
-
-hipError_t klt_order_launch(const uint32_t *iters, int32_t *order, int32_t n, int *flat_out, int *skip_calls, hipStream_t stream) {
-    if (n <= 0 || n > kKltOrderMaxFeatures) {
-        return hipErrorInvalidValue;
-    }
-    hipLaunchKernelGGL(klt_order_kernel, dim3(1), dim3(kOrderBlock), 0, stream, iters, order, n, flat_out, skip_calls);
     return hipGetLastError();
 }
 

@@ -140,9 +140,10 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
  * Same computation on device-resident buffers, asynchronous on the context's stream.
  * d_cur_uv_out / d_status_out may alias the *_in buffers (in-place, as the reference) or be
  * separate (repeatable launches for benchmarking).  d_iters may be NULL.
- * Launch order (performance only, results are independent of it): calls of 4 096 .. 32 768 features keep every feature's
- * iteration count in the context, and the next call with the same n launches the features longest-first by those counts
- * (frame-to-frame coherence of a tracker's feature list; environment FTK_KLT_SCHED=0 keeps list order).
+ * Launch order (performance only, results are independent of it): calls of >= 4 096 features keep every feature's
+ * iteration count in the context, and from the third consecutive call with the same n on the features are launched
+ * longest-first by the counts of two calls before (sorted by one extra workgroup of the launch in between; frame-to-frame
+ * coherence of a tracker's feature list; environment FTK_KLT_SCHED=0 keeps list order).
  */
 int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur,
                          const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out, const uint8_t *d_status_in,

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 w = sys.argv[1] if len(sys.argv) > 1 else "config4"
 dump = os.path.join(tempfile.gettempdir(), "sched_dump.bin")
 env = dict(os.environ, FTK_KLT_SCHED_DUMP=dump)
-subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, check=True,
+subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], env=env, check=True,
                stdout=subprocess.DEVNULL)
 d = np.fromfile(dump, dtype=np.int32)
 n = d.size // 2

@@ -7,7 +7,7 @@ for l in sys.stdin:
     try: d = json.loads(l)
     except Exception: continue
     print('    ms_per_step %.4f  bit_identical %s' % (d['ms_per_step'], d['parity']['bit_identical']))"; }
-for g in 1 2 3 4; do run config4 FTK_KLT_GROUP=$g; done
+for wv in 1 2 3 4; do run config4 FTK_KLT_WAVES=$wv; done
+for g in 2 4; do run config4 FTK_KLT_GROUP=$g; done
 run config4 FTK_LSSD_CHUNKED=0
 for wv in 1 2 3 4; do run config3 FTK_KLT_WAVES=$wv; done
-for g in 2 4; do run config3 FTK_KLT_WAVES=1 FTK_KLT_GROUP=$g; done

@@ -369,11 +369,11 @@ def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
 
 @pytest.mark.parametrize("model,method", [("affine", "inverse"), ("lssd", "fast"), ("basic", "inverse")])
 def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model, method, monkeypatch):
-    """From the second call with the same feature count on, the device entry launches the features longest-first by the
-    previous call's iteration counts (ftk_api.cpp, klt_order_kernel; calls of >= 4096 features).  Every call must return
-    what the first one did — the oracle's answer — also when the history comes from DIFFERENT inputs (a stale predictor),
-    when some features are passed through (incoming status, kMaxTrackPointsNumber) and under every experiment mode of the
-    order kernel."""
+    """From the third call with the same feature count on, the device entry launches the features longest-first by an earlier
+    call's iteration counts (ftk_api.cpp; the sort runs in an extra workgroup of the launch in between, klt_common.h
+    klt_order_block; calls of >= 4096 features).  Every call must return what the first one did — the oracle's answer — also
+    when the history comes from DIFFERENT inputs (a stale predictor) and when some features are passed through (incoming
+    status, kMaxTrackPointsNumber)."""
     import torch
     from feature_tracker_amd import device as D
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
@@ -399,11 +399,12 @@ def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model,
             return d_out.cpu().numpy(), d_so.cpu().numpy()
 
         first = run(uv)                      # list order (no history)
-        again = [run(uv) for _ in range(2)]  # ordered by the counts of the same inputs
+        again = [run(uv) for _ in range(3)]  # the third and fourth call go through the permutation
         run(other)                           # history now comes from other inputs
+        run(other)
         stale = run(uv)
     ok, c, s, _ = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, uv, status, method=method, half=5, max_points=cap)
     assert (s == 1).sum() > n // 2
-    for name, (g_uv, g_st) in (("first", first), ("second", again[0]), ("third", again[1]), ("stale history", stale)):
+    for name, (g_uv, g_st) in (("first", first), ("second", again[0]), ("third", again[1]), ("fourth", again[2]), ("stale history", stale)):
         assert np.array_equal(g_st, s), name
         assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32)), name
