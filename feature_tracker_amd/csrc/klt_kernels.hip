@@ -1498,11 +1498,12 @@ constexpr int kMaxWaves = 4;
 #define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU)))
 
 // The direct affine variant (6x6 LDLT + 24 chains + five current-image taps in registers) does not fit 128 VGPRs
-// without spilling; it runs at 3 waves per SIMD instead.
+// without spilling; it runs at 3 waves per SIMD instead — and so does the multi-wave inverse one (128 VGPRs + 16 B of scratch at
+// 4: config 3 223 -> 219 us, 2 000 features 165 -> 160 us at 3).
 // SOLO: the one-wave-per-feature instantiation (workgroup = one wavefront): compile-time, so that no barrier and no cross-wave
 // exchange is left in it.
 template <int MODEL, int METHOD, bool SOLO>
-__global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && METHOD == FTK_METHOD_DIRECT) ? 3 : FTK_WAVES_PER_EU)))
+__global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && (METHOD == FTK_METHOD_DIRECT || (METHOD == FTK_METHOD_INVERSE && !SOLO))) ? 3 : FTK_WAVES_PER_EU)))
 __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
