@@ -9,7 +9,7 @@ for l in sys.stdin:
     except Exception: continue
     print('   ', d['case'], 'gpu_kernel_ms %.4f' % d['gpu_kernel_ms'], 'exact', d['indices_bit_exact_on_sample'])"; }
 run FTK_MATCH_KERNEL=mfma
-run FTK_MATCH_KERNEL=mfma FTK_MATCH_FUSED=0
+
 run FTK_MATCH_KERNEL=scalar
 [ "$1" = quick ] && exit 0
 for wgs in 1024 1536 3072 4096; do run FTK_MATCH_KERNEL=mfma FTK_MATCH_WGS=$wgs; done
