@@ -420,7 +420,21 @@ __device__ __forceinline__ void ldlt_solve(float (&m)[N][N], const float (&b)[N]
 // same operations in the same order — Eigen's LDLT is left-looking, so the pivot search of step k sees ORIGINAL diagonal
 // entries (moved by the swaps) and the two transpositions can be decided up front; only the lower triangle is ever read.
 // ~40 % of the instructions of the generic unrolled form (no 3x3 array with predicated swaps of every element).
-__device__ __forceinline__ void ldlt3_solve(float a00, float a10, float a20, float a11, float a21, float a22, const float (&b)[3], float (&x)[3]) {
+// Independent divisions of WAVE-UNIFORM values side by side: lane k divides numerator k (the lanes beyond the last repeat it),
+// the quotients come back through v_readlane.  One correctly rounded division sequence (~10 instructions) instead of one per
+// quotient, and each quotient is the same instruction sequence on the same operands as before — bit-identical.
+__device__ __forceinline__ float uniform_lane(float v, int lane_index) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_index)); }
+__device__ __forceinline__ void lane_div2(int lane, float n0, float n1, float d, float &q0, float &q1) {
+    const float q = (lane == 0 ? n0 : n1) / d;
+    q0 = uniform_lane(q, 0);
+    q1 = uniform_lane(q, 1);
+}
+
+// kLanes: the inputs are wave-uniform and all 64 lanes are executing (the one-wave trackers): independent divisions run on
+// separate lanes (lane_div2 and its three-way form below); otherwise every lane divides for itself as before.
+template <bool kLanes = false>
+__device__ __forceinline__ void ldlt3_solve(float a00, float a10, float a20, float a11, float a21, float a22, const float (&b)[3], float (&x)[3],
+                                            int lane = 0) {
     // step 0: pivot = first maximum of |a00|, |a11|, |a22|
     float m00 = a00, m10 = a10, m20 = a20, m11 = a11, m21 = a21, m22 = a22;
     const float d0 = fabsf(m00), d1 = fabsf(m11), d2 = fabsf(m22);
@@ -444,8 +458,12 @@ __device__ __forceinline__ void ldlt3_solve(float a00, float a10, float a20, flo
     const bool degenerate = !valid0;  // a zero first pivot: Eigen stops, the transpositions become the identity
     int p1 = 1;
     if (!degenerate) {
-        m10 /= m00;
-        m20 /= m00;
+        if (kLanes) {
+            lane_div2(lane, m10, m20, m00, m10, m20);
+        } else {
+            m10 /= m00;
+            m20 /= m00;
+        }
         // step 1: pivot among the remaining diagonals
         if (fabsf(m22) > fabsf(m11)) {
             p1 = 2;
@@ -490,9 +508,18 @@ __device__ __forceinline__ void ldlt3_solve(float a00, float a10, float a20, flo
         y2 -= s;
     }
     // D^+
-    y0 = (fabsf(m00) > 1.17549435e-38f) ? y0 / m00 : 0.0f;
-    y1 = (fabsf(m11) > 1.17549435e-38f) ? y1 / m11 : 0.0f;
-    y2 = (fabsf(m22) > 1.17549435e-38f) ? y2 / m22 : 0.0f;
+    if (kLanes) {
+        const float num = lane == 0 ? y0 : (lane == 1 ? y1 : y2);
+        const float den = lane == 0 ? m00 : (lane == 1 ? m11 : m22);
+        const float q = (fabsf(den) > 1.17549435e-38f) ? num / den : 0.0f;
+        y0 = uniform_lane(q, 0);
+        y1 = uniform_lane(q, 1);
+        y2 = uniform_lane(q, 2);
+    } else {
+        y0 = (fabsf(m00) > 1.17549435e-38f) ? y0 / m00 : 0.0f;
+        y1 = (fabsf(m11) > 1.17549435e-38f) ? y1 / m11 : 0.0f;
+        y2 = (fabsf(m22) > 1.17549435e-38f) ? y2 / m22 : 0.0f;
+    }
     // L^-T
     y1 -= m21 * y2;
     {

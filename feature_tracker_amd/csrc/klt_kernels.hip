@@ -1014,7 +1014,9 @@ __device__ __forceinline__ void se2_apply(const LssdState &s, float x, float y, 
 }
 
 // delta_R << 1, -theta, theta, 1; R *= delta_R; R /= R.col(0).norm(); t += v.tail<2>()
-__device__ __forceinline__ void se2_update(LssdState &s, const float (&v)[3]) {
+// kLanes (one-wave trackers: wave-uniform state, all lanes executing): the four divisions by the norm run on four lanes.
+template <bool kLanes = false>
+__device__ __forceinline__ void se2_update(LssdState &s, const float (&v)[3], int lane = 0) {
     const float theta = v[0];
     const float d00 = 1.0f, d01 = -theta, d10 = theta, d11 = 1.0f;
     const float n00 = s.r00 * d00 + s.r01 * d10;
@@ -1022,10 +1024,18 @@ __device__ __forceinline__ void se2_update(LssdState &s, const float (&v)[3]) {
     const float n10 = s.r10 * d00 + s.r11 * d10;
     const float n11 = s.r10 * d01 + s.r11 * d11;
     const float norm = sqrtf(n00 * n00 + n10 * n10);
-    s.r00 = n00 / norm;
-    s.r01 = n01 / norm;
-    s.r10 = n10 / norm;
-    s.r11 = n11 / norm;
+    if (kLanes) {
+        const float q = (lane == 0 ? n00 : (lane == 1 ? n01 : (lane == 2 ? n10 : n11))) / norm;
+        s.r00 = uniform_lane(q, 0);
+        s.r01 = uniform_lane(q, 1);
+        s.r10 = uniform_lane(q, 2);
+        s.r11 = uniform_lane(q, 3);
+    } else {
+        s.r00 = n00 / norm;
+        s.r01 = n01 / norm;
+        s.r10 = n10 / norm;
+        s.r11 = n11 / norm;
+    }
     s.t0 += v[1];
     s.t1 += v[2];
 }
@@ -1046,11 +1056,11 @@ __device__ __forceinline__ void lssd_terms(const KltParams &p, float *terms, int
 }
 
 // Wave 0: solves the 3x3 system from the nine chain sums and publishes v in sums[16..18].
-__device__ __forceinline__ void lssd_solve(float *sums) {
+__device__ __forceinline__ void lssd_solve(float *sums, int lane) {
     const float h00 = sums[0], h01 = sums[1], h02 = sums[2], h11 = sums[3], h12 = sums[4], h22 = sums[5];
     const float bb[3] = {sums[6], sums[7], sums[8]};
     float sol[3];
-    ldlt3_solve(h00, h01, h02, h11, h12, h22, bb, sol);
+    ldlt3_solve<true>(h00, h01, h02, h11, h12, h22, bb, sol, lane);  // the whole of wave 0 is here, on the same sums
     sums[16] = sol[0];
     sums[17] = sol[1];
     sums[18] = sol[2];
@@ -1058,7 +1068,7 @@ __device__ __forceinline__ void lssd_solve(float *sums) {
 
 // Every lane: picks up the published solution and applies the SE(2) update.
 // Returns false (after setting status) on NaN.
-__device__ __forceinline__ bool lssd_solve_and_update(const float *sums, LssdState &s, float (&v)[3], uint8_t &status) {
+__device__ __forceinline__ bool lssd_solve_and_update(const float *sums, LssdState &s, float (&v)[3], uint8_t &status, int lane) {
     v[0] = sums[16];
     v[1] = sums[17];
     v[2] = sums[18];
@@ -1066,7 +1076,7 @@ __device__ __forceinline__ bool lssd_solve_and_update(const float *sums, LssdSta
         status = FTK_NUMERIC_ERROR;
         return false;
     }
-    se2_update(s, v);
+    se2_update<true>(s, v, lane);  // every wave in full, on the same published solution
     return true;
 }
 
@@ -1141,9 +1151,9 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
         if (n_valid == 0) {
             break;
         }
-        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
+        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums, b.lane); });
         float v[3];
-        const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+        const bool solved = lssd_solve_and_update(c.sums, s, v, status, b.lane);
         blk_sync(b);  // sums[] is rewritten by the first chain of the next iteration
         if (!solved) {
             break;
@@ -1252,9 +1262,9 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
             if ((both >> 16) == 0 || (both & 0xFFFFu) == 0) {
                 break;  // lssd_klt_fast.cpp:60-63 / :80-83
             }
-            chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
+            chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums, b.lane); });
             float v[3];
-            const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+            const bool solved = lssd_solve_and_update(c.sums, s, v, status, b.lane);
             blk_sync(b);
             if (!solved) {
                 break;
@@ -1330,9 +1340,9 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         if (n_valid == 0) {
             break;
         }
-        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums); });
+        chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums, b.lane); });
         float v[3];
-        const bool solved = lssd_solve_and_update(c.sums, s, v, status);
+        const bool solved = lssd_solve_and_update(c.sums, s, v, status, b.lane);
         blk_sync(b);  // sums[] may be rewritten by the luminance chain of the next iteration
         if (!solved) {
             break;
@@ -1457,12 +1467,12 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7)),
                              __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8))};
         float v[3];
-        ldlt3_solve(h00, h01, h02, h11, h12, h22, bb, v);
+        ldlt3_solve<true>(h00, h01, h02, h11, h12, h22, bb, v, b.lane);
         if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
             status = FTK_NUMERIC_ERROR;
             break;
         }
-        se2_update(s, v);
+        se2_update<true>(s, v, b.lane);
         if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
             break;
         }
