@@ -810,9 +810,12 @@ __device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow,
 // Top-left corner of the (2h+4)^2 footprint of a patch centred at (u, v): bilinear bases of the
 // patch pixels and of their +-1 neighbours lie in [floor - h - 1, floor + h + 1], plus one for the
 // +1 bilinear neighbour.
+// (u, v) are the feature's coordinates: the same in every lane of the wave (a wave never serves two features), so the corner is
+// handed on as a SCALAR — everything integer that follows from it (window tests, clamps, restaging decisions, address bases)
+// then runs on the scalar unit instead of taking vector issue slots.
 __device__ __forceinline__ void footprint_origin(const KltParams &p, float u, float v, int &r_lo, int &c_lo) {
-    r_lo = wadd(f2i(floorf(v)), -(p.half_rows + 1));
-    c_lo = wadd(f2i(floorf(u)), -(p.half_cols + 1));
+    r_lo = __builtin_amdgcn_readfirstlane(wadd(f2i(floorf(v)), -(p.half_rows + 1)));
+    c_lo = __builtin_amdgcn_readfirstlane(wadd(f2i(floorf(u)), -(p.half_cols + 1)));
 }
 
 // One pixel-pair element of a window: (img[clamp(r)][clamp(c)], img[clamp(r)][clamp(c + 1)]).

@@ -1214,8 +1214,8 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         float centre_u, centre_v;
         se2_apply(s, ref_u, ref_v, centre_u, centre_v);
         ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
-        const int min_row = wadd(f2i(centre_v), -p.patch_rows);
-        const int min_col = wadd(f2i(centre_u), -p.patch_cols);
+        const int min_row = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_v)), -p.patch_rows);  // wave-uniform: scalar from here on
+        const int min_col = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_u)), -p.patch_cols);
         const int max_row = wadd(min_row, p.patch_rows * 2);
         const int max_col = wadd(min_col, p.patch_cols * 2);
         const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
@@ -1392,8 +1392,8 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         float centre_u, centre_v;
         se2_apply(s, ref_u, ref_v, centre_u, centre_v);
         ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
-        const int min_row = wadd(f2i(centre_v), -p.patch_rows);
-        const int min_col = wadd(f2i(centre_u), -p.patch_cols);
+        const int min_row = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_v)), -p.patch_rows);  // wave-uniform: scalar from here on
+        const int min_col = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_u)), -p.patch_cols);
         const int max_row = wadd(min_row, p.patch_rows * 2);
         const int max_col = wadd(min_col, p.patch_cols * 2);
         const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
