@@ -147,6 +147,10 @@ def matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, c
         "cpu_ns_per_pair": cpu_s / (rows * n_cur) * 1e9 if not nearby else None, "cpu_full_estimate_s": cpu_s * n_ref / rows,
         "speedup": (cpu_s * n_ref / rows) / (gpu_ms * 1e-3), "indices_bit_exact_on_sample": bool(np.array_equal(gpu_idx[:rows], cidx)),
         "matched": int((gpu_idx >= 0).sum()),
+        # 256-bit descriptors are compared on the matrix cores: one int8 multiply-add per bit pair; the peak is the
+        # dense int8 rate of MI355X_MICROARCH.md (2 x BF16 per clock)
+        "roofline": {"bound": "mfma", "achieved": 2.0 * pairs * 256 / (gpu_ms * 1e-3) / 1e12, "peak": 5000.0, "unit": "TOP/s (int8, per call incl. the epilogue launch)",
+                     "frac": 2.0 * pairs * 256 / (gpu_ms * 1e-3) / 1e12 / 5000.0, "traffic": None},
     }
 
 
