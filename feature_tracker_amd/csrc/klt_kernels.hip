@@ -1499,6 +1499,10 @@ struct ChainCount<FTK_MODEL_LSSD> {
 };
 
 constexpr int kMaxWaves = 4;
+#ifndef FTK_LONG_SLOTS
+#define FTK_LONG_SLOTS 128
+#endif
+constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest first) that keep the top issue priority
 
 // Register cap: the compiler is asked to fit FTK_WAVES_PER_EU waves per SIMD so that enough feature
 // workgroups are co-resident per CU (the kernel is issue / latency bound, not register bound).
@@ -1602,7 +1606,9 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
         const DevImage cur = p.cur[level];
         blk_sync(b);  // the previous level's readers of the LDS windows / arrays are done
         const Blk b = opaque_blk(b0);  // per-thread index math stays inside the level (see opaque())
-        set_level_priority(level);
+        // the features the launch order put first are the ones expected to run longest — the launch ends when they do — so
+        // they keep the top issue priority on their SIMDs at every level
+        set_level_priority((p.order && slot_id < (uint32_t)kLongFeatureSlots) ? 3 : level);
         if (MODEL == FTK_MODEL_BASIC) {
             if (METHOD == FTK_METHOD_FAST) {
                 basic_level_fast(b, p, ref, cur, ref_u, ref_v, bs, status, iters, c);
