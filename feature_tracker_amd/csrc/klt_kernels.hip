@@ -1366,8 +1366,10 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
     Win rw, cw;
     float level_centre_u, level_centre_v;
     se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
+    FTK_STAMP_BEGIN(b);
     stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
     bool cw_staged = true;
+    FTK_STAMP_END(b, 0);  // diagnostic build: level windows
     const uint32_t ref_valid_num = extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c);
     if (ref_valid_num == 0) {
         status = FTK_OUTSIDE;
@@ -1382,6 +1384,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         dys[pxi] = dy;
     }
     blk_sync(b);
+    FTK_STAMP_END(b, 1);  // extended patch + gradients
 
     status = FTK_LARGE_RESIDUAL;
     float last_squared_step = INFINITY;
@@ -1389,6 +1392,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
     const int n_chunks = (p.P + kChunkPixels - 1) / kChunkPixels;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        FTK_STAMP_BEGIN(b);
         float centre_u, centre_v;
         se2_apply(s, ref_u, ref_v, centre_u, centre_v);
         ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
@@ -1456,6 +1460,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             }
             blk_sync(b);
         }
+        FTK_STAMP_END(b, 3);  // window check + the chunks (sampling, products, chains)
         if (cur_valid_num == 0 || n_valid == 0) {
             break;  // lssd_klt_fast.cpp:60-63 / :80-83
         }
@@ -1473,6 +1478,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             break;
         }
         se2_update<true>(s, v, b.lane);
+        FTK_STAMP_END(b, 5);  // solve + update
         if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
             break;
         }
