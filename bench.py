@@ -131,18 +131,63 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         opt = F.OpticalFlowOptions()
         opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = cfg["method"], half, half, n
         klt = D.DeviceKlt(cfg["model"], opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
-        sharded = FD.ShardedKlt(klt, n, dev, world, rank)
+        slots = [FD.ShardedKlt(klt, n, dev, world, rank) for _ in range(2)]  # two alternating result slots
+        sharded = slots[0]
         d_ref = torch.from_numpy(uv).to(dev)
         d_in = d_ref.clone()
         d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
-        for _ in range(max(1, args.warmup)):
-            sharded.launch(d_ref, d_in, d_st)
+        for k in range(max(2, args.warmup)):
+            slots[k & 1].launch_local(d_ref, d_in, d_st)
+            slots[k & 1].gather(force_collective=use_dist)
+        stream.synchronize()
+        # As in the weak-scaling path: with a collective per step the K steps are captured ONCE into a HIP graph in which the
+        # gather of step k runs on a side stream beside the kernel of step k + 1 (the kernel of step k + 2 waits for the gather
+        # of step k, which reads that slot's packed shard); capture success is all-reduced so that every rank takes the same path.
+        graph = None
+        if use_dist and args.steps >= 2 and os.environ.get("FTK_BENCH_NO_GRAPH") != "1":
+            ok = 1
+            try:
+                side = torch.cuda.Stream(device=dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    gather_done = {}
+                    for k in range(args.steps):
+                        slot = slots[k & 1]
+                        if k >= 2:
+                            stream.wait_event(gather_done[k - 2])
+                        slot.launch_local(d_ref, d_in, d_st)
+                        kernel_done = torch.cuda.Event()
+                        kernel_done.record(stream)
+                        side.wait_event(kernel_done)
+                        with torch.cuda.stream(side):
+                            slot.gather(force_collective=True)
+                            gather_done[k] = torch.cuda.Event()
+                            gather_done[k].record(side)
+                    stream.wait_stream(side)
+                graph = g
+            except Exception as exc:  # capture is not available for this collective / runtime: plain loop
+                ok = 0
+                graph = None
+                if rank == 0:
+                    print(f"bench.py: graph capture unavailable ({type(exc).__name__}: {exc}); using the per-step loop", file=sys.stderr)
+            torch.cuda.synchronize()
+            agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 0:
+                graph = None
+            if graph is not None:
+                graph.replay()  # one untimed replay: first-use initialisation of the instantiated graph
+                torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sharded.launch(d_ref, d_in, d_st)
+        if graph is not None:
+            graph.replay()
+        else:
+            for k in range(args.steps):
+                slots[k & 1].launch_local(d_ref, d_in, d_st)
+                slots[k & 1].gather(force_collective=use_dist)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -166,7 +211,9 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg['model']} KLT {cfg['method']}, {n} features in total sharded x{world}, {w}x{h}, {levels}-level pyramid, "
                                    f"{2 * half + 1}x{2 * half + 1} patch", "tracked_fraction": tracked,
-                       "gathered_equals_unsharded_bitwise": gathered_ok}}), flush=True)
+                       "gathered_equals_unsharded_bitwise": gathered_ok,
+                       "parallelism": (f"features sharded x{world}, pyramids replicated, one RCCL all-gather of packed (uv,status) per step"
+                                       + (", steps captured in one HIP graph (gather k overlaps kernel k+1)" if graph is not None else ""))}}), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -106,8 +106,9 @@ class ShardedKlt:
         self.gathered = torch.empty(packed_bytes(self.cap) * self.world, dtype=torch.uint8, device=device)
         self.uv_view, self.status_view = pack_views(self.packed, self.cap)
 
-    def launch(self, ref_uv, cur_uv_in, status_in, iters=None):
-        """Enqueue the local shard's kernel and the all-gather; returns the gathered byte buffer (asynchronous on GPUs)."""
+    def launch_local(self, ref_uv, cur_uv_in, status_in, iters=None):
+        """Enqueue only the local shard's kernel (its packed shard is complete when the stream reaches this point): for callers
+        that place the all-gather themselves, e.g. on a side stream beside the next launch."""
         m = self.end - self.begin
         if m > 0:
             kw = {}
@@ -115,7 +116,16 @@ class ShardedKlt:
                 kw["max_track_points"] = max(0, min(self.global_cap - self.begin, m))  # this block's share of the global cap
             self.tracker.track(ref_uv[self.begin:self.end], cur_uv_in[self.begin:self.end], status_in[self.begin:self.end],
                                self.uv_view[:m], self.status_view[:m], None if iters is None else iters[self.begin:self.end], **kw)
-        return all_gather_results(self.packed, self.world, group=self.group, force_collective=self.world > 1, out=self.gathered)
+
+    def gather(self, force_collective=None):
+        """The all-gather of the packed shards on the current stream; returns the gathered byte buffer."""
+        force = self.world > 1 if force_collective is None else force_collective
+        return all_gather_results(self.packed, self.world, group=self.group, force_collective=force, out=self.gathered)
+
+    def launch(self, ref_uv, cur_uv_in, status_in, iters=None):
+        """Enqueue the local shard's kernel and the all-gather; returns the gathered byte buffer (asynchronous on GPUs)."""
+        self.launch_local(ref_uv, cur_uv_in, status_in, iters)
+        return self.gather()
 
     def track(self, ref_uv, cur_uv_in, status_in, iters=None):
         """Returns (cur_uv [n, 2], status [n]) for ALL features, in order."""
