@@ -310,7 +310,8 @@ int ftk_hamming_match_sharded_device(ftk_context *ctx, ftk_comm *comm, const uin
  * high bits 0.
  * n_bits == 0 reproduces ComputeDistance's "empty descriptor" answer (kMaxInt32).
  * 256- and 512-bit descriptors (n_words 8 / 16) are compared on the matrix cores (the distances are exact integers out of
- * int8 MFMAs: same indices as the popcount scans that serve the other widths); the device pointers need 4-byte alignment only.
+ * int8 MFMAs: same indices as the popcount scans that serve the other widths).  Device descriptor pointers are read with 16-byte
+ * loads: pass 16-byte-aligned arrays (any hipMalloc'ed buffer, and any row offset into one when n_words is a multiple of 4).
  * pred_uv == NULL selects ForceMatch; otherwise NearbyMatch with the window test
  * |pred.u - cur.u| > max_col_distance || |pred.v - cur.v| > max_row_distance -> skip.
  * index_pairs is in/out (n_ref entries): written only where a candidate beats the threshold,
