@@ -117,7 +117,7 @@ __device__ __forceinline__ void issue_quads(RawQuads<N> &q, const Blk &b, const 
         int idx = tid + k * b.nt;
         idx = idx < total ? idx : 0;
         const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-        const int qq = idx - r * quads;
+        const int qq = idx - imul(r, quads);
         const uint8_t *src = base + (size_t)(unsigned)(r * im.cols + 4 * qq);
         __builtin_memcpy(&q.x[k], src, 4);
         __builtin_memcpy(&q.y[k], src + 4, 4);
@@ -134,13 +134,13 @@ __device__ __forceinline__ void store_quads(const RawQuads<N> &q, const Blk &b, 
         const int idx = tid + k * b.nt;
         if (idx < total) {
             const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-            const int qq = idx - r * quads;
+            const int qq = idx - imul(r, quads);
             const uint32_t x = q.x[k], y = q.y[k];
             const uint32_t p0 = x & 0xFFFFu;
             const uint32_t p1 = (x >> 8) & 0xFFFFu;
             const uint32_t p2 = x >> 16;
             const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
-            *reinterpret_cast<uint2 *>(dst + r * wcols + 4 * qq) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+            *reinterpret_cast<uint2 *>(dst + imul(r, wcols) + 4 * qq) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
         }
     }
 }
@@ -497,8 +497,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             const int total = n_r * n_c;
             const uint32_t m = magic20(n_c);
             for (int idx = opaque(b.tid); idx < total; idx += b.nt) {
-                const int r = (int)(((uint32_t)idx * m) >> 20);
-                const int cc = idx - r * n_c;
+                const int r = (int)(__umul24((uint32_t)idx, m) >> 20);  // idx < 4096 and m <= 2^20: the 24-bit multiplier is exact here
+                const int cc = idx - imul(r, n_c);
                 c.lattice[idx] = node_tap(rw.data, rw.cols, c.rnodes[r], c.cnodes[cc]);
             }
         }

@@ -38,6 +38,9 @@ constexpr int kWave = 64;
 // static_cast<int32_t>(float) as x86-64 cvttss2si does it (out of range / NaN -> INT_MIN)
 __device__ __forceinline__ int f2i(float x) { return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : INT_MIN; }
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+// Product of two SMALL integers (patch / window geometry, pixel and row indices inside them: |x| < 2^23, product < 2^31): the
+// 24-bit multiplier issues at full rate, v_mul_lo_u32 at a quarter of it — and the kernels are bound by vector issue.
+__device__ __forceinline__ int imul(int a, int b) { return __mul24(a, b); }
 __device__ __forceinline__ float floor_from_trunc(float x, int t) {
     const float f = (float)t;
     return (f > x) ? f - 1.0f : f;
@@ -116,8 +119,8 @@ __device__ __forceinline__ void fetch4(const DevImage &im, const Win &w, int r0,
     const int lr = (int)((unsigned)r0 - (unsigned)w.r_lo);
     const int lc = (int)((unsigned)c0 - (unsigned)w.c_lo);
     if ((unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols) {
-        const unsigned a = w.data[lr * w.cols + lc];
-        const unsigned bb = w.data[(lr + 1) * w.cols + lc];
+        const unsigned a = w.data[imul(lr, w.cols) + lc];
+        const unsigned bb = w.data[imul(lr + 1, w.cols) + lc];
         p00 = (float)(a & 0xFFu);
         p01 = (float)(a >> 8);
         p10 = (float)(bb & 0xFFu);
@@ -219,7 +222,7 @@ __device__ __forceinline__ float tap(const Win &w, const Axis &ar, const Axis &a
     const int lc = (int)((unsigned)ac.i0 - (unsigned)w.c_lo);
     const bool in = (unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols;
     hit = hit && in;
-    const int idx = in ? lr * w.cols + lc : 0;
+    const int idx = in ? imul(lr, w.cols) + lc : 0;
     const unsigned a = w.data[idx];
     const unsigned bb = w.data[idx + w.cols];
     const float w_tl = ar.inv * ac.inv;
@@ -800,7 +803,7 @@ constexpr int kChunkRow = kChunkPixels + 4;   // ring row pitch in floats: the c
 
 __device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow, int &pcol) {
     prow = (p.patch_cols == 1) ? pxi : (int)__umulhi((unsigned)pxi, p.magic_pc);
-    pcol = pxi - prow * p.patch_cols;
+    pcol = pxi - imul(prow, p.patch_cols);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -821,7 +824,7 @@ __device__ __forceinline__ void footprint_origin(const KltParams &p, float u, fl
 // One pixel-pair element of a window: (img[clamp(r)][clamp(c)], img[clamp(r)][clamp(c + 1)]).
 __device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols) {
     const int r = (int)__umulhi((unsigned)idx, magic_cols);
-    const int c = idx - r * wcols;
+    const int c = idx - imul(r, wcols);
     const int ir = clampi(wadd(r_lo, r), 0, im.rows - 1);
     const int ic = wadd(c_lo, c);
     const int ic0 = clampi(ic, 0, im.cols - 1);
@@ -867,7 +870,7 @@ __device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &
     const int total = wrows * quads;
     for (int idx = b.tid; idx < total; idx += b.nt) {
         const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-        const int q = idx - r * quads;
+        const int q = idx - imul(r, quads);
         const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
         uint32_t x, y;
         __builtin_memcpy(&x, src, 4);
@@ -876,7 +879,7 @@ __device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &
         const uint32_t p1 = (x >> 8) & 0xFFFFu;
         const uint32_t p2 = x >> 16;
         const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
-        *reinterpret_cast<uint2 *>(dst + r * wcols + 4 * q) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+        *reinterpret_cast<uint2 *>(dst + imul(r, wcols) + 4 * q) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
     }
 }
 
@@ -893,7 +896,7 @@ __device__ __forceinline__ void stage_any(const Blk &b, const DevImage &im, uint
 __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, int c_lo, int idx, int quads, uint32_t magic_quads, int &lds_off,
                                                  int wcols) {
     const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-    const int q = idx - r * quads;
+    const int q = idx - imul(r, quads);
     const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
     uint32_t x, y;
     __builtin_memcpy(&x, src, 4);
@@ -902,7 +905,7 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
     const uint32_t p1 = (x >> 8) & 0xFFFFu;
     const uint32_t p2 = x >> 16;
     const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
-    lds_off = r * wcols + 4 * q;
+    lds_off = imul(r, wcols) + 4 * q;
     return make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
 }
 

@@ -411,7 +411,7 @@ __device__ __forceinline__ uint32_t extract_extended_patch(const Blk &b, const K
         bool valid = false;
         if (e < p.E) {
             const int erow = (int)__umulhi((unsigned)e, p.magic_exc);
-            const int ecol = e - erow * p.ex_cols;
+            const int ecol = e - imul(erow, p.ex_cols);
             const int row = wadd(min_row, erow);
             const int col = wadd(min_col, ecol);
             valid = !(row < 0 || row > ref.rows - 2 || col < 0 || col > ref.cols - 2);
@@ -432,7 +432,7 @@ __device__ __forceinline__ uint32_t extract_extended_patch(const Blk &b, const K
 // Central differences on the extended patch: dx = dy = 0 where a 4-neighbour is invalid
 // (basic_klt_fast.cpp:64-99, affine_klt_fast.cpp:71-138, lssd_klt_fast.cpp:116-143).
 __device__ __forceinline__ bool ex_gradient(const KltParams &p, const float *ex, const uint8_t *exv, int prow, int pcol, float &dx, float &dy) {
-    const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+    const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
     if (exv[ei - 1] && exv[ei + 1] && exv[ei - p.ex_cols] && exv[ei + p.ex_cols]) {
         dx = ex[ei + 1] - ex[ei - 1];
         dy = ex[ei + p.ex_cols] - ex[ei - p.ex_cols];
@@ -612,7 +612,7 @@ __device__ __forceinline__ void basic_level_fast(const Blk &b, const KltParams &
                 pixel_rc(p, pxi, prow, pcol);
                 const int row = wadd(min_row, prow);
                 const int col = wadd(min_col, pcol);
-                const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+                const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
                 ok = !(row < 0 || row > cur.rows - 2 || col < 0 || col > cur.cols - 2) && exv[ei] != 0;
                 float t0 = 0.0f, t1 = 0.0f;
                 if (ok) {
@@ -972,7 +972,7 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
                 const float row_c = warped_y + s.cur_v;
                 const float col_c = warped_x + s.cur_u;
                 float i_cur = 0.0f;
-                const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+                const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
                 ok = sample(cur, cw, row_c, col_c, i_cur) && exv[ei] != 0;
                 const float dt = i_cur - ex[ei];
                 affine_bias_terms(p, c.terms, 0, pxi, ok, dt, col_c, row_c, dxs[pxi], dys[pxi]);
@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
         dxs[pxi] = dx;
         dys[pxi] = dy;
         // interior of the extended patch in row-major order == the P patch pixels
-        c.terms[pxi] = ex[(prow + 1) * p.ex_cols + pcol + 1];
+        c.terms[pxi] = ex[imul(prow + 1, p.ex_cols) + pcol + 1];
     }
     blk_sync(b);
     if (p.consider_luminance) {
@@ -1245,7 +1245,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
                         value = bilinear(cur, cw, row_j, col_j);
                         ok_cur = true;
                     }
-                    const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+                    const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
                     ok = exv[ei] != 0 && ok_cur;
                     const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
                     const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
                 pixel_rc(p, pxi, prow, pcol);
                 const float row_i = (float)(prow - p.half_rows) + ref_v;
                 const float col_i = (float)(pcol - p.half_cols) + ref_u;
-                const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+                const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
                 ok = exv[ei] != 0 && curv[pxi] != 0;
                 const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
                 const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
@@ -1433,7 +1433,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                 ok_cur = true;
             }
             ok_cur = ok_cur && in;
-            const int ei = (prow + 1) * p.ex_cols + pcol + 1;
+            const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
             const bool ok = exv[ei] != 0 && ok_cur;
             const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
             const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
