@@ -205,6 +205,9 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.a0_floats = epad > tables ? epad : tables;
     }
     p.magic_pc = div_magic(p.patch_cols);
+    // the same division on the full-rate 24-bit multiplier when it is exact over the whole patch: x * (M * d - 2^20) < 2^20 for all x < P
+    p.magic_pc20 = (p.patch_cols > 1 && (long long)p.P * p.patch_cols < (1ll << 20) && p.P < (1 << 12))
+                       ? (uint32_t)(((1u << 20) + (uint32_t)p.patch_cols - 1) / (uint32_t)p.patch_cols) : 0u;
     p.magic_exc = div_magic(p.ex_cols);
     p.rwin_rows = p.patch_rows + 3;
     p.rwin_cols = (p.patch_cols + 3 + 3) & ~3;  // pixel-pair columns, rounded up to a multiple of 4 (8-byte LDS stores)
@@ -319,6 +322,9 @@ int make_pyramid(ftk_context *ctx, ftk_pyramid **out) {
     return FTK_OK;
 }
 
+// The trackers index a level with 32-bit pixel offsets formed on the 24-bit multiplier (klt_common.h px()).
+bool level_addressable(int32_t rows, int32_t cols) { return rows < (1 << 23) && cols < (1 << 23) && (long long)rows * cols < (1ll << 31); }
+
 int check_levels(ftk_context *ctx, const ftk_image *levels, int32_t n_levels) {
     if (!levels || n_levels < 1 || n_levels > FTK_MAX_LEVELS) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: n_levels %d outside [1, %d]", n_levels, FTK_MAX_LEVELS);
@@ -326,6 +332,9 @@ int check_levels(ftk_context *ctx, const ftk_image *levels, int32_t n_levels) {
     for (int i = 0; i < n_levels; ++i) {
         if (!levels[i].data || levels[i].rows <= 0 || levels[i].cols <= 0) {
             return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: level %d is empty", i);
+        }
+        if (!level_addressable(levels[i].rows, levels[i].cols)) {
+            return fail(ctx, FTK_E_UNSUPPORTED, "pyramid: level %d (%d x %d) exceeds 2^23 on a side or 2^31 pixels", i, levels[i].rows, levels[i].cols);
         }
     }
     return FTK_OK;
@@ -538,6 +547,9 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
     FTK_LOCK(ctx);
     if (!image || rows <= 0 || cols <= 0 || n_levels < 1 || n_levels > FTK_MAX_LEVELS || !out) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_build: bad image or level count");
+    }
+    if (!level_addressable(rows, cols)) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_build: image %d x %d exceeds 2^23 on a side or 2^31 pixels", rows, cols);
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
     int32_t lrows[FTK_MAX_LEVELS], lcols[FTK_MAX_LEVELS];

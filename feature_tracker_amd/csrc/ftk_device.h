@@ -44,6 +44,7 @@ struct KltParams {
     int32_t ex_rows, ex_cols, E;
     int32_t a0_floats;  // size of the first LDS array: max(E padded, axis tables)
     uint32_t magic_pc;   // ceil(2^32 / patch_cols): row = umulhi(p, magic_pc)
+    uint32_t magic_pc20; // ceil(2^20 / patch_cols) when P * patch_cols < 2^20 (row = (p * magic_pc20) >> 20 on the 24-bit multiplier), else 0
     uint32_t magic_exc;  // ceil(2^32 / ex_cols)
     // LDS image windows (16-bit pixel pairs): reference footprint and current footprint + margin
     int32_t rwin_rows, rwin_cols;

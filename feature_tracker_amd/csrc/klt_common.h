@@ -45,7 +45,9 @@ __device__ __forceinline__ float floor_from_trunc(float x, int t) {
     const float f = (float)t;
     return (f > x) ? f - 1.0f : f;
 }
-__device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[(long long)row * im.cols + col]; }
+// 32-bit offset on the 24-bit multiplier (levels are < 2^23 on a side and < 2^31 pixels: checked where a pyramid is made), so the
+// load is base + zero-extended offset instead of a quarter-rate 64-bit multiply-add per tap
+__device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[(unsigned)(imul(row, im.cols) + col)]; }
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // Thread coordinates inside the feature's workgroup.
@@ -802,7 +804,11 @@ constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked
 constexpr int kChunkRow = kChunkPixels + 4;   // ring row pitch in floats: the chain lanes' 16-byte reads of different rows hit different banks
 
 __device__ __forceinline__ void pixel_rc(const KltParams &p, int pxi, int &prow, int &pcol) {
-    prow = (p.patch_cols == 1) ? pxi : (int)__umulhi((unsigned)pxi, p.magic_pc);
+    if (p.magic_pc20 != 0) {  // wave-uniform; v_mul_u32_u24 is full rate, v_mul_hi_u32 a quarter of it
+        prow = (int)(__umul24((unsigned)pxi, p.magic_pc20) >> 20);
+    } else {
+        prow = (p.patch_cols == 1) ? pxi : (int)__umulhi((unsigned)pxi, p.magic_pc);
+    }
     pcol = pxi - imul(prow, p.patch_cols);
 }
 
@@ -829,8 +835,8 @@ __device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo,
     const int ic = wadd(c_lo, c);
     const int ic0 = clampi(ic, 0, im.cols - 1);
     const int ic1 = clampi(wadd(ic, 1), 0, im.cols - 1);
-    const uint8_t *rowp = im.data + (long long)ir * im.cols;
-    return (uint16_t)((unsigned)rowp[ic0] | ((unsigned)rowp[ic1] << 8));
+    const unsigned row_off = (unsigned)imul(ir, im.cols);  // 32-bit offsets, as in px()
+    return (uint16_t)((unsigned)im.data[row_off + (unsigned)ic0] | ((unsigned)im.data[row_off + (unsigned)ic1] << 8));
 }
 
 // Loads up to kStageBatch window elements per thread with every global load in flight before the
@@ -871,7 +877,7 @@ __device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &
     for (int idx = b.tid; idx < total; idx += b.nt) {
         const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
         const int q = idx - imul(r, quads);
-        const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+        const uint8_t *src = im.data + (unsigned)(imul(r_lo + r, im.cols) + c_lo + 4 * q);
         uint32_t x, y;
         __builtin_memcpy(&x, src, 4);
         __builtin_memcpy(&y, src + 4, 4);
@@ -897,7 +903,7 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
                                                  int wcols) {
     const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
     const int q = idx - imul(r, quads);
-    const uint8_t *src = im.data + (long long)(r_lo + r) * im.cols + c_lo + 4 * q;
+    const uint8_t *src = im.data + (unsigned)(imul(r_lo + r, im.cols) + c_lo + 4 * q);
     uint32_t x, y;
     __builtin_memcpy(&x, src, 4);
     __builtin_memcpy(&y, src + 4, 4);
