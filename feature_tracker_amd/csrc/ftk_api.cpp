@@ -323,7 +323,7 @@ int make_pyramid(ftk_context *ctx, ftk_pyramid **out) {
 }
 
 // The trackers index a level with 32-bit pixel offsets formed on the 24-bit multiplier (klt_common.h px()).
-bool level_addressable(int32_t rows, int32_t cols) { return rows < (1 << 23) && cols < (1 << 23) && (long long)rows * cols < (1ll << 31); }
+bool level_addressable(int32_t rows, int32_t cols) { return rows < (1 << 24) && cols < (1 << 24) && (long long)rows * cols < (1ll << 32); }
 
 int check_levels(ftk_context *ctx, const ftk_image *levels, int32_t n_levels) {
     if (!levels || n_levels < 1 || n_levels > FTK_MAX_LEVELS) {
@@ -334,7 +334,7 @@ int check_levels(ftk_context *ctx, const ftk_image *levels, int32_t n_levels) {
             return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid: level %d is empty", i);
         }
         if (!level_addressable(levels[i].rows, levels[i].cols)) {
-            return fail(ctx, FTK_E_UNSUPPORTED, "pyramid: level %d (%d x %d) exceeds 2^23 on a side or 2^31 pixels", i, levels[i].rows, levels[i].cols);
+            return fail(ctx, FTK_E_UNSUPPORTED, "pyramid: level %d (%d x %d) exceeds 2^24 on a side or 2^32 pixels", i, levels[i].rows, levels[i].cols);
         }
     }
     return FTK_OK;
@@ -549,7 +549,7 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_build: bad image or level count");
     }
     if (!level_addressable(rows, cols)) {
-        return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_build: image %d x %d exceeds 2^23 on a side or 2^31 pixels", rows, cols);
+        return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_build: image %d x %d exceeds 2^24 on a side or 2^32 pixels", rows, cols);
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
     int32_t lrows[FTK_MAX_LEVELS], lcols[FTK_MAX_LEVELS];

@@ -45,9 +45,9 @@ __device__ __forceinline__ float floor_from_trunc(float x, int t) {
     const float f = (float)t;
     return (f > x) ? f - 1.0f : f;
 }
-// 32-bit offset on the 24-bit multiplier (levels are < 2^23 on a side and < 2^31 pixels: checked where a pyramid is made), so the
+// 32-bit offset on the 24-bit multiplier (levels are < 2^24 on a side and < 2^32 pixels: checked where a pyramid is made), so the
 // load is base + zero-extended offset instead of a quarter-rate 64-bit multiply-add per tap
-__device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[(unsigned)(imul(row, im.cols) + col)]; }
+__device__ __forceinline__ float px(const DevImage &im, int row, int col) { return (float)im.data[__umul24((unsigned)row, (unsigned)im.cols) + (unsigned)col]; }
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // Thread coordinates inside the feature's workgroup.
@@ -835,7 +835,7 @@ __device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo,
     const int ic = wadd(c_lo, c);
     const int ic0 = clampi(ic, 0, im.cols - 1);
     const int ic1 = clampi(wadd(ic, 1), 0, im.cols - 1);
-    const unsigned row_off = (unsigned)imul(ir, im.cols);  // 32-bit offsets, as in px()
+    const unsigned row_off = __umul24((unsigned)ir, (unsigned)im.cols);  // 32-bit offsets, as in px()
     return (uint16_t)((unsigned)im.data[row_off + (unsigned)ic0] | ((unsigned)im.data[row_off + (unsigned)ic1] << 8));
 }
 
@@ -877,7 +877,7 @@ __device__ __forceinline__ void stage_rows_inside(const Blk &b, const DevImage &
     for (int idx = b.tid; idx < total; idx += b.nt) {
         const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
         const int q = idx - imul(r, quads);
-        const uint8_t *src = im.data + (unsigned)(imul(r_lo + r, im.cols) + c_lo + 4 * q);
+        const uint8_t *src = im.data + (__umul24((unsigned)(r_lo + r), (unsigned)im.cols) + (unsigned)(c_lo + 4 * q));
         uint32_t x, y;
         __builtin_memcpy(&x, src, 4);
         __builtin_memcpy(&y, src + 4, 4);
@@ -903,7 +903,7 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
                                                  int wcols) {
     const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
     const int q = idx - imul(r, quads);
-    const uint8_t *src = im.data + (unsigned)(imul(r_lo + r, im.cols) + c_lo + 4 * q);
+    const uint8_t *src = im.data + (__umul24((unsigned)(r_lo + r), (unsigned)im.cols) + (unsigned)(c_lo + 4 * q));
     uint32_t x, y;
     __builtin_memcpy(&x, src, 4);
     __builtin_memcpy(&y, src + 4, 4);

@@ -97,6 +97,9 @@ void ftk_default_klt_options(ftk_klt_options *opt);
 
 /* ---- image pyramids resident in HBM ------------------------------------------------------ */
 
+/* A level may have up to 2^24 - 1 rows / columns and fewer than 2^32 pixels (the trackers address pixels with 32-bit
+ * offsets); larger levels fail with FTK_E_UNSUPPORTED in the three calls below. */
+
 /* Copies the levels of a host ImagePyramid (ImagePyramid::GetImageConst(i), basic_klt.cpp:22-23)
  * into ONE device allocation, level after level, each level 256-byte aligned. */
 int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n_levels, ftk_pyramid **out);

@@ -81,6 +81,21 @@ def test_direct_method_with_more_features_than_fit_in_lds(ftk, oracle):
     assert_identical(g, c)
 
 
+def test_levels_beyond_32_bit_pixel_offsets_are_refused(ftk, gpu_ctx):
+    """include/ftk.h, image pyramids: a level of 2^24 rows / columns or 2^32 pixels cannot be addressed by the trackers' 32-bit
+    offsets; the pyramid calls say so (FTK_E_UNSUPPORTED) instead of tracking on wrapped addresses.  Nothing is read at wrap time,
+    so a small allocation stands in for the image."""
+    import torch
+    from feature_tracker_amd._native import FtkError
+    t = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    for rows, cols in (((1 << 24), 8), (8, (1 << 24)), (1 << 16, 1 << 16)):
+        with pytest.raises(FtkError) as e:
+            ftk.ImagePyramid.from_device_levels([(t.data_ptr(), rows, cols)], gpu_ctx, keepalive=[t])
+        assert e.value.code == -4, e.value
+    ok = ftk.ImagePyramid.from_device_levels([(t.data_ptr(), 64, 64)], gpu_ctx, keepalive=[t])
+    assert ok is not None
+
+
 def test_two_threads_share_one_context(ftk, oracle):
     """Separate tracker / matcher objects on the process-wide context, driven from two threads at once (a stereo front end):
     calls are serialised inside the C ABI, so every result equals the single-threaded one."""
