@@ -270,7 +270,9 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
     if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && !p.consider_luminance && !(chunk_env && atoi(chunk_env) == 0)) {
         p.lssd_chunked = 1;
-        p.terms_floats = 9 * 68;
+        const int32_t epad = (p.E + 3) & ~3;
+        p.terms_floats = epad > 9 * 68 ? epad : 9 * 68;  // the ring, or the extended patch that shares its space at level entry
+        p.a0_floats = 0;                                  // (klt_kernels.hip lssd_level_fast_chunked)
     }
     if (!p.pb_enabled) {
         p.features_per_group = 1;  // the generic kernel's workgroup is one feature ...

@@ -121,8 +121,9 @@ __device__ __forceinline__ void fetch4(const DevImage &im, const Win &w, int r0,
     const int lr = (int)((unsigned)r0 - (unsigned)w.r_lo);
     const int lc = (int)((unsigned)c0 - (unsigned)w.c_lo);
     if ((unsigned)lr < (unsigned)(w.rows - 1) && (unsigned)lc < (unsigned)w.cols) {
-        const unsigned a = w.data[imul(lr, w.cols) + lc];
-        const unsigned bb = w.data[imul(lr + 1, w.cols) + lc];
+        const int top = imul(lr, w.cols) + lc;  // the row below is one pitch further (not a second multiply of lr + 1)
+        const unsigned a = w.data[top];
+        const unsigned bb = w.data[top + w.cols];
         p00 = (float)(a & 0xFFu);
         p01 = (float)(a >> 8);
         p10 = (float)(bb & 0xFFu);

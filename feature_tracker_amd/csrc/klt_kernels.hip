@@ -60,9 +60,12 @@ struct Carve {
 
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 
+// Per-pixel floats after a0: dx, dy, one spare array — or, chunked LSSD, a float4 record + a float2 coordinate pair per pixel.
+__host__ __device__ inline int carve_px_floats(const KltParams &p) { return p.lssd_chunked ? 6 : 3; }
+
 __host__ __device__ inline size_t carve_bytes(int K, const KltParams &p) {
     const size_t epad = (size_t)pad4(p.E);
-    const size_t floats = (size_t)(p.terms_floats > 0 ? p.terms_floats : K * p.Ppad) + (size_t)p.a0_floats + 3 * (size_t)p.Ppad + 72 + 24;
+    const size_t floats = (size_t)(p.terms_floats > 0 ? p.terms_floats : K * p.Ppad) + (size_t)p.a0_floats + (size_t)carve_px_floats(p) * (size_t)p.Ppad + 72 + 24;
     const size_t shorts = (size_t)pad4(p.rwin_rows * p.rwin_cols) + (size_t)pad4(p.cwin_rows * p.cwin_cols);
     return sizeof(float) * floats + sizeof(uint16_t) * shorts + epad + (size_t)p.Ppad;
 }
@@ -75,7 +78,7 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
     c.a1 = c.a0 + p.a0_floats;
     c.a2 = c.a1 + p.Ppad;
     c.a3 = c.a2 + p.Ppad;
-    c.sums = c.a3 + p.Ppad;
+    c.sums = c.a1 + carve_px_floats(p) * p.Ppad;
     c.wave_cnt = reinterpret_cast<uint32_t *>(c.sums + 72);
     c.ref_win = reinterpret_cast<uint16_t *>(c.wave_cnt + 24);
     c.cur_win = c.ref_win + pad4(p.rwin_rows * p.rwin_cols);
@@ -1360,9 +1363,16 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
 // per-pixel expressions, same row-major order of every sum as lssd_level_fast: bit-identical.
 __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
                                                         float ref_v, LssdState &s, uint8_t &status, uint32_t &iters, Carve &c) {
-    float *ex = c.a0, *dxs = c.a1, *dys = c.a2;
+    // the chunked variant has a0_floats == 0: the extended patch (level entry only) lives in the ring's space (iterations only)
+    c.a0 = c.terms;
+    float *ex = c.a0;
     uint8_t *exv = c.flagsE;
     float *ring = c.terms;  // [9][kChunkRow]
+    // what an iteration needs of a patch pixel, laid out by pixel: {dx, dy, reference value, valid} and {row_i, col_i} — one
+    // 16-byte and one 8-byte conflict-free read per pixel instead of the row / column division, the index into the extended
+    // patch and four scattered reads, every iteration
+    float4 *rec = reinterpret_cast<float4 *>(c.a1);
+    float2 *rc = reinterpret_cast<float2 *>(c.a1 + 4 * p.Ppad);
     Win rw, cw;
     float level_centre_u, level_centre_v;
     se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
@@ -1380,8 +1390,9 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         pixel_rc(p, pxi, prow, pcol);
         float dx, dy;
         ex_gradient(p, ex, exv, prow, pcol, dx, dy);
-        dxs[pxi] = dx;
-        dys[pxi] = dy;
+        const int ei = imul(prow, p.ex_cols) + pcol + (p.ex_cols + 1);
+        rec[pxi] = make_float4(dx, dy, ex[ei], __int_as_float(exv[ei] != 0 ? -1 : 0));
+        rc[pxi] = make_float2((float)(prow - p.half_rows) + ref_v, (float)(pcol - p.half_cols) + ref_u);
     }
     blk_sync(b);
     FTK_STAMP_END(b, 1);  // extended patch + gradients
@@ -1407,10 +1418,9 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             const int pxi = chunk * kChunkPixels + b.lane;
             const bool in = pxi < p.P;
             const int pp = in ? pxi : 0;
-            int prow, pcol;
-            pixel_rc(p, pp, prow, pcol);
-            const float row_i = (float)(prow - p.half_rows) + ref_v;
-            const float col_i = (float)(pcol - p.half_cols) + ref_u;
+            const float2 rci = rc[pp];
+            const float4 px4 = rec[pp];
+            const float row_i = rci.x, col_i = rci.y;
             float row_j, col_j;
             se2_apply(s, col_i, row_i, col_j, row_j);
             float value = 0.0f;
@@ -1433,16 +1443,15 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                 ok_cur = true;
             }
             ok_cur = ok_cur && in;
-            const int ei = imul(prow + 1, p.ex_cols) + pcol + 1;
-            const bool ok = exv[ei] != 0 && ok_cur;
+            const bool ok = __float_as_int(px4.w) != 0 && ok_cur;
             const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
             const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
             // An unused pixel contributes exact zeros to every sum (lssd_terms): zeroing the four factors does it with four
             // selects instead of nine — the products are then +0 or -0, and x + (+-0) == x for every x a sum can hold (the
             // sums start at +0 and +0 + (-0) == +0).
-            const float dx = ok ? dxs[pp] : 0.0f, dy = ok ? dys[pp] : 0.0f;
-            const float j0 = ok ? dxs[pp] * s0 + dys[pp] * s1 : 0.0f;
-            const float residual = ok ? value - ex[ei] : 0.0f;
+            const float dx = ok ? px4.x : 0.0f, dy = ok ? px4.y : 0.0f;
+            const float j0 = ok ? px4.x * s0 + px4.y * s1 : 0.0f;
+            const float residual = ok ? value - px4.z : 0.0f;
             ring[0 * kChunkRow + b.lane] = j0 * j0;
             ring[1 * kChunkRow + b.lane] = j0 * dx;
             ring[2 * kChunkRow + b.lane] = j0 * dy;
