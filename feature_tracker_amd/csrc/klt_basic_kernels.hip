@@ -197,7 +197,7 @@ __device__ __forceinline__ void build_nodes_pass(int lane, const AxisSpec &A, co
     const bool vp = xp >= 0.0f && xp <= lim;
     const bool needm = act && t > 0 && vm && __float_as_uint(xm) != __float_as_uint(xprev);
     const bool needp = act && t < len - 1 && vp && __float_as_uint(xp) != __float_as_uint(xnext);
-    const unsigned long long bm = __ballot(needm), bp = __ballot(needp);
+    const unsigned long long bm = wave_ballot(needm), bp = wave_ballot(needp);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int nm = (int)__popcll(bm & mine);
     int em = len + 2 + (int)__popcll(bm & mine & below);
@@ -558,7 +558,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     const int chunk = s * np + pw;
                     if (chunk < n_chunks) {
                         const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & ring_mask) * np + pw) * kTerms * kRingRow);
-                        wave_valid += (uint32_t)__popcll(__ballot(ok));
+                        wave_valid += (uint32_t)__popcll(wave_ballot(ok));
                     }
                     if (s == n_steps - 1 && b.lane == 0) {
                         c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;

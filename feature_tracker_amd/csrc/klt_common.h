@@ -41,6 +41,8 @@ __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (
 // Product of two SMALL integers (patch / window geometry, pixel and row indices inside them: |x| < 2^23, product < 2^31): the
 // 24-bit multiplier issues at full rate, v_mul_lo_u32 at a quarter of it — and the kernels are bound by vector issue.
 __device__ __forceinline__ int imul(int a, int b) { return __mul24(a, b); }
+// __ballot() takes an int: a bool predicate goes through v_cndmask 0/1 + v_cmp_ne before it becomes the lane mask it already was.
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 __device__ __forceinline__ float floor_from_trunc(float x, int t) {
     const float f = (float)t;
     return (f > x) ? f - 1.0f : f;
@@ -603,13 +605,13 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane) {
         rank += (aj > my_ad) ? 1 : 0;
         equal += (aj == my_ad) ? 1 : 0;
     }
-    const bool irregular = __ballot(lane < 6 && (equal != 1)) != 0ull;  // equal == 0: NaN; > 1: a tie
+    const bool irregular = wave_ballot(lane < 6 && (equal != 1)) != 0ull;  // equal == 0: NaN; > 1: a tie
     int pos[6];
     bool degenerate = false;
     if (!irregular) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            pos[k] = (int)__ffsll((long long)__ballot(lane < 6 && rank == k)) - 1;
+            pos[k] = (int)__ffsll((long long)wave_ballot(lane < 6 && rank == k)) - 1;
         }
         // the largest magnitude is positive here (six distinct non-negative numbers), so the first pivot is valid
     } else {
@@ -932,14 +934,14 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
 // of atomics on one address — then one atomic per remaining lane (counts spread over many bins: little contention).
 __device__ __forceinline__ int wave_bin_claim(int *bins, int bin, bool active) {
     int slot = 0;
-    const unsigned long long todo = __ballot(active);
+    const unsigned long long todo = wave_ballot(active);
     if (todo == 0ull) {
         return 0;
     }
     const int leader = __ffsll((long long)todo) - 1;
     const int leader_bin = __builtin_amdgcn_readlane(bin, leader);
     const bool with_leader = active && bin == leader_bin;
-    const unsigned long long same = __ballot(with_leader);
+    const unsigned long long same = wave_ballot(with_leader);
     int base = 0;
     if ((int)(threadIdx.x & 63) == leader) {
         base = atomicAdd(&bins[leader_bin], __popcll(same));

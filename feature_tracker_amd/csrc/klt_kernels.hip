@@ -119,7 +119,7 @@ __device__ __forceinline__ void publish_count(const Blk &b, uint32_t wave_sum, u
 // `bank` selects one of four 4-slot groups so that back-to-back uses never share slots without a
 // barrier in between (0 / 1: iteration parity, 2 / 3: level setup fast / slow pass).
 __device__ __forceinline__ bool block_any(const Blk &b, bool flag, uint32_t *slots, uint32_t bank) {
-    const bool wave_any = __ballot(flag) != 0ull;
+    const bool wave_any = wave_ballot(flag) != 0ull;
     if (b.solo) {
         blk_sync(b);
         return wave_any;
@@ -427,7 +427,7 @@ __device__ __forceinline__ uint32_t extract_extended_patch(const Blk &b, const K
             ex[e] = value;
             exv[e] = valid ? 1 : 0;
         }
-        count += (uint32_t)__popcll(__ballot(valid));
+        count += (uint32_t)__popcll(wave_ballot(valid));
     }
     return block_total(b, count, c.wave_cnt);
 }
@@ -511,7 +511,7 @@ __device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, co
                     c.terms[3 * p.Ppad + pxi] = ok ? -(fx * ft) : 0.0f;
                     c.terms[4 * p.Ppad + pxi] = ok ? -(fy * ft) : 0.0f;
                 }
-                wave_valid += (uint32_t)__popcll(__ballot(ok));
+                wave_valid += (uint32_t)__popcll(wave_ballot(ok));
             }
             return wave_valid;
         };
@@ -629,7 +629,7 @@ __device__ __forceinline__ void basic_level_fast(const Blk &b, const KltParams &
                 c.terms[0 * p.Ppad + pxi] = t0;
                 c.terms[1 * p.Ppad + pxi] = t1;
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
         publish_count(b, n_valid, c.wave_cnt, iter);
         chain_then(b, c.terms, 2, p.Ppad, c.sums, true, [&]() {
@@ -833,7 +833,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             for (int base = 0; base < p.P; base += b.nt) {
                 const int pxi = base + b.tid;
                 const bool ok = pxi < p.P ? produce(pxi) : false;
-                n_valid += (uint32_t)__popcll(__ballot(ok));
+                n_valid += (uint32_t)__popcll(wave_ballot(ok));
             }
             publish_count(b, n_valid, c.wave_cnt, iter);
             blk_sync(b);  // the terms (and the published counts) are visible
@@ -844,7 +844,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
         } else {
             {
                 const bool ok = produce(b.tid);  // P > nt: every lane has a pixel
-                n_valid += (uint32_t)__popcll(__ballot(ok));
+                n_valid += (uint32_t)__popcll(wave_ballot(ok));
             }
             blk_sync(b);  // the products of pixels [0, nt) are visible
             FTK_STAMP_END(b, 3);
@@ -857,7 +857,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
                 for (int base = b.nt; base < p.P; base += step) {
                     const int pxi = base + (b.tid - kWave);
                     const bool ok = pxi < p.P ? produce(pxi) : false;
-                    n_valid += (uint32_t)__popcll(__ballot(ok));
+                    n_valid += (uint32_t)__popcll(wave_ballot(ok));
                 }
             }
             publish_count(b, n_valid, c.wave_cnt, iter);
@@ -980,7 +980,7 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
                 const float dt = i_cur - ex[ei];
                 affine_bias_terms(p, c.terms, 0, pxi, ok, dt, col_c, row_c, dxs[pxi], dys[pxi]);
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
         publish_count(b, n_valid, c.wave_cnt, iter);
         chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() { ldlt6_solve(fac, c.sums, c.sums + A_COUNT, b.lane); });
@@ -1124,7 +1124,7 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
                 c.terms[0 * p.Ppad + pxi] = ok ? i_ref : 0.0f;
                 c.terms[1 * p.Ppad + pxi] = ok ? i_cur : 0.0f;
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
         n_valid = block_total(b, n_valid, c.wave_cnt);
         chain_sums(b, c.terms, 2, p.Ppad, c.sums);
@@ -1257,8 +1257,8 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
                     const float residual = value - ex[ei];
                     lssd_terms(p, c.terms, pxi, ok, j0, dx, dy, residual);
                 }
-                cur_valid_num += (uint32_t)__popcll(__ballot(ok_cur));
-                n_valid += (uint32_t)__popcll(__ballot(ok));
+                cur_valid_num += (uint32_t)__popcll(wave_ballot(ok_cur));
+                n_valid += (uint32_t)__popcll(wave_ballot(ok));
             }
             // both counts in one exchange: n_valid <= cur_valid_num <= P < 2^16
             const uint32_t both = block_total(b, (cur_valid_num << 16) | n_valid, c.wave_cnt);
@@ -1303,7 +1303,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
                 const bool interior = prow >= 1 && prow < p.patch_rows - 1 && pcol >= 1 && pcol < p.patch_cols - 1;
                 c.terms[pxi] = interior ? value : 0.0f;
             }
-            cur_valid_num += (uint32_t)__popcll(__ballot(ok));
+            cur_valid_num += (uint32_t)__popcll(wave_ballot(ok));
         }
         cur_valid_num = block_total(b, cur_valid_num, c.wave_cnt);
         if (cur_valid_num == 0) {
@@ -1337,7 +1337,7 @@ __device__ __forceinline__ void lssd_level_fast(const Blk &b, const KltParams &p
                 const float residual = curp[pxi] - ex[ei];
                 lssd_terms(p, c.terms, pxi, ok, j0, dx, dy, residual);
             }
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
         n_valid = block_total(b, n_valid, c.wave_cnt);
         if (n_valid == 0) {
@@ -1412,7 +1412,9 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         const int max_row = wadd(min_row, p.patch_rows * 2);
         const int max_col = wadd(min_col, p.patch_cols * 2);
         const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
-        uint32_t cur_valid_num = 0, n_valid = 0;
+        // lssd_klt_fast.cpp:60-63 / :80-83 only ask whether the two counts are zero (their values feed the luminance scaling,
+        // which this variant does not serve): one flag per lane and one ballot per iteration instead of two per chunk
+        bool seen_cur = false, seen_valid = false;
         float acc = 0.0f;
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const int pxi = chunk * kChunkPixels + b.lane;
@@ -1435,7 +1437,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                 // its +1 neighbours (the normal case: a rotation moves a pixel less than the conservative window above allows
                 // for) the cheaper form gives the same values
                 const bool roomy = row_j >= 0.0f && col_j >= 0.0f && row_j <= (float)(cur.rows - 2) && col_j <= (float)(cur.cols - 2);
-                if (__ballot(!roomy) == 0ull) {
+                if (wave_ballot(!roomy) == 0ull) {
                     value = bilinear_inside(cur, cw, row_j, col_j);
                 } else {
                     value = bilinear(cur, cw, row_j, col_j);
@@ -1461,8 +1463,8 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             ring[6 * kChunkRow + b.lane] = -(j0 * residual);
             ring[7 * kChunkRow + b.lane] = -(dx * residual);
             ring[8 * kChunkRow + b.lane] = -(dy * residual);
-            cur_valid_num += (uint32_t)__popcll(__ballot(ok_cur));
-            n_valid += (uint32_t)__popcll(__ballot(ok));
+            seen_cur = seen_cur || ok_cur;
+            seen_valid = seen_valid || ok;
             blk_sync(b);  // one wave: LDS operations run in program order; this keeps the compiler from reordering across
             if (b.lane < 9) {
                 acc = chain_chunk(acc, ring + b.lane * kChunkRow);
@@ -1470,7 +1472,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             blk_sync(b);
         }
         FTK_STAMP_END(b, 3);  // window check + the chunks (sampling, products, chains)
-        if (cur_valid_num == 0 || n_valid == 0) {
+        if (wave_ballot(seen_cur) == 0ull || wave_ballot(seen_valid) == 0ull) {
             break;  // lssd_klt_fast.cpp:60-63 / :80-83
         }
         // the nine sums sit in lanes 0..8: broadcast and solve (lssd_solve on registers)
