@@ -165,8 +165,10 @@ __device__ __forceinline__ float bilinear(const DevImage &im, const Win &w, floa
 __device__ __forceinline__ float bilinear_inside(const DevImage &im, const Win &w, float row, float col) {
     const int r0 = (int)row;
     const int c0 = (int)col;
-    const float sub_row = row - (float)r0;
-    const float sub_col = col - (float)c0;
+    // x - (float)(int)x for 0 <= x < 2^31 is x - floor(x), exact in fp32, and that is what v_fract_f32 returns (its clamp below
+    // 1.0 only matters for tiny negative x): one instruction instead of a conversion and a subtraction, same bits
+    const float sub_row = __builtin_amdgcn_fractf(row);
+    const float sub_col = __builtin_amdgcn_fractf(col);
     const float inv_sub_row = 1.0f - sub_row;
     const float inv_sub_col = 1.0f - sub_col;
     const float w_tl = inv_sub_row * inv_sub_col;
@@ -186,8 +188,8 @@ __device__ __forceinline__ bool sample(const DevImage &im, const Win &w, float r
     }
     const int r0 = (int)row;
     const int c0 = (int)col;
-    const float sub_row = row - (float)r0;
-    const float sub_col = col - (float)c0;
+    const float sub_row = __builtin_amdgcn_fractf(row);  // == row - (float)r0 for row >= 0, see bilinear_inside
+    const float sub_col = __builtin_amdgcn_fractf(col);
     const float inv_sub_row = 1.0f - sub_row;
     const float inv_sub_col = 1.0f - sub_col;
     const float w_tl = inv_sub_row * inv_sub_col;

@@ -1436,7 +1436,10 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                 // the unchecked bilinear (lssd_klt_fast.cpp:189); when every lane's sample lies inside the image with room for
                 // its +1 neighbours (the normal case: a rotation moves a pixel less than the conservative window above allows
                 // for) the cheaper form gives the same values
-                const bool roomy = row_j >= 0.0f && col_j >= 0.0f && row_j <= (float)(cur.rows - 2) && col_j <= (float)(cur.cols - 2);
+                // 0 <= x <= M as ONE unsigned compare of the bit patterns (M >= 0 here: !partly_outside): negative values, -0 and
+                // NaNs have larger patterns than any finite M and take the general form below, which returns the same values
+                const bool roomy = (unsigned)__float_as_int(row_j) <= (unsigned)__float_as_int((float)(cur.rows - 2)) &&
+                                   (unsigned)__float_as_int(col_j) <= (unsigned)__float_as_int((float)(cur.cols - 2));
                 if (wave_ballot(!roomy) == 0ull) {
                     value = bilinear_inside(cur, cw, row_j, col_j);
                 } else {
