@@ -266,6 +266,9 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // P products of all nine chains in LDS; config 4: 304 -> 242 us)
     p.terms_floats = 0;
     p.lssd_chunked = 0;
+    if (model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
+        p.terms_floats = (p.Ppad / 4) * ftk::kAffineTermsGroupFloats;  // products grouped by four pixels (klt_kernels.hip affine_all_terms)
+    }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
     if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && !p.consider_luminance && !(chunk_env && atoi(chunk_env) == 0)) {

@@ -9,6 +9,10 @@
 
 namespace ftk {
 
+// Floats per pixel group (4 pixels x 24 sums + one float4 of padding) of the non-fast affine variants' product layout
+// (klt_kernels.hip affine_all_terms); the host sizes KltParams::terms_floats with it.
+constexpr int kAffineTermsGroupFloats = 4 * 24 + 4;
+
 struct DevImage {
     const uint8_t *data;
     int32_t rows;

@@ -778,6 +778,47 @@ __device__ __forceinline__ float chain_lane(const float *row, int Ppad, float ac
     return acc;
 }
 
+// The same chain over a GROUPED layout: the terms of four consecutive pixels of one sum sit in one float4 and consecutive
+// groups lie kStride4 float4 apart ([group][sum][4 pixels], written by the pixel lanes with immediate offsets).  Same adds in the
+// same order as chain_lane; the prefetch is guarded at the tail because a stride's worth of overrun would leave the carve.
+template <int kStride4>
+__device__ __forceinline__ void chain_load_groups(float4 (&q)[kChainRound], const float4 *t, int first, int n4) {
+    if (first + kChainRound <= n4) {
+#pragma unroll
+        for (int d = 0; d < kChainRound; ++d) {
+            q[d] = t[(first + d) * kStride4];
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < kChainRound; ++d) {
+            if (first + d < n4) {
+                q[d] = t[(first + d) * kStride4];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int kStride4>
+__device__ __forceinline__ float chain_groups(const float4 *t, int n4, float acc) {
+    float4 qa[kChainRound] = {}, qb[kChainRound] = {};
+    int i = 0;
+    chain_load_groups<kStride4>(qa, t, 0, n4);
+    for (; i + 3 * kChainRound <= n4; i += 2 * kChainRound) {  // everything the body loads is in range
+        chain_load_groups<kStride4>(qb, t, i + kChainRound, n4);
+        acc = chain_consume_all(acc, qa);
+        chain_load_groups<kStride4>(qa, t, i + 2 * kChainRound, n4);
+        acc = chain_consume_all(acc, qb);
+    }
+    const int rem = n4 - i;  // 0 .. 3*kChainRound-1 groups left, the first kChainRound already in qa
+    chain_load_groups<kStride4>(qb, t, i + kChainRound, n4);
+    acc = chain_consume(acc, qa, rem);
+    chain_load_groups<kStride4>(qa, t, i + 2 * kChainRound, n4);
+    acc = chain_consume(acc, qb, rem - kChainRound);
+    acc = chain_consume(acc, qa, rem - 2 * kChainRound);
+    return acc;
+}
+
 // 64 strictly ordered adds of one chunk row (lane k < kTerms of the consumer wave), 16 terms per batch in two
 // ping-pong register sets.  The compiler hoists every ds_read of the unrolled chunk to its top if it may (64 VGPRs
 // of terms live at once — the difference between 4 and 5-6 waves per SIMD for this kernel); sched_barrier does not

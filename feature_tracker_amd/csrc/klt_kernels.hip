@@ -725,7 +725,16 @@ __device__ __forceinline__ uint8_t affine_h_index(int e) {
 // The 24 products of one pixel of the non-fast affine variants (affine_klt.cpp:229-256).  An unused pixel contributes exact zeros
 // to every sum: zeroing the five factors does that with five selects instead of one per product — every product is then +0 or
 // -0, and x + (+-0) == x for every value a sum can hold (the sums start at +0, and +0 + (-0) == +0).
-__device__ __forceinline__ void affine_all_terms(const KltParams &p, float *terms, int pxi, bool ok, float dt, float x, float y, float dx, float dy) {
+//
+// Layout: [pixel group of 4][24 sums][4 pixels], groups kAffineGroup floats apart (one float4 of padding spreads the groups over the
+// banks).  A pixel lane then writes its 24 products at IMMEDIATE offsets from one address (with the sum-major [24][Ppad] layout
+// and its run-time pitch the compiler kept 24 row pointers in registers and spent a VALU instruction on each store), and chain
+// lane k still reads four consecutive terms of its sum per ds_read_b128 (chain_groups).
+constexpr int kAffineGroup = kAffineTermsGroupFloats;
+static_assert(kAffineGroup == 4 * A_COUNT + 4, "ftk_device.h sizes the affine product groups for 24 sums");
+
+__device__ __forceinline__ void affine_all_terms(float *group_terms, int pxi, bool ok, float dt, float x, float y, float dx, float dy) {
+    float *terms = group_terms + (pxi >> 2) * kAffineGroup + (pxi & 3);
     x = ok ? x : 0.0f;
     y = ok ? y : 0.0f;
     dx = ok ? dx : 0.0f;
@@ -733,30 +742,30 @@ __device__ __forceinline__ void affine_all_terms(const KltParams &p, float *term
     dt = ok ? dt : 0.0f;
     const float xx = x * x, yy = y * y, xy = x * y;
     const float dxdx = dx * dx, dydy = dy * dy, dxdy = dx * dy;
-    terms[A_XX_DXDX * p.Ppad + pxi] = xx * dxdx;
-    terms[A_XX_DXDY * p.Ppad + pxi] = xx * dxdy;
-    terms[A_XY_DXDX * p.Ppad + pxi] = xy * dxdx;
-    terms[A_XY_DXDY * p.Ppad + pxi] = xy * dxdy;
-    terms[A_X_DXDX * p.Ppad + pxi] = x * dxdx;
-    terms[A_X_DXDY * p.Ppad + pxi] = x * dxdy;
-    terms[A_XX_DYDY * p.Ppad + pxi] = xx * dydy;
-    terms[A_XY_DYDY * p.Ppad + pxi] = xy * dydy;
-    terms[A_X_DYDY * p.Ppad + pxi] = x * dydy;
-    terms[A_YY_DXDX * p.Ppad + pxi] = yy * dxdx;
-    terms[A_YY_DXDY * p.Ppad + pxi] = yy * dxdy;
-    terms[A_Y_DXDX * p.Ppad + pxi] = y * dxdx;
-    terms[A_Y_DXDY * p.Ppad + pxi] = y * dxdy;
-    terms[A_YY_DYDY * p.Ppad + pxi] = yy * dydy;
-    terms[A_Y_DYDY * p.Ppad + pxi] = y * dydy;
-    terms[A_DXDX * p.Ppad + pxi] = dxdx;
-    terms[A_DXDY * p.Ppad + pxi] = dxdy;
-    terms[A_DYDY * p.Ppad + pxi] = dydy;
-    terms[(A_B0 + 0) * p.Ppad + pxi] = -(dt * x * dx);
-    terms[(A_B0 + 1) * p.Ppad + pxi] = -(dt * x * dy);
-    terms[(A_B0 + 2) * p.Ppad + pxi] = -(dt * y * dx);
-    terms[(A_B0 + 3) * p.Ppad + pxi] = -(dt * y * dy);
-    terms[(A_B0 + 4) * p.Ppad + pxi] = -(dt * dx);
-    terms[(A_B0 + 5) * p.Ppad + pxi] = -(dt * dy);
+    terms[4 * (A_XX_DXDX)] = xx * dxdx;
+    terms[4 * (A_XX_DXDY)] = xx * dxdy;
+    terms[4 * (A_XY_DXDX)] = xy * dxdx;
+    terms[4 * (A_XY_DXDY)] = xy * dxdy;
+    terms[4 * (A_X_DXDX)] = x * dxdx;
+    terms[4 * (A_X_DXDY)] = x * dxdy;
+    terms[4 * (A_XX_DYDY)] = xx * dydy;
+    terms[4 * (A_XY_DYDY)] = xy * dydy;
+    terms[4 * (A_X_DYDY)] = x * dydy;
+    terms[4 * (A_YY_DXDX)] = yy * dxdx;
+    terms[4 * (A_YY_DXDY)] = yy * dxdy;
+    terms[4 * (A_Y_DXDX)] = y * dxdx;
+    terms[4 * (A_Y_DXDY)] = y * dxdy;
+    terms[4 * (A_YY_DYDY)] = yy * dydy;
+    terms[4 * (A_Y_DYDY)] = y * dydy;
+    terms[4 * (A_DXDX)] = dxdx;
+    terms[4 * (A_DXDY)] = dxdy;
+    terms[4 * (A_DYDY)] = dydy;
+    terms[4 * (A_B0 + 0)] = -(dt * x * dx);
+    terms[4 * (A_B0 + 1)] = -(dt * x * dy);
+    terms[4 * (A_B0 + 2)] = -(dt * y * dx);
+    terms[4 * (A_B0 + 3)] = -(dt * y * dy);
+    terms[4 * (A_B0 + 4)] = -(dt * dx);
+    terms[4 * (A_B0 + 5)] = -(dt * dy);
 }
 
 __device__ __forceinline__ void affine_fill_matrix(const float *sums, float (&m)[6][6]) {
@@ -824,7 +833,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             float dx, dy, i_ref, i_cur;
             const bool ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
             const float dt = i_cur - i_ref;
-            affine_all_terms(p, c.terms, pxi, ok, dt, col_j, row_j, dx, dy);
+            affine_all_terms(c.terms, pxi, ok, dt, col_j, row_j, dx, dy);
             return ok;
         };
         uint32_t n_valid = 0;
@@ -839,7 +848,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             blk_sync(b);  // the terms (and the published counts) are visible
             FTK_STAMP_END(b, 3);
             if (b.wave == 0 && b.lane < A_COUNT) {
-                acc = chain_lane(c.terms + b.lane * p.Ppad, p.Ppad);
+                acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, p.Ppad >> 2, 0.0f);
             }
         } else {
             {
@@ -850,7 +859,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             FTK_STAMP_END(b, 3);
             if (b.wave == 0) {
                 if (b.lane < A_COUNT) {
-                    acc = chain_lane(c.terms + b.lane * p.Ppad, b.nt);
+                    acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, b.nt >> 2, 0.0f);
                 }
             } else {
                 const int step = b.nt - kWave;
@@ -863,7 +872,8 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             publish_count(b, n_valid, c.wave_cnt, iter);
             blk_sync(b);  // the remaining products and every wave's count are visible
             if (b.wave == 0 && b.lane < A_COUNT) {
-                acc = chain_lane(c.terms + b.lane * p.Ppad + b.nt, p.Ppad - b.nt, acc);
+                acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + (b.nt >> 2) * (kAffineGroup / 4) + b.lane,
+                                                     (p.Ppad - b.nt) >> 2, acc);
             }
         }
         if (b.wave == 0) {
@@ -1591,7 +1601,14 @@ __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
         lds_mine += (size_t)(threadIdx.x >> 6) * (p.group_lds_stride >> 2);
     }
     Carve c = carve_lds(lds_mine, K, p);
-    if (!(SOLO && p.lssd_chunked)) {
+    if (MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) {
+        // grouped layout (affine_all_terms): the pixels P .. Ppad-1 of the last group, all 24 sums
+        const int extra = p.Ppad - p.P;
+        for (int idx = b.tid; idx < A_COUNT * extra; idx += b.nt) {
+            const int k = idx / (extra > 0 ? extra : 1);
+            c.terms[((p.Ppad >> 2) - 1) * kAffineGroup + 4 * k + (4 - extra) + (idx - k * extra)] = 0.0f;
+        }
+    } else if (!(SOLO && p.lssd_chunked)) {
         zero_term_padding(b, c.terms, K, p);
     }
 
