@@ -265,14 +265,17 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // LSSD fast, one wave per feature, no luminance scaling: the chunked sweep / chain variant (a 64-pixel ring instead of all
     // P products of all nine chains in LDS; config 4: 304 -> 242 us)
     p.terms_floats = 0;
+    p.px_floats = 3;
     p.lssd_chunked = 0;
     if (model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
+        p.px_floats = 4;
         p.terms_floats = (p.Ppad / 4) * ftk::kAffineTermsGroupFloats;  // products grouped by four pixels (klt_kernels.hip affine_all_terms)
     }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
     if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && !p.consider_luminance && !(chunk_env && atoi(chunk_env) == 0)) {
         p.lssd_chunked = 1;
+        p.px_floats = 6;
         const int32_t epad = (p.E + 3) & ~3;
         p.terms_floats = epad > 9 * 68 ? epad : 9 * 68;  // the ring, or the extended patch that shares its space at level entry
         p.a0_floats = 0;                                  // (klt_kernels.hip lssd_level_fast_chunked)

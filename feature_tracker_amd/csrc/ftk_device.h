@@ -56,6 +56,7 @@ struct KltParams {
     uint32_t magic_rwc, magic_cwc;  // division by window cols
     uint32_t magic_rwq, magic_cwq;  // division by window cols / 4
     int32_t waves_per_feature;  // workgroup = 64 * waves_per_feature lanes
+    int32_t px_floats;          // per-pixel floats behind a0 in the generic kernel's LDS carve: 3, 4 (one float4 record: non-fast affine) or 6 (chunked LSSD)
     int32_t terms_floats;       // floats of the generic kernel's `terms` LDS region: K * Ppad, or the 64-pixel ring of a chunked variant
     int32_t lssd_chunked;       // LSSD fast, one wave per feature, no luminance scaling: chunked sweep / chain (klt_kernels.hip)
     int32_t features_per_group; // > 1 (only with waves_per_feature == 1): that many one-wave features share a workgroup, without

@@ -60,8 +60,9 @@ struct Carve {
 
 __host__ __device__ inline int pad4(int x) { return (x + 3) & ~3; }
 
-// Per-pixel floats after a0: dx, dy, one spare array — or, chunked LSSD, a float4 record + a float2 coordinate pair per pixel.
-__host__ __device__ inline int carve_px_floats(const KltParams &p) { return p.lssd_chunked ? 6 : 3; }
+// Per-pixel floats after a0 (KltParams::px_floats): 3 = dx, dy, one more array; 4 = one float4 record per pixel (non-fast affine);
+// 6 = a float4 record + a float2 coordinate pair (chunked LSSD).
+__host__ __device__ inline int carve_px_floats(const KltParams &p) { return p.px_floats; }
 
 __host__ __device__ inline size_t carve_bytes(int K, const KltParams &p) {
     const size_t epad = (size_t)pad4(p.E);
@@ -265,7 +266,9 @@ __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams 
 // the staged window only raises `miss` (returned workgroup-wide).  SLOW = true: every sample goes
 // through the general sampler (LDS window or global memory, identical arithmetic).  The slow pass
 // is a separate loop, so the hot loop carries no fallback code.
-template <int METHOD, bool SLOW>
+// PACKED: what an iteration reads of a pixel — {gx, gy, i_ref, used} — goes into ONE float4 at a1 (px_floats == 4) instead of three
+// float arrays and a byte array: one 16-byte read and one address per pixel and iteration instead of four.
+template <int METHOD, bool SLOW, bool PACKED>
 __device__ __forceinline__ bool nonfast_setup_pass(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
                                                    Carve &c) {
     const float4 *tab = reinterpret_cast<const float4 *>(c.a0);
@@ -306,21 +309,25 @@ __device__ __forceinline__ bool nonfast_setup_pass(const Blk &b, const KltParams
             ok = (flags & 1) != 0;
             miss = miss || (flags == 1);  // inside the image but not inside the staged window
         }
-        if (METHOD == FTK_METHOD_INVERSE) {
-            c.a1[pxi] = right - left;
-            c.a2[pxi] = bottom - top;
+        if (PACKED) {
+            reinterpret_cast<float4 *>(c.a1)[pxi] = make_float4(right - left, bottom - top, i_ref, __int_as_float(ok ? -1 : 0));
+        } else {
+            if (METHOD == FTK_METHOD_INVERSE) {
+                c.a1[pxi] = right - left;
+                c.a2[pxi] = bottom - top;
+            }
+            c.a3[pxi] = i_ref;
+            c.flagsP[pxi] = ok ? 1 : 0;
         }
-        c.a3[pxi] = i_ref;
-        c.flagsP[pxi] = ok ? 1 : 0;
     }
     return block_any(b, miss, c.wave_cnt, SLOW ? 3u : 2u);
 }
 
-template <int METHOD>
+template <int METHOD, bool PACKED = false>
 __device__ __forceinline__ void nonfast_level_setup(const Blk &b, const KltParams &p, const DevImage &ref, const Win &rw, float ref_u, float ref_v,
                                                     Carve &c) {
-    if (nonfast_setup_pass<METHOD, false>(b, p, ref, rw, ref_u, ref_v, c)) {
-        nonfast_setup_pass<METHOD, true>(b, p, ref, rw, ref_u, ref_v, c);
+    if (nonfast_setup_pass<METHOD, false, PACKED>(b, p, ref, rw, ref_u, ref_v, c)) {
+        nonfast_setup_pass<METHOD, true, PACKED>(b, p, ref, rw, ref_u, ref_v, c);
     }
 }
 
@@ -331,16 +338,28 @@ __device__ __forceinline__ void nonfast_level_setup(const Blk &b, const KltParam
 //           whose corner taps leave the window now and then: cheaper than redoing the whole phase)
 enum { kGatherHoisted = 0, kGatherGeneral = 1, kGatherInline = 2 };
 
-template <int METHOD, int MODE>
+template <int METHOD, int MODE, bool PACKED = false>
 __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &cw, const Carve &c, int pxi, float row_j, float col_j, float &gx,
                                                float &gy, float &i_ref, float &i_cur, bool &miss) {
-    bool ok = c.flagsP[pxi] != 0;
-    i_ref = c.a3[pxi];
+    bool ok;
+    float gx_ref, gy_ref;
+    if (PACKED) {
+        const float4 rec = reinterpret_cast<const float4 *>(c.a1)[pxi];
+        gx_ref = rec.x;
+        gy_ref = rec.y;
+        i_ref = rec.z;
+        ok = __float_as_int(rec.w) != 0;
+    } else {
+        ok = c.flagsP[pxi] != 0;
+        i_ref = c.a3[pxi];
+        gx_ref = (METHOD == FTK_METHOD_INVERSE) ? c.a1[pxi] : 0.0f;
+        gy_ref = (METHOD == FTK_METHOD_INVERSE) ? c.a2[pxi] : 0.0f;
+    }
     i_cur = 0.0f;
     if (MODE == kGatherGeneral) {
         if (METHOD == FTK_METHOD_INVERSE) {
-            gx = c.a1[pxi];
-            gy = c.a2[pxi];
+            gx = gx_ref;
+            gy = gy_ref;
             ok = sample(cur, cw, row_j, col_j, i_cur) && ok;
         } else {
             float left = 0.0f, right = 0.0f, top = 0.0f, bottom = 0.0f;
@@ -356,8 +375,8 @@ __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &c
     bool hit = true;
     bool valid;
     if (METHOD == FTK_METHOD_INVERSE) {
-        gx = c.a1[pxi];
-        gy = c.a2[pxi];
+        gx = gx_ref;
+        gy = gy_ref;
         valid = r0.valid && c0.valid;
         i_cur = tap(cw, r0, c0, hit);
         if (MODE == kGatherInline && valid && !hit) {
@@ -734,7 +753,7 @@ constexpr int kAffineGroup = kAffineTermsGroupFloats;
 static_assert(kAffineGroup == 4 * A_COUNT + 4, "ftk_device.h sizes the affine product groups for 24 sums");
 
 __device__ __forceinline__ void affine_all_terms(float *group_terms, int pxi, bool ok, float dt, float x, float y, float dx, float dy) {
-    float *terms = group_terms + (pxi >> 2) * kAffineGroup + (pxi & 3);
+    float *terms = group_terms + imul(pxi >> 2, kAffineGroup) + (pxi & 3);
     x = ok ? x : 0.0f;
     y = ok ? y : 0.0f;
     dx = ok ? dx : 0.0f;
@@ -809,7 +828,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
     stage_level_windows(b, p, ref, cur, ref_u, ref_v, s.cur_u, s.cur_v, c, rw, cw, (METHOD == FTK_METHOD_INVERSE) ? 3 : 1);
     bool cw_staged = true;
     FTK_STAMP_END(b, 0);
-    nonfast_level_setup<METHOD>(b, p, ref, rw, ref_u, ref_v, c);
+    nonfast_level_setup<METHOD, true>(b, p, ref, rw, ref_u, ref_v, c);
     FTK_STAMP_END(b, 1);
     const bool staged = !b.solo && b.nwaves > 1 && p.P > b.nt;
     if (b.tid < 36) {
@@ -831,7 +850,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             const float row_j = warped_y + s.cur_v;
             const float col_j = warped_x + s.cur_u;
             float dx, dy, i_ref, i_cur;
-            const bool ok = nonfast_gather<METHOD, kGatherInline>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
+            const bool ok = nonfast_gather<METHOD, kGatherInline, true>(cur, cw, c, pxi, row_j, col_j, dx, dy, i_ref, i_cur, miss_unused);
             const float dt = i_cur - i_ref;
             affine_all_terms(c.terms, pxi, ok, dt, col_j, row_j, dx, dy);
             return ok;
@@ -1541,14 +1560,12 @@ constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest firs
 #endif
 #define FTK_EU_ATTR __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU)))
 
-// The direct affine variant (6x6 LDLT + 24 chains + five current-image taps in registers) does not fit 128 VGPRs
-// without spilling; it runs at 3 waves per SIMD instead — and so does the multi-wave inverse one (128 VGPRs + 16 B of scratch at
-// 4: config 3 223 -> 219 us, 2 000 features 165 -> 160 us at 3).
+// (The non-fast affine variants used to need a cap of 3 — 168 VGPRs, 24 of them row pointers of the product stores; with the
+// grouped product layout, affine_all_terms, they fit 128 like the rest.)
 // SOLO: the one-wave-per-feature instantiation (workgroup = one wavefront): compile-time, so that no barrier and no cross-wave
 // exchange is left in it.
 template <int MODEL, int METHOD, bool SOLO>
-__global__ void __attribute__((amdgpu_waves_per_eu((MODEL == FTK_MODEL_AFFINE && (METHOD == FTK_METHOD_DIRECT || (METHOD == FTK_METHOD_INVERSE && !SOLO))) ? 3 : FTK_WAVES_PER_EU)))
-__launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
+__global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
     extern __shared__ float4 lds_raw[];
     Blk b;
     b.solo = SOLO;
