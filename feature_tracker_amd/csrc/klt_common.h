@@ -280,7 +280,7 @@ __device__ __forceinline__ void build_axis_tables(const Blk &b, const KltParams 
 
 // tap() on two table entries.
 __device__ __forceinline__ float tap_table(const Win &w, const float4 &ar, const float4 &ac) {
-    const int idx = __float_as_int(ar.x) * w.cols + __float_as_int(ac.x);
+    const int idx = imul(__float_as_int(ar.x), w.cols) + __float_as_int(ac.x);
     const unsigned a = w.data[idx];
     const unsigned bb = w.data[idx + w.cols];
     const float w_tl = ar.z * ac.z;
