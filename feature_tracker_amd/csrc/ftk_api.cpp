@@ -269,7 +269,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.lssd_chunked = 0;
     if (model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
         p.px_floats = 4;
-        p.terms_floats = (p.Ppad / 4) * ftk::kAffineTermsGroupFloats;  // products grouped by four pixels (klt_kernels.hip affine_all_terms)
+        p.terms_floats = ((p.Ppad / 4 + ftk::kAffineTermsRoundGroups - 1) / ftk::kAffineTermsRoundGroups) * ftk::kAffineTermsRoundGroups * ftk::kAffineTermsGroupFloats;  // products grouped by four pixels (klt_kernels.hip affine_all_terms)
     }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");

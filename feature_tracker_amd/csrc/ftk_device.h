@@ -12,6 +12,7 @@ namespace ftk {
 // Floats per pixel group (4 pixels x 24 sums + one float4 of padding) of the non-fast affine variants' product layout
 // (klt_kernels.hip affine_all_terms); the host sizes KltParams::terms_floats with it.
 constexpr int kAffineTermsGroupFloats = 4 * 24 + 4;
+constexpr int kAffineTermsRoundGroups = 4;  // groups are allocated in whole prefetch rounds of the chain (klt_kernels.hip FTK_CHAIN_ROUND)
 
 struct DevImage {
     const uint8_t *data;

@@ -780,42 +780,35 @@ __device__ __forceinline__ float chain_lane(const float *row, int Ppad, float ac
 
 // The same chain over a GROUPED layout: the terms of four consecutive pixels of one sum sit in one float4 and consecutive
 // groups lie kStride4 float4 apart ([group][sum][4 pixels], written by the pixel lanes with immediate offsets).  Same adds in the
-// same order as chain_lane; the prefetch is guarded at the tail because a stride's worth of overrun would leave the carve.
+// same order as chain_lane.  `rounds` rounds of kChainRound groups: the caller pads the group count to a multiple of kChainRound
+// with zero terms (x + 0 == x for every value a sum can hold), so no load is guarded and none runs past the last group — a
+// stride's worth of overrun per prefetched group would leave the carve.
 template <int kStride4>
-__device__ __forceinline__ void chain_load_groups(float4 (&q)[kChainRound], const float4 *t, int first, int n4) {
-    if (first + kChainRound <= n4) {
+__device__ __forceinline__ void chain_load_groups(float4 (&q)[kChainRound], const float4 *t) {
 #pragma unroll
-        for (int d = 0; d < kChainRound; ++d) {
-            q[d] = t[(first + d) * kStride4];
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < kChainRound; ++d) {
-            if (first + d < n4) {
-                q[d] = t[(first + d) * kStride4];
-            }
-        }
+    for (int d = 0; d < kChainRound; ++d) {
+        q[d] = t[d * kStride4];
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int kStride4>
-__device__ __forceinline__ float chain_groups(const float4 *t, int n4, float acc) {
-    float4 qa[kChainRound] = {}, qb[kChainRound] = {};
-    int i = 0;
-    chain_load_groups<kStride4>(qa, t, 0, n4);
-    for (; i + 3 * kChainRound <= n4; i += 2 * kChainRound) {  // everything the body loads is in range
-        chain_load_groups<kStride4>(qb, t, i + kChainRound, n4);
+__device__ __forceinline__ float chain_groups(const float4 *t, int rounds, float acc) {
+    // Branch-free body (a conditional load of a loop-carried register set costs a copy of the set per trip): the prefetch two
+    // rounds ahead always happens, from round 0 again once it would pass the end — in bounds, never consumed.
+    float4 qa[kChainRound], qb[kChainRound];
+    chain_load_groups<kStride4>(qa, t);
+    int r = 0;
+    for (; r + 2 <= rounds; r += 2) {
+        chain_load_groups<kStride4>(qb, t + (r + 1) * (kChainRound * kStride4));
         acc = chain_consume_all(acc, qa);
-        chain_load_groups<kStride4>(qa, t, i + 2 * kChainRound, n4);
+        const int ahead = (r + 2 < rounds) ? r + 2 : 0;  // wave-uniform: a scalar select
+        chain_load_groups<kStride4>(qa, t + ahead * (kChainRound * kStride4));
         acc = chain_consume_all(acc, qb);
     }
-    const int rem = n4 - i;  // 0 .. 3*kChainRound-1 groups left, the first kChainRound already in qa
-    chain_load_groups<kStride4>(qb, t, i + kChainRound, n4);
-    acc = chain_consume(acc, qa, rem);
-    chain_load_groups<kStride4>(qa, t, i + 2 * kChainRound, n4);
-    acc = chain_consume(acc, qb, rem - kChainRound);
-    acc = chain_consume(acc, qa, rem - 2 * kChainRound);
+    if (r < rounds) {
+        acc = chain_consume_all(acc, qa);  // odd count: round r was loaded as `ahead`
+    }
     return acc;
 }
 

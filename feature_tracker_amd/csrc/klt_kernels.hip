@@ -751,6 +751,10 @@ __device__ __forceinline__ uint8_t affine_h_index(int e) {
 // lane k still reads four consecutive terms of its sum per ds_read_b128 (chain_groups).
 constexpr int kAffineGroup = kAffineTermsGroupFloats;
 static_assert(kAffineGroup == 4 * A_COUNT + 4, "ftk_device.h sizes the affine product groups for 24 sums");
+// Groups are allocated (and chained) in rounds of kChainRound; the pixels P .. 4 * kChainRound * rounds - 1 hold zeros.
+static_assert(kChainRound == kAffineTermsRoundGroups, "ftk_device.h rounds the affine product groups to the chain's prefetch round");
+static_assert(kWave % (4 * kChainRound) == 0, "a workgroup's first pass (64 pixels per wave) covers whole rounds");
+__device__ __forceinline__ int affine_group_rounds(int Ppad) { return ((Ppad >> 2) + kChainRound - 1) / kChainRound; }
 
 __device__ __forceinline__ void affine_all_terms(float *group_terms, int pxi, bool ok, float dt, float x, float y, float dx, float dy) {
     float *terms = group_terms + imul(pxi >> 2, kAffineGroup) + (pxi & 3);
@@ -867,7 +871,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             blk_sync(b);  // the terms (and the published counts) are visible
             FTK_STAMP_END(b, 3);
             if (b.wave == 0 && b.lane < A_COUNT) {
-                acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, p.Ppad >> 2, 0.0f);
+                acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, affine_group_rounds(p.Ppad), 0.0f);
             }
         } else {
             {
@@ -878,7 +882,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             FTK_STAMP_END(b, 3);
             if (b.wave == 0) {
                 if (b.lane < A_COUNT) {
-                    acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, b.nt >> 2, 0.0f);
+                    acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, b.nt / (4 * kChainRound), 0.0f);
                 }
             } else {
                 const int step = b.nt - kWave;
@@ -892,7 +896,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             blk_sync(b);  // the remaining products and every wave's count are visible
             if (b.wave == 0 && b.lane < A_COUNT) {
                 acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + (b.nt >> 2) * (kAffineGroup / 4) + b.lane,
-                                                     (p.Ppad - b.nt) >> 2, acc);
+                                                     affine_group_rounds(p.Ppad) - b.nt / (4 * kChainRound), acc);
             }
         }
         if (b.wave == 0) {
@@ -1619,11 +1623,12 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     }
     Carve c = carve_lds(lds_mine, K, p);
     if (MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) {
-        // grouped layout (affine_all_terms): the pixels P .. Ppad-1 of the last group, all 24 sums
-        const int extra = p.Ppad - p.P;
-        for (int idx = b.tid; idx < A_COUNT * extra; idx += b.nt) {
-            const int k = idx / (extra > 0 ? extra : 1);
-            c.terms[((p.Ppad >> 2) - 1) * kAffineGroup + 4 * k + (4 - extra) + (idx - k * extra)] = 0.0f;
+        // grouped layout (affine_all_terms): the pixels behind the patch up to the end of the last round of groups, all 24 sums
+        const int first = p.P, end = affine_group_rounds(p.Ppad) * (4 * kChainRound);
+        for (int idx = b.tid; idx < A_COUNT * (end - first); idx += b.nt) {
+            const int k = idx / (end - first);
+            const int pxi = first + (idx - k * (end - first));
+            c.terms[(pxi >> 2) * kAffineGroup + 4 * k + (pxi & 3)] = 0.0f;
         }
     } else if (!(SOLO && p.lssd_chunked)) {
         zero_term_padding(b, c.terms, K, p);
