@@ -663,7 +663,8 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane) {
     Ldlt6 f;
     f.perm = pi;
     f.d_mine = 0.0f;
-    float dk[6];  // D(j), uniform
+    float dl[6];  // lane i: D(j) * L(i, j) — the product is formed on every lane BEFORE the broadcast (one multiply by a uniform,
+                  // off the critical path as soon as column j is known) instead of after it (uniform x uniform: a copy + a multiply)
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         float m_ik = bmat[k];
@@ -672,16 +673,16 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane) {
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < k; ++j) {
-                const float temp_j = dk[j] * bcast_lane(f.l[j], k);
+                const float temp_j = bcast_lane(dl[j], k);
                 s = (j == 0) ? f.l[0] * temp_j : s + f.l[j] * temp_j;
             }
             m_ik = degenerate ? m_ik : m_ik - s;
         }
         const float akk = bcast_lane(m_ik, k);
-        dk[k] = akk;
         f.d_mine = (me == k) ? akk : f.d_mine;
         const bool pivot_valid = fabsf(akk) > 0.0f;
         f.l[k] = (pivot_valid && !degenerate) ? m_ik / akk : m_ik;  // meaningful on lanes > k
+        dl[k] = akk * f.l[k];
     }
     return f;
 }
