@@ -1,3 +1,4 @@
+"""Experiment helper: per-row time difference of two bench_configs.py outputs."""
 import json, sys
 def load(p):
     d = {}
