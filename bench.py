@@ -147,9 +147,16 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         if use_dist and args.steps >= 2 and os.environ.get("FTK_BENCH_NO_GRAPH") != "1":
             ok = 1
             try:
+                # quiesce first: every collective issued so far has completed AND the process group's watchdog has had time to
+                # retire their work objects, so that it holds nothing to poll while the capture runs
+                torch.cuda.synchronize()
+                time.sleep(0.5)
                 side = torch.cuda.Stream(device=dev)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: the process group's watchdog thread polls its events with hipEventQuery while we capture; in the
+                # default (global) mode such a call from ANY thread invalidates the capture — an intermittent failure that grows
+                # with the length of the capture
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     gather_done = {}
                     for k in range(args.steps):
                         slot = slots[k & 1]
@@ -410,9 +417,16 @@ def main():
         if use_dist and args.steps >= 2 and os.environ.get("FTK_BENCH_NO_GRAPH") != "1":
             ok = 1
             try:
+                # quiesce first: every collective issued so far has completed AND the process group's watchdog has had time to
+                # retire their work objects, so that it holds nothing to poll while the capture runs
+                torch.cuda.synchronize()
+                time.sleep(0.5)
                 side = torch.cuda.Stream(device=dev)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
+                # thread_local: the process group's watchdog thread polls its events with hipEventQuery while we capture; in the
+                # default (global) mode such a call from ANY thread invalidates the capture — an intermittent failure that grows
+                # with the length of the capture
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     gather_done = {}
                     for k in range(args.steps):
                         slot = k & 1
