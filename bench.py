@@ -207,6 +207,7 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         torch.cuda.synchronize()
         gathered_ok = bool(torch.equal(guv.view(torch.int32), d_all.view(torch.int32)) and torch.equal(gst, d_all_st))
         assert gathered_ok, "gathered sharded result differs from the unsharded launch"
+    rccl_ranks = int(dist.get_world_size()) if use_dist else 1
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -214,7 +215,7 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
     if rank == 0:
         print(json.dumps({
             "metric": "tracked features/sec (sharded)", "value": n * args.steps / elapsed, "unit": "tracked features/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg['model']} KLT {cfg['method']}, {n} features in total sharded x{world}, {w}x{h}, {levels}-level pyramid, "
                                    f"{2 * half + 1}x{2 * half + 1} patch", "tracked_fraction": tracked,
@@ -279,6 +280,8 @@ def run_native_comm(args, cfg, world, rank, local_rank, dev):
         ok = bool(torch.equal(d_out[b:e].view(torch.int32), d_chk.view(torch.int32)) and torch.equal(d_sto[b:e], d_chk_st))
         assert ok, "gathered block differs from the local launch"
         tracked = float((d_sto == 1).float().mean().item())
+        from feature_tracker_amd import _native as NL
+        rccl_ranks = int(NL.lib().ftk_comm_world(comm.handle))  # the communicator libftk_hip.so itself holds
         comm.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -287,7 +290,7 @@ def run_native_comm(args, cfg, world, rank, local_rank, dev):
     if rank == 0:
         print(json.dumps({
             "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": n * args.steps / elapsed, "unit": "tracked features/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['model']} KLT {cfg['method']}, {n_local} features/GPU, {w}x{h}, {levels}-level pyramid, "
                                    f"{2 * half + 1}x{2 * half + 1} patch",
@@ -296,6 +299,90 @@ def run_native_comm(args, cfg, world, rank, local_rank, dev):
                        "tracked_fraction": tracked, "gathered_block_equals_local_launch": ok}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks: int, argv, timeout_s: float) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and return the worst exit code.
+    This parent never imports torch and never touches a GPU (no exec of a GPU-initialised process); rank 0's JSON line
+    goes to the inherited stdout, the other ranks print nothing there."""
+    import subprocess
+
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FTK_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+        if live and (rc != 0 or time.monotonic() > deadline):
+            # one rank failed (the others would wait in a collective for ever) or the launch timed out: end exactly the
+            # processes started above
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: the {n_ranks}-rank run did not finish within {timeout_s:.0f} s", file=sys.stderr, flush=True)
+            for p in live:
+                p.terminate()
+            t_kill = time.monotonic() + 10.0
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except Exception:
+                    p.kill()
+                    p.wait()
+            live = []
+        elif live:
+            time.sleep(0.05)
+    return rc
+
+
+def dry_launch(args, world: int, rank: int) -> None:
+    """--dry-launch: the rank plumbing of an N-rank run without any device work (gloo on the CPU): every rank joins the
+    process group, one all-reduce counts the ranks, one all-gather moves a packed result shard of the workload's size, and rank 0
+    prints the line's launch fields.  This is what the CPU test of `bench.py --gpus 2` runs."""
+    import torch
+    import torch.distributed as dist
+
+    from feature_tracker_amd import dist as FD
+    from feature_tracker_amd import synth
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(ones)
+    n = synth.CONFIGS[args.workload]["n"]
+    packed = torch.full((FD.packed_bytes(n),), rank, dtype=torch.uint8)
+    gathered = FD.all_gather_results(packed, world, force_collective=True)
+    per = FD.packed_bytes(n)
+    shards_ok = all(bool((gathered[r * per:(r + 1) * per] == r).all()) for r in range(world))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": int(dist.get_world_size()), "ranks_counted": int(ones.item()),
+                          "backend": "gloo", "all_gather_ok": shards_ok, "self_launched": os.environ.get("FTK_BENCH_SELF_LAUNCHED") == "1",
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.destroy_process_group()
+    if not shards_ok or int(ones.item()) != world:
+        raise SystemExit(4)
 
 
 def main():
@@ -314,7 +401,26 @@ def main():
                          "of torch.distributed's all_gather_into_tensor; same workload, same metric ($FTK_BENCH_NATIVE_COMM=1 selects it too)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.0,
                     help="experiment knob: keep the device busy with untimed steps for this long before the W warmup steps (clock ramp study)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rank plumbing only: gloo on the CPU, no device work (CPU test of the N-rank launch)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 runs: seconds before the ranks are ended")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # Who starts the ranks.  Under a launcher (torchrun: WORLD_SIZE is set) this process IS one rank.  Without one,
+    # `--gpus N > 1` starts its own N ranks as children BEFORE anything touches torch or HIP, so that the plain
+    # `python bench.py --gpus 8` measures eight GPUs.  Any other disagreement between --gpus and the world is an error:
+    # a run must never print a line whose n_gpus differs from what was asked for.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run (the reported n_gpus would be wrong)")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
 
     import torch
     import torch.distributed as dist
@@ -324,11 +430,8 @@ def main():
     from feature_tracker_amd import dist as FD
     from feature_tracker_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < world:  # counting devices does not initialise the GPU
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -495,6 +598,7 @@ def main():
             for slot in range(min(2, args.steps)):
                 assert torch.equal(gathered2[slot][rank * per:(rank + 1) * per], packed2[slot]), "all-gather did not return this rank's shard"
 
+    rccl_ranks = int(dist.get_world_size()) if use_dist else 1  # ranks of the process group the per-step all-gather ran over
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -514,7 +618,7 @@ def main():
         cpu_uv, cpu_st, cpu_it, _ = oracle_once(cfg, ref_levels, cur_levels, uv)
         out = {
             "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": value, "unit": "tracked features/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['model']} KLT {cfg['method']}, {n} features/GPU, {w}x{h}, {levels}-level pyramid, "
                                    f"{2 * half + 1}x{2 * half + 1} patch", "parallelism": (f"features sharded x{world}, pyramids replicated, one RCCL all-gather of packed (uv,status) per step"
