@@ -24,7 +24,7 @@ METHODS = {"inverse": 0, "direct": 1, "fast": 2, "sse": 3, "neon": 4}
 
 # every symbol include/ftk.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "ftk_abi_version", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
+    "ftk_abi_version", "ftk_build_info", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize",
     "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
     "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_ldlt6_solve", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
     l = C.CDLL(path)
     vp, i32, u32p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)
     l.ftk_abi_version.restype = C.c_int
+    l.ftk_build_info.restype = C.c_char_p
     l.ftk_device_count.restype = C.c_int
     l.ftk_context_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     l.ftk_context_destroy.argtypes = [vp]
@@ -161,6 +162,12 @@ def lib() -> C.CDLL:
     l.ftk_hamming_match_sharded_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, C.c_float, vp, vp, i32, i32, vp]
     _lib = l
     return l
+
+
+def build_info() -> dict:
+    """ftk_build_info() as a dict: source_hash, compiler, arch, mllvm (accepted internal LLVM options), mllvm_rejected."""
+    text = lib().ftk_build_info().decode()
+    return {k.strip(): v.strip() for k, v in (item.split("=", 1) for item in text.split(";") if "=" in item)}
 
 
 def check(rc: int, ctx_handle=None) -> None:

@@ -713,6 +713,9 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                 for (int k = 0; k < 2; ++k) {
                     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_iters[k]), sizeof(uint32_t) * cap));
                     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_order[k]), sizeof(int32_t) * cap));
+                    // never-written entries must still be valid feature ids (0) and valid counts, whatever happens to a launch
+                    FTK_HIP(ctx, hipMemsetAsync(ctx->sched_iters[k], 0, sizeof(uint32_t) * cap, ctx->stream));
+                    FTK_HIP(ctx, hipMemsetAsync(ctx->sched_order[k], 0, sizeof(int32_t) * cap, ctx->stream));
                 }
                 ctx->sched_capacity = cap;
             }
@@ -792,7 +795,14 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     }
     return FTK_OK;
 #else
-    FTK_HIP(ctx, ftk::klt_launch(model, opt->method, p, ctx->stream));
+    const hipError_t launch_rc = ftk::klt_launch(model, opt->method, p, ctx->stream);
+    if (launch_rc != hipSuccess) {
+        // The launch-order state advanced above assumed this launch would write its iteration counts and (from the second call
+        // on) a permutation: it did neither, so the history starts over — the next call must not install an order nobody wrote.
+        ctx->sched_calls = 0;
+        ctx->sched_n = 0;
+        return fail(ctx, launch_rc == hipErrorOutOfMemory ? FTK_E_OUT_OF_MEMORY : FTK_E_HIP, "klt launch failed: %s", hipGetErrorString(launch_rc));
+    }
     return FTK_OK;
 #endif
 }

@@ -168,7 +168,11 @@ int ftk_comm_create(ftk_context *ctx, int32_t rank, int32_t world, const void *u
             delete c;
             return ftk_fail(ctx, FTK_E_UNSUPPORTED, "comm_create: %s", api.error.c_str());
         }
-        FTK_HIP(ctx, hipSetDevice(ctx->device));
+        const hipError_t de = hipSetDevice(ctx->device);
+        if (de != hipSuccess) {
+            delete c;
+            return ftk_fail(ctx, FTK_E_HIP, "comm_create: hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(de));
+        }
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof(id));
         const ncclResult_t r = api.CommInitRank(&c->comm, world, id, rank);
@@ -290,6 +294,14 @@ int ftk_klt_track_sharded_device(ftk_context *ctx, ftk_comm *comm, int model, co
     rc = ftk_klt_track_shard_device(ctx, comm->rank, comm->world, model, opt, ref, cur, d_ref_uv, d_cur_uv_in, d_status_in, n, prior,
                                     consider_luminance, single_level, comm->packed, d_iters);
     if (rc != FTK_OK) {
+        // The peers are (or will be) inside the collective: leaving without it would block them for ever.  Contribute a POISONED
+        // shard instead — every byte 0xFF: status 255 is no TrackStatus and (u, v) are NaNs — so that every rank, this one
+        // included, sees the failure in the data (the host-buffer entry turns it into an error code), and report the local error.
+        const std::string local_error = ctx->error;
+        if (hipMemsetAsync(comm->packed, 0xFF, shard, ctx->stream) == hipSuccess && all_gather(comm, shard) == FTK_OK) {
+            (void)ftk_klt_unpack_shards_device(ctx, comm->gathered, n, comm->world, d_cur_uv_out, d_status_out);
+        }
+        ctx->error = local_error;
         return rc;
     }
     rc = all_gather(comm, shard);
@@ -347,6 +359,21 @@ int ftk_klt_track_sharded(ftk_context *ctx, ftk_comm *comm, int model, const ftk
         FTK_HIP(ctx, hipMemcpyAsync(iters, d_it, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     }
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // A rank whose tracker launch failed contributes a poisoned shard (every byte 0xFF) instead of leaving its peers blocked in
+    // the collective: report it here, on every rank, instead of handing NaNs to the caller.
+    for (int32_t r = 0; r < comm->world; ++r) {
+        int32_t b = 0, e = 0;
+        shard_range(n, comm->world, r, &b, &e);
+        bool poisoned = e > b;
+        for (int32_t i = b; i < e && poisoned; ++i) {
+            uint32_t bits[2];
+            memcpy(bits, cur_uv + 2 * (size_t)i, sizeof(bits));
+            poisoned = status[i] == 0xFF && bits[0] == 0xFFFFFFFFu && bits[1] == 0xFFFFFFFFu;
+        }
+        if (poisoned) {
+            return ftk_fail(ctx, FTK_E_HIP, "klt_track_sharded: rank %d of %d reported a failed tracker launch (poisoned result shard)", r, comm->world);
+        }
+    }
     return FTK_OK;
 }
 

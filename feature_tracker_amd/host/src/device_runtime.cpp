@@ -1,8 +1,11 @@
 #include "device_runtime.h"
 
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -17,12 +20,14 @@ bool g_tried = false;  // a failed creation (no device) is not retried on every 
 std::string g_error;
 
 ftk_comm *g_comm = nullptr;
-bool g_comm_tried = false;
+bool g_comm_tried = false;  // one rendezvous per process: a failed one is reported on every call, not repeated (it can block for minutes)
+std::string g_comm_error;
 
 int EnvInt(const char *primary, const char *secondary, int fallback) {
     for (const char *name : {primary, secondary}) {
         if (name != nullptr) {
-            if (const char *v = std::getenv(name)) {
+            const char *v = std::getenv(name);
+            if (v != nullptr && v[0] != '\0') {
                 return std::atoi(v);
             }
         }
@@ -70,54 +75,148 @@ ftk_context *SharedContext(std::string *error) {
     return g_ctx;
 }
 
+namespace {
+// The id file: magic, a per-launch nonce, the 128-byte RCCL unique id.  The nonce is what tells this launch's file from one a
+// previous (or crashed) run left under the same path: readers wait until a file with THEIR nonce appears.
+constexpr char kIdMagic[8] = {'F', 'T', 'K', 'I', 'D', '0', '0', '2'};
+constexpr size_t kNonceBytes = 64;
+struct IdFile {
+    char magic[8];
+    char nonce[kNonceBytes];
+    unsigned char id[FTK_UNIQUE_ID_BYTES];
+};
+
+void PadNonce(const std::string &nonce, char out[kNonceBytes]) {
+    std::memset(out, 0, kNonceBytes);
+    std::memcpy(out, nonce.data(), nonce.size() < kNonceBytes - 1 ? nonce.size() : kNonceBytes - 1);
+}
+}  // namespace
+
+std::string CommLaunchNonce() {
+    for (const char *name : {"FTK_COMM_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
+        const char *v = std::getenv(name);
+        if (v != nullptr && v[0] != '\0') {
+            return std::string(name) + "=" + v;
+        }
+    }
+    return std::string();
+}
+
+bool PublishCommId(const std::string &path, const std::string &nonce, const unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error) {
+    // A file of an earlier run must never be read as this run's: it is removed BEFORE the new one exists (callers remove it
+    // before they even generate the id); the new one is written under a temporary name and renamed in, so that a reader never
+    // sees a partial file.
+    std::remove(path.c_str());
+    IdFile file;
+    std::memcpy(file.magic, kIdMagic, sizeof(kIdMagic));
+    PadNonce(nonce, file.nonce);
+    std::memcpy(file.id, id, FTK_UNIQUE_ID_BYTES);
+    const std::string tmp = path + ".tmp." + std::to_string(static_cast<long>(getpid()));
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    const bool ok = f != nullptr && std::fwrite(&file, 1, sizeof(file), f) == sizeof(file);
+    if ((f != nullptr && std::fclose(f) != 0) || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+        std::remove(tmp.c_str());
+        if (error != nullptr) {
+            *error = "cannot write the RCCL unique id to " + path;
+        }
+        return false;
+    }
+    return true;
+}
+
+bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_ms, unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error) {
+    char want[kNonceBytes];
+    PadNonce(nonce, want);
+    bool stale_seen = false;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (;;) {
+        if (FILE *f = std::fopen(path.c_str(), "rb")) {
+            IdFile file;
+            const bool whole = std::fread(&file, 1, sizeof(file), f) == sizeof(file) && std::memcmp(file.magic, kIdMagic, sizeof(kIdMagic)) == 0;
+            std::fclose(f);
+            if (whole && std::memcmp(file.nonce, want, kNonceBytes) == 0) {
+                std::memcpy(id, file.id, FTK_UNIQUE_ID_BYTES);
+                return true;
+            }
+            stale_seen = true;  // another launch's file, an old format or a foreign file: rank 0 of THIS launch replaces it
+        }
+        if (std::chrono::steady_clock::now() >= deadline) {
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+    if (error != nullptr) {
+        *error = "timed out waiting for the RCCL unique id in " + path +
+                 (stale_seen ? " (the file there belongs to another launch: its nonce differs from this rank's)" : "");
+    }
+    return false;
+}
+
+int CommOptIn(int *rank, int *world, std::string *error) {
+    // Opt-in is EXPLICIT: the sharded mode is only valid when every rank passes identical pyramids and feature lists, which the
+    // generic launcher variables cannot establish (a data-parallel job under torchrun tracks DIFFERENT frames per rank).  So only
+    // FTK_* variables switch it on — FTK_COMM_ID_FILE, or FTK_WORLD_SIZE > 1, which then demands the file — and RANK / WORLD_SIZE
+    // are read as defaults only once that opt-in is present.  LOCAL_RANK stays the device default (SharedContext).
+    const char *id_file = std::getenv("FTK_COMM_ID_FILE");
+    if (id_file != nullptr && id_file[0] == '\0') {
+        id_file = nullptr;
+    }
+    const int ftk_world = EnvInt("FTK_WORLD_SIZE", nullptr, 0);
+    if (id_file == nullptr && ftk_world <= 1) {
+        return 0;
+    }
+    *world = ftk_world > 0 ? ftk_world : EnvInt("WORLD_SIZE", nullptr, 1);
+    *rank = EnvInt("FTK_RANK", "RANK", 0);
+    if (id_file == nullptr) {
+        *error = "FTK_WORLD_SIZE > 1 needs FTK_COMM_ID_FILE (a path every rank can read, unique per launch) to hand out the RCCL unique id";
+        return -1;
+    }
+    if (*world < 1 || *rank < 0 || *rank >= *world) {
+        *error = "FTK_RANK / FTK_WORLD_SIZE: rank " + std::to_string(*rank) + " is not in [0, " + std::to_string(*world) + ")";
+        return -1;
+    }
+    return 1;
+}
+
 ftk_comm *SharedComm(ftk_context *ctx, std::string *error) {
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_comm != nullptr || g_comm_tried) {
-        if (g_comm == nullptr && !g_error.empty() && error != nullptr) {
-            *error = g_error;
+        if (g_comm == nullptr && !g_comm_error.empty() && error != nullptr) {
+            *error = g_comm_error;
         }
         return g_comm;
     }
     g_comm_tried = true;
-    const int world = EnvInt("FTK_WORLD_SIZE", "WORLD_SIZE", 1), rank = EnvInt("FTK_RANK", "RANK", 0);
-    const char *id_file = std::getenv("FTK_COMM_ID_FILE");
-    if (world <= 1 && id_file == nullptr) {
-        return nullptr;  // a single process: the plain calls
+    int rank = 0, world = 1;
+    const int opt_in = CommOptIn(&rank, &world, &g_comm_error);
+    if (opt_in == 0) {
+        return nullptr;  // a single process, or the ranks of somebody else's job: the plain calls
     }
+    const char *id_file = std::getenv("FTK_COMM_ID_FILE");
+    const std::string nonce = CommLaunchNonce();
     unsigned char id[FTK_UNIQUE_ID_BYTES];
-    if (id_file == nullptr) {
-        g_error = "FTK_WORLD_SIZE > 1 needs FTK_COMM_ID_FILE (a path every rank can read) to hand out the RCCL unique id";
+    if (opt_in < 0) {
+        id_file = nullptr;  // g_comm_error says why
     } else if (rank == 0) {
-        // written under a temporary name and renamed, so that a reader never sees a partial id
-        const std::string tmp = std::string(id_file) + ".tmp";
-        FILE *f = nullptr;
+        std::remove(id_file);  // before the new id exists, so that the window in which a stale file can be read is as short as possible
         if (ftk_comm_unique_id(id) != FTK_OK) {
-            g_error = ftk_last_error(nullptr);
-        } else if ((f = std::fopen(tmp.c_str(), "wb")) == nullptr || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 ||
-                   std::rename(tmp.c_str(), id_file) != 0) {
-            g_error = std::string("cannot write the RCCL unique id to ") + id_file;
+            g_comm_error = ftk_last_error(nullptr);
+        } else {
+            PublishCommId(id_file, nonce, id, &g_comm_error);
         }
     } else {
-        bool got = false;
-        for (int attempt = 0; attempt < 1200 && !got; ++attempt) {  // up to two minutes for rank 0 to come up
-            if (FILE *f = std::fopen(id_file, "rb")) {
-                got = std::fread(id, 1, sizeof(id), f) == sizeof(id);
-                std::fclose(f);
-            }
-            if (!got) {
-                std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            }
-        }
-        if (!got) {
-            g_error = std::string("timed out waiting for the RCCL unique id in ") + id_file;
-        }
+        AwaitCommId(id_file, nonce, 120000, id, &g_comm_error);  // up to two minutes for rank 0 to come up
     }
-    if (g_error.empty() && ftk_comm_create(ctx, rank, world, id, &g_comm) != FTK_OK) {
+    if (g_comm_error.empty() && ftk_comm_create(ctx, rank, world, id, &g_comm) != FTK_OK) {
         g_comm = nullptr;
-        g_error = ftk_last_error(ctx);
+        g_comm_error = ftk_last_error(ctx);
+    }
+    // ncclCommInitRank is collective: once it has returned on rank 0 every rank has read the id, and the file has done its job.
+    if (rank == 0 && id_file != nullptr) {
+        std::remove(id_file);
     }
     if (g_comm == nullptr && error != nullptr) {
-        *error = g_error;
+        *error = g_comm_error;
     }
     return g_comm;
 }

@@ -18,13 +18,26 @@ namespace device {
 // Returns the shared context, creating it on first use; nullptr (and *error filled) when no HIP
 // device is usable.  There is no CPU fallback: callers report the error and return false.
 ftk_context *SharedContext(std::string *error);
-// One process per GPU: when FTK_WORLD_SIZE (default 1) says this process is one rank of several — or FTK_COMM_ID_FILE is set,
-// which exercises the same path at world size 1 — the trackers shard their feature list over the ranks and every process
-// receives the complete result (ftk_klt_track_sharded: RCCL all-gather issued by libftk_hip.so).  Environment: FTK_RANK,
-// FTK_WORLD_SIZE (RANK / WORLD_SIZE of a torchrun-style launcher are honoured too), FTK_DEVICE (default: LOCAL_RANK, else 0) and
-// FTK_COMM_ID_FILE, a path all ranks can read: rank 0 writes the 128-byte RCCL unique id there, the others wait for it.
+// One process per GPU, EXPLICIT opt-in: when FTK_COMM_ID_FILE is set (world size 1 included: same path through RCCL) — or
+// FTK_WORLD_SIZE > 1, which then requires it — the trackers shard their feature list over the ranks and every process receives
+// the complete result (ftk_klt_track_sharded: RCCL all-gather issued by libftk_hip.so).  That is only valid when EVERY rank passes
+// the same pyramids and the same feature list, which a launcher's generic WORLD_SIZE / RANK cannot tell (the ranks of a
+// data-parallel job track different frames): those two are therefore read only as DEFAULTS for FTK_WORLD_SIZE / FTK_RANK once
+// the opt-in is present.  FTK_DEVICE (default: LOCAL_RANK, else 0) picks the GPU.
+// FTK_COMM_ID_FILE is a path all ranks can read and that is UNIQUE PER LAUNCH: rank 0 removes whatever is there, writes
+// {magic, launch nonce, the 128-byte RCCL unique id} under a temporary name, renames it in, and removes it again once the
+// communicator exists; the others wait (up to two minutes) for a file carrying THEIR nonce, so a file left by a crashed or
+// earlier run under the same path is not mistaken for this run's.  The nonce is $FTK_COMM_NONCE, else $TORCHELASTIC_RUN_ID, else
+// $MASTER_PORT, else empty (then only the path's uniqueness protects the launch).
+// One rendezvous per process: a failure is reported by every later call, not retried (it can block for minutes).
 // Returns nullptr (and no error) for a single process; nullptr with *error filled when the communicator cannot be made.
 ftk_comm *SharedComm(ftk_context *ctx, std::string *error);
+// The rendezvous' two halves and its nonce (no device needed; tests/test_host_logic_cpu.py drives them through comm_id_cli).
+// 0: the environment does not opt in (plain single-process calls); 1: it does, *rank / *world filled; -1: it does but is inconsistent (*error).
+int CommOptIn(int *rank, int *world, std::string *error);
+std::string CommLaunchNonce();
+bool PublishCommId(const std::string &path, const std::string &nonce, const unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error);
+bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_ms, unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error);
 // Text of the last failure on the shared context.
 std::string LastError();
 // Device twin of a host ImagePyramid: uploaded once per generation of the host object, then reused by

@@ -84,6 +84,10 @@ typedef struct ftk_pyramid ftk_pyramid;
 /* ---- runtime ----------------------------------------------------------------------------- */
 
 int ftk_abi_version(void);
+/* "key=value; ..." text describing this build of the library: source_hash (over every source file of libftk_hip.so; bench.py
+ * compares it with the hash recorded next to committed counter figures), compiler (hipcc's version line), arch, mllvm (the
+ * internal LLVM options the toolchain accepted when the library was built — each is probed, csrc/Makefile) and mllvm_rejected. */
+const char *ftk_build_info(void);
 /* Number of visible HIP devices (0 when none / no driver). Does not create a HIP context. */
 int ftk_device_count(void);
 /* stream: a hipStream_t to launch on (borrowed, e.g. a torch stream), or NULL to let the context
@@ -280,6 +284,12 @@ int ftk_comm_world(const ftk_comm *comm);
  * on return (asynchronously, stream-ordered) every rank's d_cur_uv_out / d_status_out hold all n results.
  * Launches: the tracker kernel on this rank's block, ncclAllGather of the packed shards, one scatter kernel.
  * d_iters (optional, n entries) receives only this rank's block.
+ * Failure symmetry: a rank whose tracker launch fails still takes part in the collective with a POISONED shard (every byte
+ * 0xFF: status 255, NaN coordinates) and returns its error, so its peers finish instead of blocking; the host-buffer form below
+ * turns a poisoned block into FTK_E_HIP on every rank, the device form leaves it visible in the data.  (A rank that cannot even
+ * allocate its exchange buffers cannot contribute: destroy the communicator's process group in that case.)
+ * HIP-graph capture: the exchange buffers grow on demand (hipFree / hipMalloc, which a capture does not allow), so make ONE eager
+ * call with the largest n before capturing any.
  */
 int ftk_klt_track_sharded_device(ftk_context *ctx, ftk_comm *comm, int model, const ftk_klt_options *opt, const ftk_pyramid *ref,
                                  const ftk_pyramid *cur, const float *d_ref_uv, const float *d_cur_uv_in, float *d_cur_uv_out,

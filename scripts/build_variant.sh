@@ -13,6 +13,7 @@ hipcc $F -mllvm -amdgpu-sched-strategy=max-ilp -c -o $T/direct_kernels.o direct_
 hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -c -o $T/matcher_kernels.o matcher_kernels.hip & pids="$pids $!"  # as in the Makefile
 hipcc $F -x hip -c -o $T/ftk_api.o ftk_api.cpp & pids="$pids $!"
 hipcc $F -x hip -c -o $T/ftk_comm.o ftk_comm.cpp
+make -s ftk_build_info.inc && hipcc -O2 -std=c++17 -fPIC -c -o $T/ftk_build_info.o ftk_build_info.cpp  # the hash is the tree's; the tag names the variant
 for p in $pids; do wait $p; done  # a failed compile fails the script (set -e)
 mkdir -p diag
 hipcc -shared -fPIC --offload-arch=gfx950 -o diag/libftk_hip_$TAG.so $T/*.o -ldl

@@ -306,7 +306,9 @@ def test_cpp_tracker_as_one_rank_of_a_communicator(tmp_path, oracle, model, meth
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
     uv = scenes.features(203, 320, 240, half=5)
     env = {"FTK_WORLD_SIZE": "1", "FTK_RANK": "0", "FTK_COMM_ID_FILE": str(tmp_path / "rccl_id.bin")}
+    with open(tmp_path / "rccl_id.bin", "wb") as f:
+        f.write(b"\x55" * 128)  # a stale file of an earlier launch under the same path: rank 0 replaces it
     c, s, it, head = run_track_cli(tmp_path, model, method, 3, 5, ref_levels[0], cur_levels[0], uv, max_points=150, env=env)
-    assert os.path.getsize(tmp_path / "rccl_id.bin") == 128  # rank 0 published the unique id
+    assert not os.path.exists(tmp_path / "rccl_id.bin")  # rank 0 published the unique id and removed the file once the communicator existed
     ok, oc, os_, oit = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=5, max_points=150)
     assert np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and np.array_equal(it, oit)

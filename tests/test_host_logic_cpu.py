@@ -205,3 +205,59 @@ def test_argument_errors_are_raised_before_any_device_call(ftk):
         dm.TrackFeatures(FakePyramid(), FakePyramid(), [1, 1, 0, 0], np.zeros((2, 3), np.float32), np.zeros((5, 2), np.float32))  # fewer points than features
     ok, idx = ftk.CosineMatcher().NearbyMatch(np.zeros((3, 8), np.float32), np.zeros((2, 8), np.float32), np.zeros((2, 2)), np.zeros((2, 2)))
     assert ok is False  # descriptor_matcher.h:95 — pred size != ref size
+
+
+# ---- the C++ layer's multi-GPU rendezvous (host/src/device_runtime.cpp, SharedComm): no device needed ----
+
+COMM_CLI = os.path.join(ROOT, "feature_tracker_amd", "host", "build", "comm_id_cli")
+LAUNCHER_VARS = ("FTK_WORLD_SIZE", "FTK_RANK", "FTK_COMM_ID_FILE", "FTK_COMM_NONCE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")
+
+
+def _comm_cli(args, timeout=30, **env):
+    assert os.path.exists(COMM_CLI), "host layer not built (python -c 'import __graft_entry__ as g; g.build()')"
+    base = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    return subprocess.run([COMM_CLI, *args], capture_output=True, text=True, timeout=timeout, env=dict(base, **env))
+
+
+def test_sharded_mode_needs_an_explicit_ftk_opt_in():
+    # a torchrun-style environment alone (data-parallel job: every rank tracks DIFFERENT frames) must NOT switch the trackers to
+    # the sharded path, nor make them fail
+    assert _comm_cli(["optin"], WORLD_SIZE="8", RANK="3", LOCAL_RANK="3", MASTER_PORT="29500").stdout.strip() == "off"
+    assert _comm_cli(["optin"]).stdout.strip() == "off"
+    assert _comm_cli(["optin"], FTK_WORLD_SIZE="1").stdout.strip() == "off"
+    # FTK_WORLD_SIZE > 1 is explicit but incomplete without the id file
+    assert _comm_cli(["optin"], FTK_WORLD_SIZE="2", FTK_RANK="1").stdout.startswith("error ")
+    # the id file is the opt-in; launcher variables then serve as defaults, FTK_* win
+    assert _comm_cli(["optin"], FTK_COMM_ID_FILE="/tmp/x", WORLD_SIZE="8", RANK="3").stdout.strip() == "on 3 8"
+    assert _comm_cli(["optin"], FTK_COMM_ID_FILE="/tmp/x", WORLD_SIZE="8", RANK="3", FTK_WORLD_SIZE="2", FTK_RANK="1").stdout.strip() == "on 1 2"
+    assert _comm_cli(["optin"], FTK_COMM_ID_FILE="/tmp/x").stdout.strip() == "on 0 1"
+    assert _comm_cli(["optin"], FTK_COMM_ID_FILE="/tmp/x", FTK_WORLD_SIZE="2", FTK_RANK="2").stdout.startswith("error ")
+
+
+def test_stale_id_file_is_not_mistaken_for_this_launch(tmp_path):
+    path = str(tmp_path / "rccl_id.bin")
+    # an earlier launch (nonce A) left its file behind; a reader of launch B must not take it ...
+    assert _comm_cli(["publish", path, "17"], FTK_COMM_NONCE="A").returncode == 0
+    late = _comm_cli(["await", path, "300"], FTK_COMM_NONCE="B")
+    assert late.returncode == 2 and "another launch" in late.stderr
+    # ... nor a round-2 style file (the bare 128 bytes), nor a truncated one
+    with open(path, "wb") as f:
+        f.write(bytes(128))
+    assert _comm_cli(["await", path, "200"], FTK_COMM_NONCE="B").returncode == 2
+    # launch B's rank 0 replaces the file while a reader is already waiting: the reader gets B's id, not A's
+    assert _comm_cli(["publish", path, "17"], FTK_COMM_NONCE="A").returncode == 0
+    base = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    reader = subprocess.Popen([COMM_CLI, "await", path, "20000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(base, FTK_COMM_NONCE="B"))
+    import time
+    time.sleep(0.5)
+    assert reader.poll() is None  # still waiting: A's file does not satisfy it
+    assert _comm_cli(["publish", path, "42"], FTK_COMM_NONCE="B").returncode == 0
+    out, err = reader.communicate(timeout=30)
+    assert reader.returncode == 0 and out.strip() == "42", err
+    # the nonce falls back to what torchrun exports
+    assert _comm_cli(["nonce"], MASTER_PORT="29512").stdout.strip() == "MASTER_PORT=29512"
+    assert _comm_cli(["nonce"], MASTER_PORT="29512", TORCHELASTIC_RUN_ID="job7").stdout.strip() == "TORCHELASTIC_RUN_ID=job7"
+    assert _comm_cli(["nonce"], MASTER_PORT="29512", FTK_COMM_NONCE="n").stdout.strip() == "FTK_COMM_NONCE=n"
+    assert _comm_cli(["nonce"]).stdout.strip() == ""
+    # no temporary files are left next to the id file
+    assert sorted(os.listdir(tmp_path)) == ["rccl_id.bin"]
