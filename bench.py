@@ -52,25 +52,38 @@ def algorithmic_bytes(iters: np.ndarray, levels: int, half: int, method: str) ->
     return int(iters.size * (levels * r + 26) + int(iters.astype(np.int64).sum()) * c)
 
 
-VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz
+# Vector-ALU issue peak: 256 CUs x 4 SIMD-32.  The datasheet rate is one wave64 instruction per 2 cycles per SIMD
+# (MI355X_MICROARCH.md, cycle constants); what a SATURATED SIMD actually sustains on this chip, measured with
+# scripts/microbench/int_valu_rate.hip (profiles/r2_microbench_int_valu.txt: 8 waves per SIMD, independent v_add_f32 /
+# v_xor_b32), is 2.5 cycles per wave-instruction.  The fraction is quoted against the MEASURED rate (against the
+# datasheet's 2 it understates how close an issue-bound kernel is); the datasheet peak is given beside it.
+VALU_CYCLES_PER_WAVE_INST_MEASURED = 2.5
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / VALU_CYCLES_PER_WAVE_INST_MEASURED
+VALU_PEAK_DATASHEET = 1024 * 2.4e9 / 2.0
 
 
-def pmc_profile(workload: str) -> dict:
+def pmc_profile(workload: str, source_hash: str):
     """Counter-derived per-launch figures of the workload's tracker kernel from the committed rocprofv3 PMC summary
-    (profiles/pmc_traffic.json, written by scripts/summarize_profile.py from separate --pmc passes): HBM bytes
-    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and vector-ALU wave-instructions.  Empty when nothing is committed."""
+    (profiles/pmc_traffic.json, written by scripts/summarize_profile.py from separate --pmc passes over THIS bench command): HBM
+    bytes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and vector-ALU wave-instructions.  Counters cannot be collected inside a timed
+    run, so they are tied to the build instead: the summary records the library's source hash (ftk_build_info()), and figures
+    whose hash is not the RUNNING library's are refused — returned as (None, why) — rather than silently reported for kernels
+    that have changed since.  Returns (entry, None) when they belong to this build."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
     except Exception:
-        return {}
+        return None, "no counter summary committed (profiles/pmc_traffic.json)"
     w = d.get("workloads", {}).get(workload)
-    if w:
-        return w
-    if workload == "config2" and "klt_config2_bytes_per_launch" in d:  # round-1 layout
-        return {"bytes_per_launch": d["klt_config2_bytes_per_launch"], "source": d.get("source")}
-    return {}
+    if not w:
+        return None, f"no counter summary for workload {workload}"
+    recorded = w.get("source_hash")
+    if not recorded:
+        return None, f"the committed counters ({w.get('source')}) predate build hashes: taken on an earlier build of the kernels"
+    if recorded != source_hash:
+        return None, f"the committed counters ({w.get('source')}) were taken on build {recorded}; this library is build {source_hash}"
+    return w, None
 
 
 def parity_report(gpu_uv, gpu_st, cpu_uv, cpu_st) -> dict:
@@ -109,6 +122,51 @@ def cpu_baseline(cfg, ref_levels, cur_levels, uv, budget_s=12.0):
         "sample": f"{len(times)} full calls of the workload ({cfg['n']} features each), median {med * 1e3:.2f} ms/call, "
                   f"oracle/liboracle.so (gcc -O3, no -march, -ffp-contract=off), host cpus={os.cpu_count()}",
     }
+
+
+def with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur_in, d_st_in, n, levels, stream, out_views):
+    """the metric "with H2D pyramid upload".  The reference's own timed region (test/test_optical_flow.cpp:69-73)
+    spans CreateImagePyramid x 2 + TrackFeatures; here one call = both raw frames copied from pinned host memory into HBM,
+    levels >= 1 of both pyramids rebuilt on the device (ftk_pyramid_update, no allocation), then the same tracker launch on the
+    same features — all stream-ordered, one synchronisation at the end of the K calls.  `value` is never the headline (inputs
+    are not resident when the timed region starts); it is reported beside it."""
+    import torch
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+
+    h_ref, h_cur = torch.from_numpy(np.ascontiguousarray(ref_img)).pin_memory(), torch.from_numpy(np.ascontiguousarray(cur_img)).pin_memory()
+    pr, pc = F.ImagePyramid.build(ref_img, levels, ctx), F.ImagePyramid.build(cur_img, levels, ctx)
+    klt_up = D.DeviceKlt(cfg["model"], opt, pr, pc, ctx)
+    launch = klt_up.bind(d_ref, d_cur_in, d_st_in, out_views[0], out_views[1], None)
+    p_ref, p_cur = h_ref.data_ptr(), h_cur.data_ptr()
+
+    def call():
+        pr.update(p_ref, "host_async")
+        pc.update(p_cur, "host_async")
+        launch()
+
+    for _ in range(max(3, min(args.warmup, 10))):
+        call()
+    stream.synchronize()
+    steps = max(10, min(args.steps, 200))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    stream.synchronize()
+    elapsed = time.perf_counter() - t0
+    # one call alone, synchronised: the latency a caller that waits for every frame sees
+    lat = []
+    for _ in range(20):
+        t1 = time.perf_counter()
+        call()
+        stream.synchronize()
+        lat.append(time.perf_counter() - t1)
+    return {"value": n * steps / elapsed, "unit": "tracked features/s", "ms_per_call": elapsed / steps * 1e3, "calls_timed": steps,
+            "ms_per_call_synchronised": float(np.median(lat)) * 1e3,
+            "includes": f"H2D of two {ref_img.shape[1]}x{ref_img.shape[0]} frames from pinned host memory + device 2x2 downsample of levels 1..{levels - 1} "
+                        "of both pyramids (ftk_pyramid_update) + the tracker launch; inputs are NOT resident when the region starts",
+            "result_uv": out_views[0], "result_st": out_views[1]}
 
 
 def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
@@ -392,6 +450,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", help="feature_tracker_amd.synth.CONFIGS key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the with_pyramid_upload measurement (N = 1 only; it runs after the timed region)")
     ap.add_argument("--shard-total", type=int, default=0,
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
                          "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
@@ -592,6 +651,19 @@ def main():
             launches[k & 1]()
             ev1[k].record(stream)
         torch.cuda.synchronize()
+        # what an event pair measures with NOTHING between the two records: the marker-to-marker cost that every bracketed
+        # launch above carries on top of the kernel itself (the rocprofv3 kernel-trace duration does not)
+        null0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+        null1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+        for a, b in zip(null0, null1):
+            launches[0]()  # keep the queue in the same state as above: a kernel in front of the pair
+            a.record(stream)
+            b.record(stream)
+        torch.cuda.synchronize()
+        event_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in zip(null0, null1)]))
+        upload = None
+        if world == 1 and args.features == 0 and not args.no_upload_leg:
+            upload = with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur_in, d_st_in, n, levels, stream, views2[1])
         if use_dist:
             # every rank must now hold every rank's result shard: spot-check the own shard inside the gathered buffer
             per = FD.packed_bytes(n)
@@ -604,7 +676,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in ev0]))
+    kernel_ms_bracketed = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in ev0]))
+    kernel_ms = max(kernel_ms_bracketed - event_overhead_ms, 1e-6)  # the ONE kernel time both roofline objects use
     # the LAST launch's result as well: calls of >= 4096 features go through the longest-first launch order from the third call on
     # (ftk_klt_track_device), so the first step alone would not show that the ordered launches return the same bits
     last_uv, last_st = views2[0][0].cpu().numpy().copy(), views2[0][1].cpu().numpy().copy()
@@ -613,7 +686,10 @@ def main():
         value = total_features / elapsed
         algo = algorithmic_bytes(iters, levels, half, cfg["method"])
         achieved = algo / (kernel_ms * 1e-3) / 1e9
-        pmc = pmc_profile(args.workload) if args.features == 0 else {}
+        from feature_tracker_amd import _native as NL
+        build = NL.build_info()
+        pmc, pmc_refused = pmc_profile(args.workload, build.get("source_hash")) if args.features == 0 else (None, "--features overrides the workload")
+        pmc = pmc or {}
         kernel_name = "klt_basic_inverse_pipelined_kernel" if (cfg["model"], cfg["method"]) == ("basic", "inverse") else f"klt_track_kernel<{cfg['model']}, {cfg['method']}>"
         cpu_uv, cpu_st, cpu_it, _ = oracle_once(cfg, ref_levels, cur_levels, uv)
         out = {
@@ -626,9 +702,14 @@ def main():
                        if use_dist else "single GPU",
                        "tracked_fraction": float((status == 1).mean()), "mean_iterations_per_feature": float(iters.mean())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
+                         "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"), "traffic_refused": pmc_refused,
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "kernel_launches_timed": len(ev0),
+                         "kernel_ms_method": "HIP events on the launch stream around each of the launches in a separate pass after the timed "
+                                             "region, minus the cost of an empty event pair measured the same way",
+                         "kernel_ms_event_bracketed": kernel_ms_bracketed, "event_pair_overhead_ms": event_overhead_ms,
+                         "kernel_ms_rocprofv3_trace_this_build": (pmc.get("trace_average_ns") or 0) * 1e-6 or None,
                          "algorithmic_bytes_per_launch": algo},
+            "build": build,
             "parity": dict(parity_report(first_uv, first_st, cpu_uv, cpu_st), iteration_counts_equal=bool(np.array_equal(iters, cpu_it)),
                            last_launch_bit_identical=bool(np.array_equal(last_uv.view(np.uint32), cpu_uv.view(np.uint32)) and np.array_equal(last_st, cpu_st))),
         }
@@ -636,7 +717,16 @@ def main():
             valu = pmc["valu_insts_per_launch"] / (kernel_ms * 1e-3)
             out["roofline_valu"] = {"bound": "valu_issue", "achieved": valu, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
                                     "frac": valu / VALU_PEAK_WAVE_INSTS_PER_S, "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                                    "peak_is": f"1024 SIMDs x 2.4 GHz / {VALU_CYCLES_PER_WAVE_INST_MEASURED} cycles per wave64 instruction, the rate a saturated SIMD "
+                                               "sustains (scripts/microbench/int_valu_rate.hip, profiles/r2_microbench_int_valu.txt)",
+                                    "frac_of_datasheet_peak": valu / VALU_PEAK_DATASHEET,
                                     "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "source": pmc.get("source")}
+        else:
+            out["roofline_valu"] = None  # no counters of THIS build: see roofline.traffic_refused
+        if upload is not None:
+            up_uv, up_st = upload.pop("result_uv").cpu().numpy(), upload.pop("result_st").cpu().numpy()
+            upload["bit_identical_to_resident_path"] = bool(np.array_equal(up_uv.view(np.uint32), first_uv.view(np.uint32)) and np.array_equal(up_st, first_st))
+            out["with_pyramid_upload"] = upload
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
         print(json.dumps(out), flush=True)

@@ -1481,4 +1481,12 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// First-use cost out of the callers' timed regions (ftk_warmup): launching this empty kernel makes the runtime load this
+// translation unit's code object onto the device, which otherwise happens inside the first real call.
+__global__ void cosine_warm_kernel() {}
+hipError_t cosine_warm(hipStream_t stream) {
+    hipLaunchKernelGGL(cosine_warm_kernel, dim3(1), dim3(64), 0, stream);
+    return hipGetLastError();
+}
+
 }  // namespace ftk

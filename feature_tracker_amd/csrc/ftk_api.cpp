@@ -469,6 +469,50 @@ int ftk_synchronize(ftk_context *ctx) {
     return FTK_OK;
 }
 
+int ftk_warmup(ftk_context *ctx, unsigned what) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "warmup: null context");
+    }
+    FTK_LOCK(ctx);
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    if (what & FTK_WARM_KLT) {
+        FTK_HIP(ctx, ftk::klt_warm(ctx->stream));
+        FTK_HIP(ctx, ftk::klt_basic_warm(ctx->stream));
+        FTK_HIP(ctx, ftk::pyramid_warm(ctx->stream));
+        // the staging blocks of the host-buffer entry points, at the size a few thousand features need
+        int rc = ensure_scratch(ctx, 1u << 18);
+        if (rc == FTK_OK) {
+            rc = ensure_pinned(ctx, 1u << 18);
+        }
+        if (rc != FTK_OK) {
+            return rc;
+        }
+    }
+    if (what & FTK_WARM_HAMMING) {
+        FTK_HIP(ctx, ftk::matcher_warm(ctx->stream));
+        FTK_HIP(ctx, ftk::feature_warm(ctx->stream));  // BRIEF descriptors sit in front of the matcher
+        int rc = ensure_match_keys(ctx, 4096);
+        if (rc == FTK_OK) {
+            rc = ensure_scratch(ctx, 1u << 18);
+        }
+        if (rc != FTK_OK) {
+            return rc;
+        }
+    }
+    if (what & FTK_WARM_COSINE) {
+        FTK_HIP(ctx, ftk::cosine_warm(ctx->stream));
+    }
+    if (what & FTK_WARM_DIRECT) {
+        FTK_HIP(ctx, ftk::direct_warm(ctx->stream));
+        FTK_HIP(ctx, ftk::pyramid_warm(ctx->stream));
+    }
+    if (what & FTK_WARM_FEATURES) {
+        FTK_HIP(ctx, ftk::feature_warm(ctx->stream));
+    }
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
 /* ---- pyramids ------------------------------------------------------------------------------ */
 
 int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n_levels, ftk_pyramid **out) {
@@ -615,6 +659,34 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
         return fail(ctx, FTK_E_HIP, "pyramid_build: %s", hipGetErrorString(e));
     }
     *out = pyr;
+    return FTK_OK;
+}
+
+int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image, int image_location) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_update: null context");
+    }
+    FTK_LOCK(ctx);
+    if (!pyr || !image || image_location < FTK_IMAGE_HOST || image_location > FTK_IMAGE_HOST_ASYNC) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_update: null pyramid / image or unknown image location %d", image_location);
+    }
+    if (pyr->device != ctx->device) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "pyramid_update: the pyramid lives on another device");
+    }
+    if (!pyr->owned || pyr->levels[0].data != pyr->owned) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_update: only pyramids that own their level 0 (ftk_pyramid_upload, ftk_pyramid_build of a host image) can be refilled");
+    }
+    FTK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes0 = (size_t)pyr->levels[0].rows * pyr->levels[0].cols;
+    FTK_HIP(ctx, hipMemcpyAsync(pyr->owned, image, bytes0, image_location == FTK_IMAGE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                ctx->stream));
+    for (int i = 1; i < pyr->n_levels; ++i) {
+        FTK_HIP(ctx, ftk::pyramid_downsample_launch(pyr->levels[i - 1].data, pyr->levels[i - 1].rows, pyr->levels[i - 1].cols,
+                                                    const_cast<uint8_t *>(pyr->levels[i].data), ctx->stream));
+    }
+    if (image_location == FTK_IMAGE_HOST) {
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may release or rewrite the host image on return
+    }
     return FTK_OK;
 }
 

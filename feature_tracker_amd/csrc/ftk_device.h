@@ -199,4 +199,13 @@ hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);
 
+// One empty launch per translation unit: loads its code object (ftk_warmup).
+hipError_t klt_warm(hipStream_t stream);
+hipError_t klt_basic_warm(hipStream_t stream);
+hipError_t matcher_warm(hipStream_t stream);
+hipError_t cosine_warm(hipStream_t stream);
+hipError_t direct_warm(hipStream_t stream);
+hipError_t pyramid_warm(hipStream_t stream);
+hipError_t feature_warm(hipStream_t stream);
+
 }  // namespace ftk

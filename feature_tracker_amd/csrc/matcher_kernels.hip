@@ -982,4 +982,12 @@ hipError_t match_launch(const MatchParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// First-use cost out of the callers' timed regions (ftk_warmup): launching this empty kernel makes the runtime load this
+// translation unit's code object onto the device, which otherwise happens inside the first real call.
+__global__ void matcher_warm_kernel() {}
+hipError_t matcher_warm(hipStream_t stream) {
+    hipLaunchKernelGGL(matcher_warm_kernel, dim3(1), dim3(64), 0, stream);
+    return hipGetLastError();
+}
+
 }  // namespace ftk

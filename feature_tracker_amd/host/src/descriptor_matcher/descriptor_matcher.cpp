@@ -15,6 +15,8 @@
 namespace feature_tracker {
 namespace device {
 
+void WarmUpMatcher(bool hamming) { WarmUp(hamming ? FTK_WARM_HAMMING : FTK_WARM_COSINE); }
+
 float HammingDistance(const std::vector<bool> &a, const std::vector<bool> &b) {
     if (a.empty() || b.empty()) {
         return static_cast<float>(kMaxInt32);

@@ -37,6 +37,9 @@ namespace device {
 bool HammingMatch(const std::vector<std::vector<bool>> &descriptors_ref, const std::vector<std::vector<bool>> &descriptors_cur,
                   const std::vector<Vec2> *pixel_uv_pred_in_cur, const std::vector<Vec2> *pixel_uv_cur, float max_distance,
                   int32_t max_col_distance, int32_t max_row_distance, std::vector<int32_t> &index_pairs_in_cur);
+// First-use device cost (context, code objects, workspaces) at construction time instead of inside the first match
+// (device_runtime.h, WarmUp): hamming != 0 for per-bit descriptors, else the float (cosine) matcher's kernels.
+void WarmUpMatcher(bool hamming);
 // Plain Hamming distance of two per-bit descriptors, used for the call-time probe.
 float HammingDistance(const std::vector<bool> &a, const std::vector<bool> &b);
 // Float descriptors stored back to back (n x dim floats).  pred_uv == nullptr selects ForceMatch.
@@ -75,7 +78,13 @@ public:
     };
 
 public:
-    DescriptorMatcher() = default;
+    DescriptorMatcher() {  // = default in the reference
+        if (std::is_same<DescriptorType, std::vector<bool>>::value) {
+            device::WarmUpMatcher(true);
+        } else if (detail::IsFloatVector<DescriptorType>::value) {
+            device::WarmUpMatcher(false);
+        }
+    }
     virtual ~DescriptorMatcher() = default;
 
     bool ForceMatch(const std::vector<DescriptorType> &descriptors_ref, const std::vector<DescriptorType> &descriptors_cur,

@@ -152,6 +152,26 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
     return false;
 }
 
+void WarmUp(unsigned what) {
+    static std::mutex warm_mutex;
+    static unsigned warmed = 0;
+    static const bool disabled = std::getenv("FTK_NO_WARMUP") != nullptr && std::atoi(std::getenv("FTK_NO_WARMUP")) != 0;  // experiment switch
+    if (disabled) {
+        return;
+    }
+    std::lock_guard<std::mutex> lock(warm_mutex);
+    const unsigned todo = what & ~warmed;
+    if (todo == 0) {
+        return;
+    }
+    warmed |= todo;  // one attempt per family
+    std::string error;
+    ftk_context *ctx = SharedContext(&error);
+    if (ctx != nullptr) {
+        (void)ftk_warmup(ctx, todo);
+    }
+}
+
 int CommOptIn(int *rank, int *world, std::string *error) {
     // Opt-in is EXPLICIT: the sharded mode is only valid when every rank passes identical pyramids and feature lists, which the
     // generic launcher variables cannot establish (a data-parallel job under torchrun tracks DIFFERENT frames per rank).  So only

@@ -10,6 +10,8 @@
 
 namespace feature_tracker {
 
+DirectMethod::DirectMethod() { device::WarmUp(FTK_WARM_DIRECT); }
+
 bool DirectMethod::TrackFeatures(const ImagePyramid &ref_pyramid, const ImagePyramid &cur_pyramid, const std::array<float, 4> &K, const Quat ref_q_wc,
                                  const Vec3 ref_p_wc, const std::vector<Vec3> &p_w, const std::vector<Vec2> &ref_pixel_uv, std::vector<Vec2> &cur_pixel_uv,
                                  Quat &cur_q_wc, Vec3 &cur_p_wc, std::vector<uint8_t> &status) {

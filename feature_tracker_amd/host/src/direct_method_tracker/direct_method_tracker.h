@@ -41,7 +41,7 @@ struct DirectMethodOptions {
 class DirectMethod {
 
 public:
-    DirectMethod() = default;
+    DirectMethod();  // = default in the reference; also the first-use device cost (device_runtime.h, WarmUp)
     virtual ~DirectMethod() = default;
     DirectMethod(const DirectMethod &direct_method) = delete;
 

@@ -43,6 +43,8 @@ ftk_pyramid *UploadSingle(ftk_context *ctx, const GrayImage &image, std::string 
 
 }  // namespace
 
+OpticalFlow::OpticalFlow() { device::WarmUp(FTK_WARM_KLT); }
+
 bool OpticalFlow::TrackFeatures(const ImagePyramid &ref_pyramid, const ImagePyramid &cur_pyramid, const std::vector<Vec2> &ref_pixel_uv,
                                 std::vector<Vec2> &cur_pixel_uv, std::vector<uint8_t> &status) {
     RETURN_FALSE_IF(ref_pixel_uv.empty());

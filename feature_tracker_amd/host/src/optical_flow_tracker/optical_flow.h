@@ -39,7 +39,7 @@ struct OpticalFlowOptions {
 class OpticalFlow {
 
 public:
-    OpticalFlow() = default;
+    OpticalFlow();  // = default in the reference; here it also takes the first-use device cost out of the first TrackFeatures (device_runtime.h, WarmUp)
     virtual ~OpticalFlow() = default;
 
     virtual std::string OpticalFlowMethodName() const { return "None"; }

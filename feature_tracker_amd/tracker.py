@@ -42,6 +42,11 @@ class Context:
     def synchronize(self):
         N.check(N.lib().ftk_synchronize(self._h), self._h)
 
+    def warmup(self, what: int = 31):
+        """ftk_warmup: code-object load and first staging allocations now instead of inside the first real call
+        (mask of FTK_WARM_*: 1 KLT, 2 Hamming, 4 cosine, 8 direct method, 16 BRIEF / Harris)."""
+        N.check(N.lib().ftk_warmup(self._h, int(what)), self._h)
+
     def close(self):
         if self._h:
             N.lib().ftk_context_destroy(self._h)
@@ -120,6 +125,21 @@ class ImagePyramid:
         h = C.c_void_p()
         N.check(N.lib().ftk_pyramid_build(ctx.handle, C.c_void_p(int(device_ptr)), rows, cols, int(levels), 1, C.byref(h)), ctx.handle)
         return cls(h, ctx, keepalive)
+
+    def update(self, image, location: str = "host"):
+        """The next frame into this pyramid (ftk_pyramid_update): level 0 overwritten, levels >= 1 rebuilt on the device, no
+        allocation.  ``image``: a uint8 array of level 0's shape (location "host": synchronous), or a raw pointer (int) with
+        location "device" (stream-ordered) / "host_async" (pinned host memory that stays valid until the stream has passed)."""
+        loc = {"host": 0, "device": 1, "host_async": 2}[location]
+        if isinstance(image, (int, np.integer)):
+            ptr = C.c_void_p(int(image))
+        else:
+            a = np.ascontiguousarray(image, dtype=np.uint8)
+            _, rows, cols = self.level_desc(0)
+            if a.shape != (rows, cols):
+                raise ValueError(f"image shape {a.shape} differs from level 0 ({rows}, {cols})")
+            ptr = _ptr(a)
+        N.check(N.lib().ftk_pyramid_update(self._ctx.handle, self._h, ptr, loc), self._ctx.handle)
 
     @property
     def handle(self):

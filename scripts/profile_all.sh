@@ -11,6 +11,8 @@ WORKLOADS=${*:-config2 config3 config4 config5_shard hamming}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# which build these counters belong to: bench.py refuses committed PMC figures whose source hash is not the running library's
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from feature_tracker_amd import _native as N; import json; print(json.dumps(N.build_info()))" > "$OUT/build_info.json"
 cd /tmp && export TMPDIR=/tmp
 GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU"
@@ -33,5 +35,5 @@ for W in $WORKLOADS; do
   done
 done
 # keep the box->repo merge small: drop everything but csv/log
-find "$OUT" -type f ! -name '*.csv' ! -name '*.log' -delete
+find "$OUT" -type f ! -name '*.csv' ! -name '*.log' ! -name 'build_info.json' -delete
 du -sh "$OUT"

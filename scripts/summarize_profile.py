@@ -32,6 +32,10 @@ def main(tag):
     except Exception:
         traffic = {}
     traffic.setdefault("workloads", {})
+    try:
+        build = json.load(open(os.path.join(src, "build_info.json")))  # written by scripts/profile_all.sh on the GPU box
+    except Exception:
+        build = {}
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fs, open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as fp:
         ws, wp = csv.writer(fs), csv.writer(fp)
         ws.writerow(["workload", "Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
@@ -61,7 +65,8 @@ def main(tag):
             if dom:
                 k = max(dom, key=lambda kk: sum(len(x) for x in vals[kk].values()))
                 v = {c: statistics.median(x) for c, x in vals[k].items()}
-                entry = {"kernel": k, "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc, separate passes; scripts/profile_all.sh {tag})"}
+                entry = {"kernel": k, "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc, separate passes; scripts/profile_all.sh {tag})",
+                         "source_hash": build.get("source_hash"), "mllvm": build.get("mllvm")}
                 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                     entry["fetch_size_kb_median"], entry["write_size_kb_median"] = v["FETCH_SIZE"], v["WRITE_SIZE"]
                     entry["bytes_per_launch"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)

@@ -121,6 +121,40 @@ def test_hamming_match_sharded_world_1(ftk, oracle, nearby):
     assert np.array_equal(d_idx.cpu().numpy(), want)
 
 
+def test_a_failed_local_launch_poisons_its_shard_instead_of_leaving_the_collective(ftk):
+    """when this rank's tracker launch fails the call must still take part in the all-gather (the peers would block in
+    it for ever) — with a shard of 0xFF bytes — and report the local error; the host-buffer form turns a poisoned block into an
+    error.  Forced here with a patch size the kernels refuse (FTK_E_UNSUPPORTED), world size 1 through RCCL."""
+    import ctypes as C
+    from feature_tracker_amd import _native
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    n = 300
+    uv = scenes.features(n, 320, 240, half=5)
+    torch, D, dev, stream, ctx, klt = _device_tracker(ftk, "basic", "inverse", 5, ref_levels, cur_levels, n)
+    with torch.cuda.stream(stream):
+        comm = D.Comm(ctx, 0, 1, D.Comm.unique_id())
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_out, d_st = torch.zeros_like(d_ref), torch.zeros(n, dtype=torch.uint8, device=dev)
+        klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)  # sizes the exchange buffers
+        stream.synchronize()
+        klt.opt.half_rows = 64  # outside [0, 63]: fill_klt_params refuses it
+        with pytest.raises(_native.FtkError) as e:
+            klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)
+        assert e.value.code == -4 and "half patch" in str(e.value)
+        stream.synchronize()
+        assert (d_st.cpu().numpy() == 0xFF).all() and (d_out.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
+        # host-buffer form
+        cur, st = uv.copy(), np.zeros(n, np.uint8)
+        rc = _native.lib().ftk_klt_track_sharded(ctx.handle, comm.handle, klt.model, C.byref(klt.opt), klt.ref_pyr.handle, klt.cur_pyr.handle,
+                                                 uv.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), n, None, 0, 0, None)
+        assert rc != 0
+        klt.opt.half_rows = 5  # and the communicator is still usable afterwards
+        klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)
+        stream.synchronize()
+        assert (d_st.cpu().numpy() <= 4).all()
+        comm.close()
+
+
 def test_comm_argument_errors(ftk):
     import torch
     from feature_tracker_amd import _native

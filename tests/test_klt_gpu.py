@@ -241,6 +241,58 @@ def test_pyramid_build_matches_oracle(ftk, oracle):
             assert np.array_equal(pyr.download_level(i), ref[i]), (w, h, i)
 
 
+def test_pyramid_update_refills_an_existing_pyramid(ftk, oracle):
+    """ftk_pyramid_update: the next frame into the same allocation == a freshly built pyramid == the oracle's, from host memory,
+    from device memory and from pinned host memory (stream-ordered); and a tracker on the refilled pair gives the oracle's result."""
+    import torch
+    from feature_tracker_amd import _native, synth
+    w, h, levels = 321, 243, 4
+    img_a, img_b = synth.make_image_pair(w, h, (2.2, -1.4))
+    pyr = ftk.ImagePyramid.build(img_a, levels)
+    ref_b = oracle.create_pyramid(img_b, levels)
+    pyr.update(img_b)
+    for i in range(levels):
+        assert np.array_equal(pyr.download_level(i), ref_b[i]), i
+    ref_a = oracle.create_pyramid(img_a, levels)
+    d_img = torch.from_numpy(img_a).cuda()
+    torch.cuda.synchronize()
+    pyr.update(d_img.data_ptr(), "device")
+    for i in range(levels):
+        assert np.array_equal(pyr.download_level(i), ref_a[i]), i
+    pinned = torch.from_numpy(img_b.copy()).pin_memory()
+    pyr.update(pinned.data_ptr(), "host_async")
+    for i in range(levels):  # download_level synchronises the context's stream
+        assert np.array_equal(pyr.download_level(i), ref_b[i]), i
+    # an uploaded pyramid owns its level 0 too; a wrapped / device-borrowed one does not
+    up = ftk.ImagePyramid.from_host_levels(ref_a)
+    up.update(img_b)
+    assert np.array_equal(up.download_level(levels - 1), ref_b[levels - 1])
+    borrowed = ftk.ImagePyramid.build_from_device(d_img.data_ptr(), h, w, levels, keepalive=d_img)
+    with pytest.raises(_native.FtkError):
+        borrowed.update(img_b)
+    with pytest.raises(ValueError):
+        pyr.update(img_b[:-1])
+    # tracking on refilled pyramids
+    other = ftk.ImagePyramid.build(img_b, levels)
+    other.update(img_a)  # ref := a
+    pyr.update(img_b)    # cur := b
+    uv = scenes.features(200, w, h, half=5)
+    klt = ftk.OpticalFlowBasicKlt()
+    klt.options().kMethod, klt.options().kPatchRowHalfSize, klt.options().kPatchColHalfSize = "inverse", 5, 5
+    ok, c, s = klt.TrackFeatures(other, pyr, uv)
+    ok_c, c_c, s_c, _ = oracle.klt_track_pyramid("basic", ref_a, ref_b, uv, method="inverse", half=5)
+    assert ok and np.array_equal(s, s_c) and np.array_equal(c.view(np.uint32), c_c.view(np.uint32))
+
+
+def test_warmup_and_build_info(ftk):
+    from feature_tracker_amd import _native
+    ctx = ftk.Context()
+    ctx.warmup()       # every family
+    ctx.warmup(1 | 2)  # again: idempotent
+    info = _native.build_info()
+    assert len(info["source_hash"]) == 16 and info["arch"] == "gfx950" and "mllvm" in info
+
+
 @pytest.mark.parametrize("model", MODELS)
 def test_tiny_image_and_coarse_levels_smaller_than_patch(ftk, oracle, model):
     """Pyramid levels smaller than the patch footprint: every window is clamped at the border."""
