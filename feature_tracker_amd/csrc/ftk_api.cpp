@@ -376,6 +376,7 @@ void ftk_default_klt_options(ftk_klt_options *opt) {
 }
 
 int ftk_context_create(int device, void *stream, ftk_context **out) {
+    FTK_TRACE_SCOPE("ftk_context_create");
     if (!out) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "context: null output pointer");
     }
@@ -469,7 +470,10 @@ int ftk_synchronize(ftk_context *ctx) {
     return FTK_OK;
 }
 
+static int ensure_brief_pattern(ftk_context *ctx, int32_t n_bits, int32_t half);
+
 int ftk_warmup(ftk_context *ctx, unsigned what) {
+    FTK_TRACE_SCOPE("ftk_warmup");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "warmup: null context");
     }
@@ -479,10 +483,11 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
         FTK_HIP(ctx, ftk::klt_warm(ctx->stream));
         FTK_HIP(ctx, ftk::klt_basic_warm(ctx->stream));
         FTK_HIP(ctx, ftk::pyramid_warm(ctx->stream));
-        // the staging blocks of the host-buffer entry points, at the size a few thousand features need
-        int rc = ensure_scratch(ctx, 1u << 18);
+        // the staging blocks of the host-buffer entry points, at the size a few thousand features need ...
+        // ... and what the upload of one 1080p pyramid stages (ftk_pyramid_upload gathers the levels in the pinned block)
+        int rc = ensure_scratch(ctx, 4u << 20);
         if (rc == FTK_OK) {
-            rc = ensure_pinned(ctx, 1u << 18);
+            rc = ensure_pinned(ctx, 4u << 20);
         }
         if (rc != FTK_OK) {
             return rc;
@@ -493,7 +498,13 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
         FTK_HIP(ctx, ftk::feature_warm(ctx->stream));  // BRIEF descriptors sit in front of the matcher
         int rc = ensure_match_keys(ctx, 4096);
         if (rc == FTK_OK) {
-            rc = ensure_scratch(ctx, 1u << 18);
+            rc = ensure_scratch(ctx, 4u << 20);
+        }
+        if (rc == FTK_OK) {
+            rc = ensure_pinned(ctx, 4u << 20);
+        }
+        if (rc == FTK_OK) {
+            rc = ensure_brief_pattern(ctx, 256, 8);  // kLength / kHalfPatchSize of the reference's caller (test_descriptor_matcher_brief.cpp:71-72)
         }
         if (rc != FTK_OK) {
             return rc;
@@ -509,6 +520,18 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
     if (what & FTK_WARM_FEATURES) {
         FTK_HIP(ctx, ftk::feature_warm(ctx->stream));
     }
+    if (ctx->pinned && ctx->scratch) {
+        // first copies in both directions between the staging blocks (the copy path's first use is not free either)
+        // (an image-sized one: copies beyond a few KB take another path in the runtime than small ones, and the first 361 KB
+        // upload of a process was measured at 5.8 - 7.9 ms)
+        const size_t probe = ctx->pinned_bytes < ctx->scratch_bytes ? ctx->pinned_bytes : ctx->scratch_bytes;
+        FTK_HIP(ctx, hipMemcpyAsync(ctx->scratch, ctx->pinned, probe, hipMemcpyHostToDevice, ctx->stream));
+        FTK_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch, probe, hipMemcpyDeviceToHost, ctx->stream));
+        void *tmp = nullptr;  // and one image-sized allocation: what every ftk_pyramid_upload / ftk_pyramid_build makes
+        if (hipMalloc(&tmp, 4u << 20) == hipSuccess) {
+            (void)hipFree(tmp);
+        }
+    }
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
 }
@@ -516,6 +539,7 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
 /* ---- pyramids ------------------------------------------------------------------------------ */
 
 int ftk_pyramid_upload(ftk_context *ctx, const ftk_image *host_levels, int32_t n_levels, ftk_pyramid **out) {
+    FTK_TRACE_SCOPE("ftk_pyramid_upload");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_upload: null context");
     }
@@ -593,6 +617,7 @@ int ftk_pyramid_wrap_device(ftk_context *ctx, const ftk_image *device_levels, in
 
 int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int32_t cols, int32_t n_levels, int image_on_device,
                       ftk_pyramid **out) {
+    FTK_TRACE_SCOPE("ftk_pyramid_build");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_build: null context");
     }
@@ -663,6 +688,7 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
 }
 
 int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image, int image_location) {
+    FTK_TRACE_SCOPE("ftk_pyramid_update");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_update: null context");
     }
@@ -703,6 +729,7 @@ int ftk_pyramid_level(const ftk_pyramid *pyr, int32_t level, ftk_image *out) {
 }
 
 int ftk_pyramid_download_level(ftk_context *ctx, const ftk_pyramid *pyr, int32_t level, uint8_t *host_out) {
+    FTK_TRACE_SCOPE("ftk_pyramid_download_level");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "pyramid_download_level: null context");
     }
@@ -717,6 +744,7 @@ int ftk_pyramid_download_level(ftk_context *ctx, const ftk_pyramid *pyr, int32_t
 }
 
 void ftk_pyramid_destroy(ftk_pyramid *pyr) {
+    FTK_TRACE_SCOPE("ftk_pyramid_destroy");
     if (!pyr) {
         return;
     }
@@ -881,6 +909,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
 
 int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *ref_uv,
                   float *cur_uv, uint8_t *status, int32_t n, const float *prior, int consider_luminance, int single_level, uint32_t *iters) {
+    FTK_TRACE_SCOPE("ftk_klt_track");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "klt_track: null context");
     }
@@ -964,6 +993,7 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
 
 int ftk_extract_extend_patch(ftk_context *ctx, const ftk_pyramid *ref, int32_t level, float u, float v, int32_t ex_rows, int32_t ex_cols,
                              float *ex_patch, uint8_t *valid, uint32_t *valid_count) {
+    FTK_TRACE_SCOPE("ftk_extract_extend_patch");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "extract_extend_patch: null context");
     }
@@ -1010,7 +1040,14 @@ static int ensure_brief_pattern(ftk_context *ctx, int32_t n_bits, int32_t half) 
         v = (int8_t)((int32_t)((state >> 8) % span) - half);
     }
     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->brief_pattern), pattern.size()));
-    FTK_HIP(ctx, hipMemcpy(ctx->brief_pattern, pattern.data(), pattern.size(), hipMemcpyHostToDevice));
+    // through the pinned block on the context's stream: a pageable hipMemcpy on the null stream costs milliseconds the first time
+    const int prc = ensure_pinned(ctx, pattern.size());
+    if (prc != FTK_OK) {
+        return prc;
+    }
+    memcpy(ctx->pinned, pattern.data(), pattern.size());
+    FTK_HIP(ctx, hipMemcpyAsync(ctx->brief_pattern, ctx->pinned, pattern.size(), hipMemcpyHostToDevice, ctx->stream));
+    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned block is reused by the caller right away
     ctx->brief_bits = n_bits;
     ctx->brief_half = half;
     return FTK_OK;
@@ -1051,6 +1088,7 @@ int ftk_brief_compute_device(ftk_context *ctx, const ftk_pyramid *image, int32_t
 
 int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level, const float *uv, int32_t n, int32_t n_bits,
                       int32_t half_patch, uint32_t *words) {
+    FTK_TRACE_SCOPE("ftk_brief_compute");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "brief_compute: null context");
     }
@@ -1072,17 +1110,29 @@ int ftk_brief_compute(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
     if (rc != FTK_OK) {
         return rc;
     }
-    uint8_t *base = static_cast<uint8_t *>(ctx->scratch);
+    if (n_bits <= 0 || half_patch <= 0 || half_patch > 63) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "brief_compute: bad arguments (bits %d, half %d)", n_bits, half_patch);
+    }
+    rc = ensure_brief_pattern(ctx, n_bits, half_patch);  // before the pinned block is filled: it stages the pattern there
+    if (rc == FTK_OK) {
+        rc = ensure_pinned(ctx, uv_bytes + w_bytes);
+    }
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->scratch), *hbase = static_cast<uint8_t *>(ctx->pinned);
     float *d_uv = reinterpret_cast<float *>(base);
     uint32_t *d_words = reinterpret_cast<uint32_t *>(base + uv_bytes);
-    FTK_HIP(ctx, hipMemcpyAsync(d_uv, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(hbase, uv, sizeof(float) * 2 * (size_t)n);
+    FTK_HIP(ctx, hipMemcpyAsync(d_uv, hbase, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     rc = ftk_brief_compute_device(ctx, image, level, d_uv, n, n_bits, half_patch, d_words);
     if (rc != FTK_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
-    FTK_HIP(ctx, hipMemcpyAsync(words, d_words, sizeof(uint32_t) * n_words * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(hbase + uv_bytes, d_words, sizeof(uint32_t) * n_words * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(words, hbase + uv_bytes, sizeof(uint32_t) * n_words * (size_t)n);
     return FTK_OK;
 }
 
@@ -1130,7 +1180,8 @@ static int harris_run(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
         }
         survivors->resize(count);
         if (count > 0) {
-            FTK_HIP(ctx, hipMemcpy(survivors->data(), p.list, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost));
+            FTK_HIP(ctx, hipMemcpyAsync(survivors->data(), p.list, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost, ctx->stream));
+            FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     } else {
         FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1139,6 +1190,7 @@ static int harris_run(ftk_context *ctx, const ftk_pyramid *image, int32_t level,
 }
 
 int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t level, float *response) {
+    FTK_TRACE_SCOPE("ftk_harris_response");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_response: null context");
     }
@@ -1151,6 +1203,7 @@ int ftk_harris_response(ftk_context *ctx, const ftk_pyramid *image, int32_t leve
 
 int ftk_harris_detect(ftk_context *ctx, const ftk_pyramid *image, int32_t level, int32_t max_count, int32_t min_distance, float min_response,
                       float *uv, int32_t *n_out) {
+    FTK_TRACE_SCOPE("ftk_harris_detect");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "harris_detect: null context");
     }
@@ -1361,6 +1414,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
 int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref, const uint32_t *cur_words, int32_t n_cur, int32_t n_words,
                       int32_t n_bits, float max_distance, const float *pred_uv, const float *cur_uv, int32_t max_col_distance,
                       int32_t max_row_distance, int32_t *index_pairs, int *matched_ok) {
+    FTK_TRACE_SCOPE("ftk_hamming_match");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "hamming_match: null context");
     }
@@ -1406,36 +1460,50 @@ int ftk_hamming_match(ftk_context *ctx, const uint32_t *ref_words, int32_t n_ref
     float *d_pred = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes) : nullptr;
     float *d_cuv = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes + pred_bytes) : nullptr;
     int32_t *d_idx = reinterpret_cast<int32_t *>(base + ref_bytes + cur_bytes + pred_bytes + cuv_bytes);
+    // One H2D per call: the inputs are gathered in the context's pinned block, laid out like the device scratch (pageable
+    // hipMemcpyAsync calls are staged one by one by the runtime, ~10 us each; the reference's callers time this call).
+    const size_t in_bytes = ref_bytes + cur_bytes + pred_bytes + cuv_bytes + idx_bytes;
+    rc = ensure_pinned(ctx, in_bytes);
+    if (rc != FTK_OK) {
+        return rc;
+    }
+    uint8_t *hbase = static_cast<uint8_t *>(ctx->pinned);
     if (dev_words == n_words) {
-        FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_words, sizeof(uint32_t) * (size_t)n_ref * n_words, hipMemcpyHostToDevice, ctx->stream));
-        FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_words, sizeof(uint32_t) * (size_t)n_cur * n_words, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(hbase, ref_words, sizeof(uint32_t) * (size_t)n_ref * n_words);
+        memcpy(hbase + ref_bytes, cur_words, sizeof(uint32_t) * (size_t)n_cur * n_words);
     } else {
         // zero-pad each descriptor to the next supported width (pad bits are equal in both sets -> distance unchanged)
-        FTK_HIP(ctx, hipMemsetAsync(d_ref, 0, ref_bytes + cur_bytes, ctx->stream));
-        FTK_HIP(ctx, hipMemcpy2DAsync(d_ref, sizeof(uint32_t) * dev_words, ref_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
-                                      (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
-        FTK_HIP(ctx, hipMemcpy2DAsync(d_cur, sizeof(uint32_t) * dev_words, cur_words, sizeof(uint32_t) * n_words, sizeof(uint32_t) * n_words,
-                                      (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+        memset(hbase, 0, ref_bytes + cur_bytes);
+        for (int32_t i = 0; i < n_ref; ++i) {
+            memcpy(hbase + sizeof(uint32_t) * (size_t)i * dev_words, ref_words + (size_t)i * n_words, sizeof(uint32_t) * n_words);
+        }
+        for (int32_t i = 0; i < n_cur; ++i) {
+            memcpy(hbase + ref_bytes + sizeof(uint32_t) * (size_t)i * dev_words, cur_words + (size_t)i * n_words, sizeof(uint32_t) * n_words);
+        }
     }
     if (pred_uv) {
-        FTK_HIP(ctx, hipMemcpyAsync(d_pred, pred_uv, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
-        FTK_HIP(ctx, hipMemcpyAsync(d_cuv, cur_uv, sizeof(float) * 2 * (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(hbase + ref_bytes + cur_bytes, pred_uv, sizeof(float) * 2 * (size_t)n_ref);
+        memcpy(hbase + ref_bytes + cur_bytes + pred_bytes, cur_uv, sizeof(float) * 2 * (size_t)n_cur);
     }
-    FTK_HIP(ctx, hipMemcpyAsync(d_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *h_idx = hbase + ref_bytes + cur_bytes + pred_bytes + cuv_bytes;
+    memcpy(h_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref);
+    FTK_HIP(ctx, hipMemcpyAsync(base, hbase, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = ftk_hamming_match_device(ctx, d_ref, n_ref, d_cur, n_cur, dev_words, n_bits, max_distance, d_pred, d_cuv, max_col_distance,
                                   max_row_distance, d_idx, nullptr);
     if (rc != FTK_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
-    FTK_HIP(ctx, hipMemcpyAsync(index_pairs, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(index_pairs, h_idx, sizeof(int32_t) * (size_t)n_ref);
     return FTK_OK;
 }
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 
 int ftk_ldlt6_solve(ftk_context *ctx, const float *a, const float *b, float *x, int32_t n) {
+    FTK_TRACE_SCOPE("ftk_ldlt6_solve");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "ldlt6_solve: null context");
     }
@@ -1578,6 +1646,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
 int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, const float *K,
                      const float *p_c_in_ref, const float *ref_uv, float *cur_uv, int32_t n, float *q_rc_wxyz, float *p_rc, uint8_t *status,
                      int status_valid, uint32_t *iterations) {
+    FTK_TRACE_SCOPE("ftk_direct_track");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "direct_track: null context");
     }
@@ -1765,6 +1834,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
 int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, const float *cur_desc, int32_t n_cur, int32_t dim, float max_distance,
                      const float *pred_uv, const float *cur_uv, int32_t max_col_distance, int32_t max_row_distance, int32_t *index_pairs,
                      int *matched_ok) {
+    FTK_TRACE_SCOPE("ftk_cosine_match");
     if (!ctx) {
         return fail(nullptr, FTK_E_INVALID_ARGUMENT, "cosine_match: null context");
     }
@@ -1803,20 +1873,30 @@ int ftk_cosine_match(ftk_context *ctx, const float *ref_desc, int32_t n_ref, con
     float *d_pred = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes) : nullptr;
     float *d_cuv = pred_uv ? reinterpret_cast<float *>(base + ref_bytes + cur_bytes + pred_bytes) : nullptr;
     int32_t *d_idx = reinterpret_cast<int32_t *>(base + ref_bytes + cur_bytes + pred_bytes + cuv_bytes);
-    FTK_HIP(ctx, hipMemcpyAsync(d_ref, ref_desc, sizeof(float) * (size_t)n_ref * dim, hipMemcpyHostToDevice, ctx->stream));
-    FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_desc, sizeof(float) * (size_t)n_cur * dim, hipMemcpyHostToDevice, ctx->stream));
-    if (pred_uv) {
-        FTK_HIP(ctx, hipMemcpyAsync(d_pred, pred_uv, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
-        FTK_HIP(ctx, hipMemcpyAsync(d_cuv, cur_uv, sizeof(float) * 2 * (size_t)n_cur, hipMemcpyHostToDevice, ctx->stream));
+    // one H2D per call through the pinned block (see ftk_hamming_match)
+    const size_t in_bytes = ref_bytes + cur_bytes + pred_bytes + cuv_bytes + idx_bytes;
+    rc = ensure_pinned(ctx, in_bytes);
+    if (rc != FTK_OK) {
+        return rc;
     }
-    FTK_HIP(ctx, hipMemcpyAsync(d_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *hbase = static_cast<uint8_t *>(ctx->pinned);
+    memcpy(hbase, ref_desc, sizeof(float) * (size_t)n_ref * dim);
+    memcpy(hbase + ref_bytes, cur_desc, sizeof(float) * (size_t)n_cur * dim);
+    if (pred_uv) {
+        memcpy(hbase + ref_bytes + cur_bytes, pred_uv, sizeof(float) * 2 * (size_t)n_ref);
+        memcpy(hbase + ref_bytes + cur_bytes + pred_bytes, cur_uv, sizeof(float) * 2 * (size_t)n_cur);
+    }
+    uint8_t *h_idx = hbase + ref_bytes + cur_bytes + pred_bytes + cuv_bytes;
+    memcpy(h_idx, index_pairs, sizeof(int32_t) * (size_t)n_ref);
+    FTK_HIP(ctx, hipMemcpyAsync(base, hbase, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = ftk_cosine_match_device(ctx, d_ref, n_ref, d_cur, n_cur, dim, max_distance, d_pred, d_cuv, max_col_distance, max_row_distance, d_idx);
     if (rc != FTK_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
-    FTK_HIP(ctx, hipMemcpyAsync(index_pairs, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
+    FTK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, sizeof(int32_t) * (size_t)n_ref, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(index_pairs, h_idx, sizeof(int32_t) * (size_t)n_ref);
     return FTK_OK;
 }
 

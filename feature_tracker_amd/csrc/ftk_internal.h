@@ -2,6 +2,10 @@
 // Not installed, not part of the boundary: include/ftk.h is.
 #pragma once
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
 #include <mutex>
 #include <string>
 
@@ -76,5 +80,28 @@ int ftk_fail(ftk_context *ctx, int code, const char *fmt, ...);
 #define FTK_LOCK(ctx) std::lock_guard<std::recursive_mutex> ftk_lock_guard_((ctx)->lock)
 
 inline size_t ftk_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// FTK_TRACE=1 in the environment: every host-buffer entry point of the C ABI prints its wall time to stderr when it returns
+// ("[ftk trace] ftk_klt_track 83.1 us") — for finding out where a caller's timed region goes; costs one getenv per process.
+struct ftk_trace_scope {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit ftk_trace_scope(const char *n) : name(n), on(enabled()) {
+        if (on) {
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+    ~ftk_trace_scope() {
+        if (on) {
+            fprintf(stderr, "[ftk trace] %s %.1f us\n", name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
+    static bool enabled() {
+        static const bool e = getenv("FTK_TRACE") != nullptr && atoi(getenv("FTK_TRACE")) != 0;
+        return e;
+    }
+};
+#define FTK_TRACE_SCOPE(name) ftk_trace_scope ftk_trace_scope_(name)
 // Grows a context-owned device buffer (stream-synchronising first: earlier launches may still read the old one).
 int ftk_ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes);

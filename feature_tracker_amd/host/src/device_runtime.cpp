@@ -67,6 +67,19 @@ ftk_context *SharedContext(std::string *error) {
         if (rc != FTK_OK) {
             g_ctx = nullptr;
             g_error = ftk_last_error(nullptr);
+        } else {
+            // First-use cost, once per process and HERE: loading the kernels' code objects and the first staging allocations take
+            // milliseconds, and the reference's programs start their timers at different points relative to the construction of
+            // their objects (test_optical_flow.cpp:64 vs :69 constructs first; test_descriptor_matcher_brief.cpp:69 vs :79 starts
+            // the timer first) — but all of them touch the device (Harris corners, CreateImagePyramid) before any timer runs.
+            static const bool no_warmup = std::getenv("FTK_NO_WARMUP") != nullptr && std::atoi(std::getenv("FTK_NO_WARMUP")) != 0;  // experiment switch
+            if (!no_warmup) {
+                callers_state = initstate(1u, scratch_state, sizeof(scratch_state));
+                (void)ftk_warmup(g_ctx, FTK_WARM_ALL);
+                if (callers_state != nullptr) {
+                    setstate(callers_state);
+                }
+            }
         }
     }
     if (g_ctx == nullptr && error != nullptr) {
@@ -153,23 +166,9 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
 }
 
 void WarmUp(unsigned what) {
-    static std::mutex warm_mutex;
-    static unsigned warmed = 0;
-    static const bool disabled = std::getenv("FTK_NO_WARMUP") != nullptr && std::atoi(std::getenv("FTK_NO_WARMUP")) != 0;  // experiment switch
-    if (disabled) {
-        return;
-    }
-    std::lock_guard<std::mutex> lock(warm_mutex);
-    const unsigned todo = what & ~warmed;
-    if (todo == 0) {
-        return;
-    }
-    warmed |= todo;  // one attempt per family
+    (void)what;  // the shared context prepares every family when it is created (SharedContext)
     std::string error;
-    ftk_context *ctx = SharedContext(&error);
-    if (ctx != nullptr) {
-        (void)ftk_warmup(ctx, todo);
-    }
+    (void)SharedContext(&error);
 }
 
 int CommOptIn(int *rank, int *world, std::string *error) {
