@@ -142,8 +142,6 @@ namespace {
 
 int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) { return ftk_ensure_device_buffer(ctx, buf, have, bytes); }
 
-uint32_t div_magic(int32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
-
 int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, int32_t n,
                     const float *prior, int consider_luminance, int single_level, ftk::KltParams *out) {
     if (!opt || !ref || !cur) {
@@ -193,31 +191,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.prior[i] = pr[i];
     }
     p.consider_luminance = consider_luminance ? 1 : 0;
-    p.patch_rows = 2 * opt->half_rows + 1;
-    p.patch_cols = 2 * opt->half_cols + 1;
-    p.P = p.patch_rows * p.patch_cols;
-    p.Ppad = (p.P + 3) & ~3;
-    p.ex_rows = p.patch_rows + 2;
-    p.ex_cols = p.patch_cols + 2;
-    p.E = p.ex_rows * p.ex_cols;
-    {
-        const int32_t epad = (p.E + 3) & ~3, tables = 12 * (p.patch_rows + p.patch_cols);
-        p.a0_floats = epad > tables ? epad : tables;
-    }
-    p.magic_pc = div_magic(p.patch_cols);
-    // the same division on the full-rate 24-bit multiplier when it is exact over the whole patch: x * (M * d - 2^20) < 2^20 for all x < P
-    p.magic_pc20 = (p.patch_cols > 1 && (long long)p.P * p.patch_cols < (1ll << 20) && p.P < (1 << 12))
-                       ? (uint32_t)(((1u << 20) + (uint32_t)p.patch_cols - 1) / (uint32_t)p.patch_cols) : 0u;
-    p.magic_exc = div_magic(p.ex_cols);
-    p.rwin_rows = p.patch_rows + 3;
-    p.rwin_cols = (p.patch_cols + 3 + 3) & ~3;  // pixel-pair columns, rounded up to a multiple of 4 (8-byte LDS stores)
-    p.cwin_margin = 2;
-    p.cwin_rows = p.rwin_rows + 2 * p.cwin_margin;
-    p.cwin_cols = (p.patch_cols + 3 + 2 * p.cwin_margin + 3) & ~3;
-    p.magic_rwc = div_magic(p.rwin_cols);
-    p.magic_cwc = div_magic(p.cwin_cols);
-    p.magic_rwq = div_magic(p.rwin_cols / 4);
-    p.magic_cwq = div_magic(p.cwin_cols / 4);
+    ftk::klt_fill_geometry(p);  // patch / window / lattice geometry: everything that follows from the half sizes alone (ftk_device.h)
     // Wavefronts per feature (measured on MI355X; 4096 wave slots at 4 waves per SIMD):
     //  * small batches are latency-bound: up to 4 waves share the pixel loops (21x21 patch, <= 1024
     //    features: 56 / 41 / 32 us per call at 1 / 2 / 4 waves);
@@ -290,26 +264,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
         }
     }
-    p.pb_rwin_rows = p.patch_rows + 4;
-    p.pb_rwin_cols = (p.patch_cols + 4 + 3) & ~3;
-    p.pb_magic_rwc = div_magic(p.pb_rwin_cols);
-    p.pb_magic_rwq = div_magic(p.pb_rwin_cols / 4);
-    {
-        // extras per axis: a unit step crosses at most log2(len + 2) + 3 binade boundaries, two nodes each
-        auto extras = [](int len) {
-            int bits = 0;
-            while ((1 << bits) < len + 2) {
-                ++bits;
-            }
-            return 2 * (bits + 3);
-        };
-        p.pb_cap_r = p.patch_rows + 2 + extras(p.patch_rows);
-        p.pb_cap_c = p.patch_cols + 2 + extras(p.patch_cols);
 #ifdef FTK_PB_EXTRAS_TIMING_ONLY  // diagnostic builds only (scripts/build_variant.sh): a capacity below the provable maximum gives wrong results
-        p.pb_cap_r = p.patch_rows + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
-        p.pb_cap_c = p.patch_cols + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
+    p.pb_cap_r = p.patch_rows + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
+    p.pb_cap_c = p.patch_cols + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
 #endif
-    }
     const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
     if (lds == 0 || lds > 160 * 1024) {
         return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu B of LDS (limit 163840)", p.patch_rows, p.patch_cols, lds);

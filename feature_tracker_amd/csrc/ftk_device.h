@@ -71,6 +71,52 @@ struct KltParams {
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
 };
 
+// ceil(2^32 / d): row = umulhi(index, magic)
+__host__ __device__ constexpr uint32_t klt_div_magic(int32_t d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+
+// Everything in KltParams that follows from (half_rows, half_cols) ALONE.  One definition for the host (fill_klt_params) and
+// for the kernels' compile-time specialisations (klt_basic_kernels.hip instantiates the pipelined kernel for the common patch
+// sizes: the geometry then folds into immediates instead of living in ~40 SGPRs, most of them spilled to vector lanes).
+__host__ __device__ constexpr void klt_fill_geometry(KltParams &p) {
+    p.patch_rows = 2 * p.half_rows + 1;
+    p.patch_cols = 2 * p.half_cols + 1;
+    p.P = p.patch_rows * p.patch_cols;
+    p.Ppad = (p.P + 3) & ~3;
+    p.ex_rows = p.patch_rows + 2;
+    p.ex_cols = p.patch_cols + 2;
+    p.E = p.ex_rows * p.ex_cols;
+    const int32_t epad = (p.E + 3) & ~3, tables = 12 * (p.patch_rows + p.patch_cols);
+    p.a0_floats = epad > tables ? epad : tables;
+    p.magic_pc = klt_div_magic(p.patch_cols);
+    // the same division on the full-rate 24-bit multiplier when it is exact over the whole patch: x * (M * d - 2^20) < 2^20 for all x < P
+    p.magic_pc20 = (p.patch_cols > 1 && (long long)p.P * p.patch_cols < (1ll << 20) && p.P < (1 << 12))
+                       ? (uint32_t)(((1u << 20) + (uint32_t)p.patch_cols - 1) / (uint32_t)p.patch_cols) : 0u;
+    p.magic_exc = klt_div_magic(p.ex_cols);
+    p.rwin_rows = p.patch_rows + 3;
+    p.rwin_cols = (p.patch_cols + 3 + 3) & ~3;  // pixel-pair columns, rounded up to a multiple of 4 (8-byte LDS stores)
+    p.cwin_margin = 2;
+    p.cwin_rows = p.rwin_rows + 2 * p.cwin_margin;
+    p.cwin_cols = (p.patch_cols + 3 + 2 * p.cwin_margin + 3) & ~3;
+    p.magic_rwc = klt_div_magic(p.rwin_cols);
+    p.magic_cwc = klt_div_magic(p.cwin_cols);
+    p.magic_rwq = klt_div_magic(p.rwin_cols / 4);
+    p.magic_cwq = klt_div_magic(p.cwin_cols / 4);
+    p.pb_rwin_rows = p.patch_rows + 4;
+    p.pb_rwin_cols = (p.patch_cols + 4 + 3) & ~3;
+    p.pb_magic_rwc = klt_div_magic(p.pb_rwin_cols);
+    p.pb_magic_rwq = klt_div_magic(p.pb_rwin_cols / 4);
+    // lattice extras per axis: a unit step crosses at most log2(len + 2) + 3 binade boundaries, two nodes each
+    int bits_r = 0, bits_c = 0;
+    while ((1 << bits_r) < p.patch_rows + 2) {
+        ++bits_r;
+    }
+    while ((1 << bits_c) < p.patch_cols + 2) {
+        ++bits_c;
+    }
+    p.pb_cap_r = p.patch_rows + 2 + 2 * (bits_r + 3);
+    p.pb_cap_c = p.patch_cols + 2 + 2 * (bits_c + 3);
+}
+
 // LDS bytes a (model, method) variant needs for the given geometry; 0 if the variant is unknown.
 size_t klt_lds_bytes(int model, int method, const KltParams &p);
 // Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.

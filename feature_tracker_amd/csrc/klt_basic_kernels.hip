@@ -34,6 +34,8 @@
 #define FTK_CHAIN_ROUND 4  // 16 terms per round: the consumer wave holds 32 VGPRs of prefetched terms
 #include "klt_common.h"
 
+#include <stdlib.h>
+
 namespace ftk {
 namespace {
 
@@ -322,8 +324,19 @@ __device__ __forceinline__ void pb_sync(bool solo) {
 
 // SOLO: one wave per feature, p.features_per_group features per workgroup (compile-time, so that the one-wave code carries none
 // of the producer / consumer split).
-template <bool SOLO>
-__global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p) {
+// HR / HC: the half patch sizes as compile-time constants (the common ones are instantiated below), or 0 / 0 for "as passed":
+// the whole patch / window / lattice geometry then folds into immediates (klt_fill_geometry) instead of being ~40 SGPR-resident
+// kernel arguments, most of which the register allocator spills to vector lanes (106 SGPRs + 104 spills in the generic form).
+template <bool SOLO, int HR, int HC>
+__global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p_arg) {
+    // `p` carries everything but the level tables, which stay in the kernel argument (p_arg.ref / p_arg.cur): a local copy whose
+    // arrays are indexed with a run-time level would be placed in scratch memory (measured: the kernel twice as slow).
+    KltParams p = p_arg;
+    if constexpr (HR > 0 && HC > 0) {
+        p.half_rows = HR;
+        p.half_cols = HC;
+        klt_fill_geometry(p);  // the same function the host filled p_arg with: identical values, now compile-time
+    }
     extern __shared__ float4 lds_raw[];
     Blk b;
     uint32_t id;
@@ -412,16 +425,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     int buf = 0;
     {
         // the coarsest level's reference window: nothing to overlap it with yet
-        const DevImage ref = p.ref[p.n_levels - 1];
+        const DevImage ref = p_arg.ref[p.n_levels - 1];
         int r_lo, c_lo;
         footprint_origin(p, ref_u, ref_v, r_lo, c_lo);
         stage_any(opaque_blk(b), ref, c.ref_win, r_lo, c_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
     }
+#ifdef FTK_STAMPS_FINE2
+    FTK_STAMP_END(b, 2);  // fine2: the prologue's reference window (reported in the "count" column together with the B1 waits)
+#endif
     uint32_t iters = 0;
     float out_u = in_u, out_v = in_v;
     for (int level = p.n_levels - 1; level > -1; --level) {
-        const DevImage ref = p.ref[level];
-        const DevImage cur = p.cur[level];
+        const DevImage ref = p_arg.ref[level];
+        const DevImage cur = p_arg.cur[level];
         set_level_priority(level);
 #ifdef FTK_PB_CHAIN_PRIO
         if (b.nwaves > 1) {
@@ -455,18 +471,23 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             footprint_origin(p, ref_u * 2.0f, ref_v * 2.0f, nr_lo, nc_lo);
         }
         const bool cur_async = cur_fits && window_inside(cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols);
-        const bool next_async = level > 0 && ref_fits && window_inside(p.ref[level > 0 ? level - 1 : 0], nr_lo, nc_lo, rrows, rcols);
+        const bool next_async = level > 0 && ref_fits && window_inside(p_arg.ref[level > 0 ? level - 1 : 0], nr_lo, nc_lo, rrows, rcols);
         // the window loads are issued FIRST (they depend on the footprints only) and fly while the node tables and
         // the lattice are built: at one wave per feature the level entry is a chain of dependent latencies
         RawQuads<kCurQuads> qc;
         RawQuads<kRefQuads> qn;
+#ifdef FTK_STAMPS_FINE2
+        FTK_STAMP_END(b, 0);  // fine2: footprints, window tests, level priority, DevImage fetches
+#endif
         if (cur_async) {
             issue_quads(qc, b, cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwq);
         }
         if (next_async) {
-            issue_quads(qn, b, p.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
+            issue_quads(qn, b, p_arg.ref[level - 1], nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwq);
         }
-#ifdef FTK_STAMPS_FINE
+#ifdef FTK_STAMPS_FINE2
+        FTK_STAMP_END(b, 1);  // fine2: issuing the window loads
+#elif defined(FTK_STAMPS_FINE)
         FTK_STAMP_END(b, 0);  // fine: footprints + issuing the window loads
 #endif
         if (b.wave == 0) {
@@ -483,7 +504,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 build_nodes_pass(lane, ac, none);
             }
         }
-#ifdef FTK_STAMPS_FINE
+#ifdef FTK_STAMPS_FINE2
+        FTK_STAMP_END(b, 3);  // fine2: node tables (wave 0) land in the lattice column
+        pb_sync(solo);
+        FTK_STAMP_END(b, 2);
+#elif defined(FTK_STAMPS_FINE)
         FTK_STAMP_END(b, 1);  // fine: node tables (wave 0)
         pb_sync(solo);
         FTK_STAMP_END(b, 2);  // fine: wait at B1
@@ -515,7 +540,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             if (next_async) {
                 store_quads(qn, b, c.ref_win + (buf ^ 1) * c.ref_win_stride, rrows, rcols, p.pb_magic_rwq);
             } else {
-                stage_any(opaque_blk(b), p.ref[level - 1], c.ref_win + (buf ^ 1) * c.ref_win_stride, nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
+                stage_any(opaque_blk(b), p_arg.ref[level - 1], c.ref_win + (buf ^ 1) * c.ref_win_stride, nr_lo, nc_lo, rrows, rcols, p.pb_magic_rwc, p.pb_magic_rwq);
             }
         }
 #ifdef FTK_STAMPS_FINE
@@ -631,7 +656,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         FTK_STAMP_BEGIN(b);
     }
 
-    if (uv_outside(out_u, out_v, p.cur[0])) {
+    if (uv_outside(out_u, out_v, p_arg.cur[0])) {
         status = FTK_OUTSIDE;  // basic_klt.cpp:49-53
     }
     if (b.tid == 0) {
@@ -691,7 +716,22 @@ hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream)
     if (solo && p.features_per_group < 1) {
         p.features_per_group = 1;
     }
-    auto kernel = solo ? klt_basic_inverse_pipelined_kernel<true> : klt_basic_inverse_pipelined_kernel<false>;
+    // compile-time geometry for the patch sizes of the BASELINE configurations and the reference's default (11x11, 13x13, 21x21)
+    void (*kernel)(const KltParams) = solo ? klt_basic_inverse_pipelined_kernel<true, 0, 0> : klt_basic_inverse_pipelined_kernel<false, 0, 0>;
+    static const bool specialise = !(getenv("FTK_PB_SPECIALISE") && atoi(getenv("FTK_PB_SPECIALISE")) == 0);  // experiment switch
+    if (specialise && p.half_rows == p.half_cols) {
+        KltParams check = p;
+        klt_fill_geometry(check);  // the specialised kernels recompute exactly this: refuse them if the caller's geometry differs (diagnostic builds)
+        const bool same = check.pb_cap_r == p.pb_cap_r && check.pb_cap_c == p.pb_cap_c && check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols;
+        if (same) {
+            switch (p.half_rows) {
+                case 5: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 5, 5> : klt_basic_inverse_pipelined_kernel<false, 5, 5>; break;
+                case 6: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 6, 6> : klt_basic_inverse_pipelined_kernel<false, 6, 6>; break;
+                case 10: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 10, 10> : klt_basic_inverse_pipelined_kernel<false, 10, 10>; break;
+                default: break;
+            }
+        }
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
