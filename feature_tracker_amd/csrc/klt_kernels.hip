@@ -38,6 +38,8 @@
 #define FTK_CHAIN_ROUND 4
 #include "klt_common.h"
 
+#include <stdlib.h>
+
 namespace ftk {
 namespace {
 
@@ -1568,8 +1570,21 @@ constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest firs
 // grouped product layout, affine_all_terms, they fit 128 like the rest.)
 // SOLO: the one-wave-per-feature instantiation (workgroup = one wavefront): compile-time, so that no barrier and no cross-wave
 // exchange is left in it.
-template <int MODEL, int METHOD, bool SOLO>
-__global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p) {
+// H: the half patch size (rows == columns) as a compile-time constant — 6, the reference's default (optical_flow.h:24-25) and
+// the patch of BASELINE configurations 3 and 4, is instantiated — or 0 for "as passed".  With it the patch / window geometry
+// folds into immediates (klt_fill_geometry, the function the host filled the argument with) instead of occupying SGPRs, most
+// of which the register allocator otherwise spills to vector lanes.
+template <int MODEL, int METHOD, bool SOLO, int H>
+__global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p_arg) {
+    // `p` carries everything but the level tables, which stay in the kernel argument: a local copy whose arrays are indexed
+    // with a run-time level would live in scratch memory
+    KltParams p = p_arg;
+    if constexpr (H > 0) {
+        p.half_rows = H;
+        p.half_cols = H;
+        klt_fill_geometry(p);
+        p.a0_floats = p_arg.a0_floats;  // the host overrides it for the chunked LSSD variant (its extended patch lives in the ring's space)
+    }
     extern __shared__ float4 lds_raw[];
     Blk b;
     b.solo = SOLO;
@@ -1661,8 +1676,8 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     float out_u = in_u, out_v = in_v;
     const Blk &b0 = b;
     for (int level = p.n_levels - 1; level > -1; --level) {
-        const DevImage ref = p.ref[level];
-        const DevImage cur = p.cur[level];
+        const DevImage ref = p_arg.ref[level];
+        const DevImage cur = p_arg.cur[level];
         blk_sync(b);  // the previous level's readers of the LDS windows / arrays are done
         const Blk b = opaque_blk(b0);  // per-thread index math stays inside the level (see opaque())
         // the features the launch order put first are the ones expected to run longest — the launch ends when they do — so
@@ -1726,7 +1741,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         }
     }
 
-    if (uv_outside(out_u, out_v, p.cur[0])) {
+    if (uv_outside(out_u, out_v, p_arg.cur[0])) {
         status = FTK_OUTSIDE;
     }
     if (b.tid == 0) {
@@ -1752,7 +1767,20 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
 
 template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
-    auto kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true> : klt_track_kernel<MODEL, METHOD, false>;
+    void (*kernel)(const KltParams) = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0> : klt_track_kernel<MODEL, METHOD, false, 0>;
+    static const bool specialise = !(getenv("FTK_KLT_SPECIALISE") && atoi(getenv("FTK_KLT_SPECIALISE")) == 0);  // experiment switch
+    // (measured per variant, 13 x 13: Basic -6...-14 %, LSSD -16...-21 %, affine fast -16 %; the non-fast affine variants — 24 sums per
+    // pixel, at the register cap already — get 9...18 % SLOWER with the geometry folded in and keep the run-time form)
+    constexpr bool gains = !(MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST);
+    if constexpr (gains) {
+        if (specialise && p.half_rows == 6 && p.half_cols == 6) {
+            KltParams check = p;
+            klt_fill_geometry(check);  // what the specialised kernel recomputes: it must be what the caller passed
+            if (check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols && check.Ppad == p.Ppad && check.rwin_cols == p.rwin_cols) {
+                kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 6> : klt_track_kernel<MODEL, METHOD, false, 6>;
+            }
+        }
+    }
     const unsigned sort_block = p.sort_iters ? 1u : 0u;  // one more workgroup: the sort of a later call's launch order
     if (sort_block && lds_bytes < (size_t)kOrderLdsBytes) {
         lds_bytes = kOrderLdsBytes;
