@@ -627,12 +627,15 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
     }
     pyr->levels[0].rows = rows;
     pyr->levels[0].cols = cols;
-    for (int i = 1; i < n_levels && e == hipSuccess; ++i) {
-        uint8_t *dst = pyr->owned + offsets[i];
-        e = ftk::pyramid_downsample_launch(pyr->levels[i - 1].data, lrows[i - 1], lcols[i - 1], dst, ctx->stream);
-        pyr->levels[i].data = dst;
+    uint8_t *level_ptr[FTK_MAX_LEVELS] = {nullptr};
+    for (int i = 1; i < n_levels; ++i) {
+        level_ptr[i] = pyr->owned + offsets[i];
+        pyr->levels[i].data = level_ptr[i];
         pyr->levels[i].rows = lrows[i];
         pyr->levels[i].cols = lcols[i];
+    }
+    if (e == hipSuccess) {
+        e = ftk::pyramid_build_levels_launch(pyr->levels[0].data, rows, cols, level_ptr, n_levels, ctx->stream);  // one launch for all levels
     }
     if (e == hipSuccess && !image_on_device) {
         e = hipStreamSynchronize(ctx->stream);  // host image may be released by the caller
@@ -664,10 +667,16 @@ int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image,
     const size_t bytes0 = (size_t)pyr->levels[0].rows * pyr->levels[0].cols;
     FTK_HIP(ctx, hipMemcpyAsync(pyr->owned, image, bytes0, image_location == FTK_IMAGE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                 ctx->stream));
+    uint8_t *level_ptr[FTK_MAX_LEVELS] = {nullptr};
+    bool halves = true;  // every level is the floor-half of the one above it (true for every pyramid this library builds)
     for (int i = 1; i < pyr->n_levels; ++i) {
-        FTK_HIP(ctx, ftk::pyramid_downsample_launch(pyr->levels[i - 1].data, pyr->levels[i - 1].rows, pyr->levels[i - 1].cols,
-                                                    const_cast<uint8_t *>(pyr->levels[i].data), ctx->stream));
+        level_ptr[i] = const_cast<uint8_t *>(pyr->levels[i].data);
+        halves = halves && pyr->levels[i].rows == pyr->levels[i - 1].rows / 2 && pyr->levels[i].cols == pyr->levels[i - 1].cols / 2;
     }
+    if (!halves) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_update: the levels of this pyramid are not successive halves (uploaded with another geometry)");
+    }
+    FTK_HIP(ctx, ftk::pyramid_build_levels_launch(pyr->levels[0].data, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream));
     if (image_location == FTK_IMAGE_HOST) {
         FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may release or rewrite the host image on return
     }

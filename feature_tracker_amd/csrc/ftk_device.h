@@ -242,6 +242,8 @@ hipError_t harris_launch(const HarrisParams &p, hipStream_t stream);
 hipError_t unpack_klt_shards_launch(const uint8_t *d_gathered, int32_t n, int32_t world, int32_t cap, int64_t shard_bytes, float *d_uv_out,
                                     uint8_t *d_status_out, hipStream_t stream);
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream);
+// Levels 1 .. n_levels - 1 from level 0 (dst[l] = level l, l >= 1): one fused launch (pyramid_fused_kernel), deeper levels one by one.
+hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream);
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);
 

@@ -10,6 +10,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace ftk {
 namespace {
@@ -57,6 +58,84 @@ __global__ void __launch_bounds__(kBlock) downsample_kernel(const uint8_t *__res
             const unsigned sum = (unsigned)top[2 * k] + top[2 * k + 1] + bottom[2 * k] + bottom[2 * k + 1];
             out[k] = (uint8_t)(sum >> 2);
         }
+    }
+}
+
+// Every level of a pyramid in ONE launch.  CreateImagePyramid sits inside the reference's timed region, right in front of
+// TrackFeatures (test/test_optical_flow.cpp:69-73), and a launch per level costs more in launch gaps than the kernels take at
+// camera resolutions (640 x 480: three ~3 us launches for 0.1 MB of work).  A workgroup owns one 64 x 64 tile of level 0; since 64
+// is a multiple of 2^l for every level it serves (l <= 6), the tile maps onto a whole (64 >> l)^2 tile of level l and no
+// workgroup needs another's pixels.  Level l + 1 is computed from the level-l BYTES just produced (kept in LDS), so the values
+// are those of the level-by-level kernel: the truncating mean of truncated means, not a mean over the 4^l source pixels.
+// rows_l = rows >> l (floor division composes), so an odd trailing row / column drops out exactly as in the reference.
+constexpr int kTile = 64;
+constexpr int kFusedMaxLevels = 7;  // levels 1..6 below a 64 x 64 tile; deeper pyramids finish with the per-level kernel
+
+struct PyramidLevels {
+    uint8_t *dst[kFusedMaxLevels];  // [l]: level l (l >= 1); [0] unused
+    int32_t n_levels;               // levels to produce here incl. level 0: 2..kFusedMaxLevels
+};
+
+__global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__restrict__ src, int rows, int cols, PyramidLevels lv) {
+    __shared__ uint8_t tile[2][kTile * kTile];  // ping-pong: level l in tile[l & 1], pitch kTile >> l
+    const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
+    const int r0 = ty * kTile, c0 = tx * kTile;
+    // level 0 -> LDS: 256 threads x 16 bytes per pass, rows of 64 bytes; pixels beyond the image are never read by a valid output
+    for (int k = tid; k < kTile * kTile / 16; k += kBlock) {
+        const int r = k >> 2, seg = (k & 3) << 4;
+        const int gr = r0 + r, gc = c0 + seg;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gr < rows) {
+            const uint8_t *q = src + (size_t)gr * (size_t)cols + (size_t)gc;
+            if (gc + 16 <= cols) {
+                __builtin_memcpy(&v, q, 16);  // unaligned 16-byte load
+            } else if (gc < cols) {
+                uint8_t tmp[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    tmp[i] = (gc + i < cols) ? q[i] : (uint8_t)0;
+                }
+                __builtin_memcpy(&v, tmp, 16);
+            }
+        }
+        *reinterpret_cast<uint4 *>(&tile[0][r * kTile + seg]) = v;
+    }
+    __syncthreads();
+    int lrows = rows, lcols = cols;
+    for (int l = 1; l < lv.n_levels; ++l) {
+        lrows >>= 1;
+        lcols >>= 1;
+        const int side = kTile >> l, prev_pitch = kTile >> (l - 1);
+        const uint8_t *in = tile[(l - 1) & 1];
+        uint8_t *out = tile[l & 1];
+        const int lr0 = r0 >> l, lc0 = c0 >> l;
+        uint8_t *g = lv.dst[l];
+        // four horizontally adjacent outputs per thread where the level is wide enough: one 32-bit store
+        const int quads = side >= 4 ? side >> 2 : 1, per = side >= 4 ? 4 : side;
+        for (int k = tid; k < side * quads; k += kBlock) {
+            const int r = k / quads, q = (k - r * quads) * per;
+            uint32_t packed = 0;
+#pragma unroll 4
+            for (int i = 0; i < per; ++i) {
+                const uint8_t *t = in + (2 * r) * prev_pitch + 2 * (q + i);
+                const uint32_t sum = (uint32_t)t[0] + t[1] + t[prev_pitch] + t[prev_pitch + 1];
+                const uint32_t m = sum >> 2;
+                out[r * side + q + i] = (uint8_t)m;
+                packed |= m << (8 * i);
+            }
+            const int gr = lr0 + r, gc = lc0 + q;
+            if (gr < lrows && gc < lcols) {
+                uint8_t *o = g + (size_t)gr * (size_t)lcols + (size_t)gc;
+                if (per == 4 && gc + 4 <= lcols && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+                    *reinterpret_cast<uint32_t *>(o) = packed;
+                } else {
+                    for (int i = 0; i < per && gc + i < lcols; ++i) {
+                        o[i] = (uint8_t)(packed >> (8 * i));
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -139,6 +218,37 @@ hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32
     const unsigned blocks = (unsigned)((groups + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(downsample_kernel, dim3(blocks), dim3(kBlock), 0, stream, src, src_cols, dst, dst_rows, dst_cols);
     return hipGetLastError();
+}
+
+// Levels 1 .. n_levels - 1 of a pyramid whose level 0 is `level0` (rows x cols): one fused launch for the first six, the
+// per-level kernel for anything deeper.  dst[l] / out_rows / out_cols describe level l (entries >= 1 are used).
+hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream) {
+    if (n_levels <= 1) {
+        return hipSuccess;
+    }
+    static const bool fused = !(getenv("FTK_PYRAMID_FUSED") && atoi(getenv("FTK_PYRAMID_FUSED")) == 0);  // experiment switch
+    int done = 1;  // levels that exist so far
+    if (fused) {
+        PyramidLevels lv;
+        lv.n_levels = n_levels < kFusedMaxLevels ? n_levels : kFusedMaxLevels;
+        for (int l = 0; l < kFusedMaxLevels; ++l) {
+            lv.dst[l] = (l >= 1 && l < lv.n_levels) ? dst[l] : nullptr;
+        }
+        const dim3 grid((unsigned)((cols + kTile - 1) / kTile), (unsigned)((rows + kTile - 1) / kTile));
+        hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(kBlock), 0, stream, level0, rows, cols, lv);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            return e;
+        }
+        done = lv.n_levels;
+    }
+    for (int l = done; l < n_levels; ++l) {
+        const hipError_t e = pyramid_downsample_launch(l == 1 ? level0 : dst[l - 1], rows >> (l - 1), cols >> (l - 1), dst[l], stream);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    return hipSuccess;
 }
 
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,

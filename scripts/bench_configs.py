@@ -58,6 +58,36 @@ def klt_case(name, cfg, torch, F, D, synth, oracle, reps, cpu_reps, motion=(3.3,
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
         gpu_uv, gpu_st, iters = d_out.cpu().numpy(), d_sto.cpu().numpy(), d_it.cpu().numpy()
+        # Launch order (calls of >= 4096 features are launched longest-first by the iteration counts of two calls before,
+        # ftk_klt_track_device): the loop above repeats ONE call, so its predictor is perfect ("warm").  Two more regimes:
+        #   cold     — no history: a call with another feature count in between resets it, every timed call runs in list order;
+        #   permuted — the feature list is reshuffled between calls (features re-detected in another order): the counts of two
+        #              calls ago belong to other features, i.e. the order in use is an arbitrary one.
+        order_regimes = None
+        if n >= 4096:
+            def timed(fn_before, args):
+                out = []
+                for k in range(reps):
+                    fn_before(k)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    klt.track(*args(k))
+                    e1.record(stream)
+                    e1.synchronize()
+                    out.append(e0.elapsed_time(e1))
+                return float(np.median(out))
+
+            def reset_history(_k):
+                klt.track(d_ref[: n - 1], d_in[: n - 1], d_st[: n - 1], d_out[: n - 1], d_sto[: n - 1], None)
+
+            cold_ms = timed(reset_history, lambda k: (d_ref, d_in, d_st, d_out, d_sto, None))
+            rs = np.random.RandomState(5)
+            shuffled = [torch.from_numpy(np.ascontiguousarray(uv[rs.permutation(n)])).to(dev) for _ in range(5)]
+            for k in range(4):  # history of the same length as in the timed loop
+                klt.track(shuffled[k % 5], shuffled[k % 5], d_st, d_out, d_sto, None)
+            perm_ms = timed(lambda _k: None, lambda k: (shuffled[k % 5], shuffled[k % 5], d_st, d_out, d_sto, None))
+            order_regimes = {"warm_ms": float(np.median(times)), "cold_ms": cold_ms, "permuted_ms": perm_ms}
+            stream.synchronize()
     # host-call path (what the C++ / Python classes do per TrackFeatures)
     cls = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}[model]()
     o = cls.options()
@@ -94,7 +124,7 @@ def klt_case(name, cfg, torch, F, D, synth, oracle, reps, cpu_reps, motion=(3.3,
         "tracked_fraction": float((cst == 1).mean()), "mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
         "parity_max_px": float(d.max()) if d.size else 0.0, "parity_frac_gt_1e-3": float((d > 1e-3).mean()) if d.size else 0.0,
         "bit_identical": bool(np.array_equal(gpu_uv.view(np.uint32), cuv.view(np.uint32))), "status_mismatches": int((gpu_st != cst).sum()),
-        "algorithmic_bytes": int(algo), "algorithmic_GBps": algo / (gpu_ms * 1e-3) / 1e9,
+        "algorithmic_bytes": int(algo), "algorithmic_GBps": algo / (gpu_ms * 1e-3) / 1e9, "launch_order_regimes": order_regimes,
     }
 
 

@@ -232,7 +232,9 @@ def test_extract_extend_patch(ftk, oracle):
 def test_pyramid_build_matches_oracle(ftk, oracle):
     """Device CreateImagePyramid == truncating 2x2 box mean, including odd sizes."""
     from feature_tracker_amd import synth
-    for (w, h, levels) in [(640, 480, 4), (321, 243, 4), (37, 29, 3)]:
+    # one fused launch builds levels 1..6 from 64 x 64 tiles (pyramid_kernels.hip), deeper levels one by one: odd sizes, sizes
+    # around the tile edge, more than seven levels, a full-HD frame
+    for (w, h, levels) in [(640, 480, 4), (321, 243, 4), (37, 29, 3), (65, 64, 5), (63, 129, 6), (300, 260, 8), (1920, 1080, 5), (128, 128, 7), (2, 2, 2)]:
         img, _ = synth.make_image_pair(w, h)
         pyr = ftk.ImagePyramid.build(img, levels)
         ref = oracle.create_pyramid(img, levels)
