@@ -247,9 +247,9 @@ __device__ __forceinline__ float node_tap(const uint16_t *win, int wcols, const 
 }
 
 // Per-iteration tables of the current-image taps, private to one producer wave (so no barrier):
-// entry 2t   = node_entry of the current coordinate of patch row / column t, w = valid AND the
-//              reference-side validity of that row / column
-// entry 2t+1 = lattice offsets {centre, minus, plus} of that row (pre-multiplied by n_c) / column
+// entry t         = node_entry of the current coordinate of patch row / column t, w = valid AND the
+//                   reference-side validity of that row / column
+// entry total + t = lattice offsets {centre, minus, plus} of that row (pre-multiplied by n_c) / column
 __device__ __forceinline__ void cur_tables(int lane, const KltParams &p, const PbLds &c, float4 *tab, const DevImage &cur, const Win &cw, float cur_u,
                                            float cur_v, int n_c) {
     const int total = p.patch_rows + p.patch_cols;
@@ -262,8 +262,10 @@ __device__ __forceinline__ void cur_tables(int lane, const KltParams &p, const P
         const uint4 id = is_row ? c.ridx[d] : c.cidx[d];
         e.w = __int_as_float(__float_as_int(e.w) & (int)id.w);
         const int mul = is_row ? n_c : 1;
-        tab[2 * t] = e;
-        tab[2 * t + 1] = make_float4(__int_as_float((int)id.x * mul), __int_as_float((int)id.y * mul), __int_as_float((int)id.z * mul), 0.0f);
+        // two arrays, not interleaved pairs: the pixel lanes of a chunk read consecutive COLUMN entries with ds_read_b128, and
+        // 32-byte strides put lanes i and i + 8 of a 16-lane group on the same banks (a 2-way conflict on every such read)
+        tab[t] = e;
+        tab[total + t] = make_float4(__int_as_float((int)id.x * mul), __int_as_float((int)id.y * mul), __int_as_float((int)id.z * mul), 0.0f);
     }
 }
 
@@ -274,8 +276,9 @@ __device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltPara
     const int pp = in ? pxi : 0;
     int prow, pcol;
     pixel_rc(p, pp, prow, pcol);
-    const float4 r0 = tab[2 * prow], r1 = tab[2 * prow + 1];
-    const float4 c0 = tab[2 * (p.patch_rows + pcol)], c1 = tab[2 * (p.patch_rows + pcol) + 1];
+    const int tab_total = p.patch_rows + p.patch_cols;
+    const float4 r0 = tab[prow], r1 = tab[tab_total + prow];
+    const float4 c0 = tab[p.patch_rows + pcol], c1 = tab[tab_total + p.patch_rows + pcol];
     const float i_cur = node_tap(cw.data, cw.cols, r0, c0);
     const float *lat = c.lattice;
     const int rc = __float_as_int(r1.x), rm = __float_as_int(r1.y), rp = __float_as_int(r1.z);
