@@ -450,6 +450,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", help="feature_tracker_amd.synth.CONFIGS key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tree-leg", action="store_true", help="skip the throughput_mode measurement (N = 1 only; it runs after the timed region)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the with_pyramid_upload measurement (N = 1 only; it runs after the timed region)")
     ap.add_argument("--shard-total", type=int, default=0,
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
@@ -661,6 +662,25 @@ def main():
             b.record(stream)
         torch.cuda.synchronize()
         event_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in zip(null0, null1)]))
+        # Throughput mode (ftk_set_reduction_mode(TREE)): the same launches with butterfly sums instead of the exact-order chains.
+        # Reported beside the contract path — what bit-exactness costs — never asserted and never the headline.
+        tree = None
+        if world == 1 and not args.no_tree_leg:
+            ctx.set_reduction("tree")
+            try:
+                tree_out = (torch.empty_like(views2[1][0]), torch.empty_like(views2[1][1]))
+                tree_launch = klt.bind(d_ref, d_cur_in, d_st_in, tree_out[0], tree_out[1], None)
+                for _ in range(max(3, min(args.warmup, 20))):
+                    tree_launch()
+                stream.synchronize()
+                t_tree = time.perf_counter()
+                for _ in range(args.steps):
+                    tree_launch()
+                stream.synchronize()
+                tree_elapsed = time.perf_counter() - t_tree
+                tree = {"elapsed": tree_elapsed, "uv": tree_out[0].cpu().numpy(), "st": tree_out[1].cpu().numpy()}
+            finally:
+                ctx.set_reduction("exact")
         upload = None
         if world == 1 and args.features == 0 and not args.no_upload_leg:
             upload = with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur_in, d_st_in, n, levels, stream, views2[1])
@@ -723,6 +743,16 @@ def main():
                                     "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "source": pmc.get("source")}
         else:
             out["roofline_valu"] = None  # no counters of THIS build: see roofline.traffic_refused
+        if tree is not None:
+            rep = parity_report(tree["uv"], tree["st"], cpu_uv, cpu_st)
+            out["throughput_mode"] = {
+                "value": n * args.steps / tree["elapsed"], "unit": "tracked features/s", "ms_per_step": tree["elapsed"] / args.steps * 1e3,
+                "speedup_over_exact": (elapsed / args.steps) / (tree["elapsed"] / args.steps),
+                "max_px": rep["max_px"], "p99_px": rep["p99_px"], "frac_gt_1e-3": rep["frac_gt_1e-3"], "status_mismatches": rep["status_mismatches"],
+                "bit_identical": rep["bit_identical"],
+                "what": "ftk_set_reduction_mode(FTK_REDUCTION_TREE): the same per-pixel products summed by per-lane partials + a butterfly instead of in the "
+                        "reference's pixel order; px-error against the CPU oracle on the timed inputs; reported, not the contract, never the default",
+            }
         if upload is not None:
             up_uv, up_st = upload.pop("result_uv").cpu().numpy(), upload.pop("result_st").cpu().numpy()
             upload["bit_identical_to_resident_path"] = bool(np.array_equal(up_uv.view(np.uint32), first_uv.view(np.uint32)) and np.array_equal(up_st, first_st))

@@ -168,6 +168,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     }
     ftk::KltParams &p = *out;
     memset(&p, 0, sizeof(p));
+    p.tree = (ctx && ctx->reduction == FTK_REDUCTION_TREE) ? 1 : 0;  // before the LDS size is computed: the throughput mode of the pipelined kernel keeps one table per wave
     p.n_levels = single_level ? 1 : ref->n_levels;
     p.single_level = single_level ? 1 : 0;
     for (int i = 0; i < p.n_levels; ++i) {
@@ -368,6 +369,9 @@ int ftk_context_create(int device, void *stream, ftk_context **out) {
         }
         ctx->owns_stream = true;
     }
+    if (const char *env = getenv("FTK_REDUCTION")) {  // experiment switch: contexts start in the throughput mode ("tree"); default exact
+        ctx->reduction = (strcmp(env, "tree") == 0) ? FTK_REDUCTION_TREE : FTK_REDUCTION_EXACT;
+    }
     *out = ctx;
     return FTK_OK;
 }
@@ -429,6 +433,18 @@ int ftk_synchronize(ftk_context *ctx) {
 }
 
 static int ensure_brief_pattern(ftk_context *ctx, int32_t n_bits, int32_t half);
+
+int ftk_set_reduction_mode(ftk_context *ctx, int mode) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "set_reduction_mode: null context");
+    }
+    FTK_LOCK(ctx);
+    if (mode != FTK_REDUCTION_EXACT && mode != FTK_REDUCTION_TREE) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "set_reduction_mode: unknown mode %d", mode);
+    }
+    ctx->reduction = mode;
+    return FTK_OK;
+}
 
 int ftk_warmup(ftk_context *ctx, unsigned what) {
     FTK_TRACE_SCOPE("ftk_warmup");
@@ -745,6 +761,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     if (rc != FTK_OK) {
         return rc;
     }
+    p.tree = ctx->reduction == FTK_REDUCTION_TREE ? 1 : 0;
     p.ref_uv = d_ref_uv;
     p.cur_uv_in = d_cur_uv_in;
     p.cur_uv_out = d_cur_uv_out;

@@ -68,6 +68,8 @@ struct KltParams {
     int32_t pb_rwin_rows, pb_rwin_cols;  // reference window incl. the rounding row / column: 2h+5 (cols padded to 4)
     uint32_t pb_magic_rwc, pb_magic_rwq;
     int32_t pb_cap_r, pb_cap_c;          // lattice node capacity per axis: len + 2 + provable maximum of extras
+    int32_t tree;                        // 0: sums in the reference's order (the contract); 1: throughput mode — the same per-pixel products, summed
+                                         // by per-lane partials + a cross-lane butterfly (ftk_set_reduction_mode; reported, never the default)
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
 };
 

@@ -55,6 +55,8 @@ struct ftk_context {
     // BRIEF sampling pattern resident on the device, cached per (n_bits, half)
     int8_t *brief_pattern = nullptr;
     int32_t brief_bits = 0, brief_half = 0;
+    // FTK_REDUCTION_EXACT (default) or FTK_REDUCTION_TREE: how the trackers' normal-equation sums are formed (ftk_set_reduction_mode)
+    int32_t reduction = 0;
 };
 
 struct ftk_pyramid {

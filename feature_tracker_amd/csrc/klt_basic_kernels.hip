@@ -68,11 +68,14 @@ struct PbLds {
     uint16_t *cur_win;
 };
 
+// Current-tap tables: one per producer wave; in the throughput mode (p.tree) every wave samples, so one per wave.
+__host__ __device__ inline int pb_tables(const KltParams &p, int waves) { return p.tree ? waves : pb_producers(waves); }
+
 __host__ __device__ inline size_t pb_lds_bytes(const KltParams &p, int waves) {
     const int np = pb_producers(waves);
     size_t bytes = 16 * (size_t)(p.pb_cap_r + p.pb_cap_c);
     bytes += 16 * (size_t)(p.patch_rows + p.patch_cols);
-    bytes += 16 * (size_t)np * 2 * (p.patch_rows + p.patch_cols);
+    bytes += 16 * (size_t)pb_tables(p, waves) * 2 * (p.patch_rows + p.patch_cols);
     bytes += 4 * (size_t)pb_ring_slots(waves) * np * kTerms * kRingRow;
     bytes += 4 * (size_t)pb_pad4(p.pb_cap_r * p.pb_cap_c);
     bytes += 4 * 4 + 4 * 16;
@@ -89,7 +92,7 @@ __device__ __forceinline__ PbLds pb_carve(float4 *base, const KltParams &p, int 
     c.ridx = reinterpret_cast<uint4 *>(c.cnodes + p.pb_cap_c);
     c.cidx = c.ridx + p.patch_rows;
     c.ctab = reinterpret_cast<float4 *>(c.cidx + p.patch_cols);
-    c.ring = reinterpret_cast<float *>(c.ctab + np * 2 * (p.patch_rows + p.patch_cols));
+    c.ring = reinterpret_cast<float *>(c.ctab + pb_tables(p, waves) * 2 * (p.patch_rows + p.patch_cols));
     c.lattice = c.ring + pb_ring_slots(waves) * np * kTerms * kRingRow;
     c.sol = c.lattice + pb_pad4(p.pb_cap_r * p.pb_cap_c);
     c.slots = reinterpret_cast<uint32_t *>(c.sol + 4);
@@ -269,8 +272,8 @@ __device__ __forceinline__ void cur_tables(int lane, const KltParams &p, const P
     }
 }
 
-// The per-pixel products of one 64-pixel chunk -> ring slot; returns the lane's validity.
-__device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltParams &p, const PbLds &c, const float4 *tab, const Win &cw, float *slot) {
+// The five per-pixel products of one 64-pixel chunk (basic_klt.cpp:135-144); returns the lane's validity.
+__device__ __forceinline__ bool chunk_products(int lane, int chunk, const KltParams &p, const PbLds &c, const float4 *tab, const Win &cw, float (&prod)[kTerms]) {
     const int pxi = chunk * kChunk + lane;
     const bool in = pxi < p.P;
     const int pp = in ? pxi : 0;
@@ -289,16 +292,38 @@ __device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltPara
     const float bottom = lat[rp + cc];
     const float i_ref = lat[rc + cc];
     const bool ok = in && ((__float_as_int(r0.w) & __float_as_int(c0.w)) != 0);
-    // basic_klt.cpp:135-144; an unused pixel contributes exact zeros (x + (+-0) == x)
+    // an unused pixel contributes exact zeros (x + (+-0) == x)
     const float fx = ok ? right - left : 0.0f;
     const float fy = ok ? bottom - top : 0.0f;
     const float ft = ok ? i_cur - i_ref : 0.0f;
-    slot[0 * kRingRow + lane] = fx * fx;
-    slot[1 * kRingRow + lane] = fy * fy;
-    slot[2 * kRingRow + lane] = fx * fy;
-    slot[3 * kRingRow + lane] = -(fx * ft);
-    slot[4 * kRingRow + lane] = -(fy * ft);
+    prod[0] = fx * fx;
+    prod[1] = fy * fy;
+    prod[2] = fx * fy;
+    prod[3] = -(fx * ft);
+    prod[4] = -(fy * ft);
     return ok;
+}
+
+// ... -> ring slot (the exact mode: the consumer wave adds them in pixel order).
+__device__ __forceinline__ bool produce_chunk(int lane, int chunk, const KltParams &p, const PbLds &c, const float4 *tab, const Win &cw, float *slot) {
+    float prod[kTerms];
+    const bool ok = chunk_products(lane, chunk, p, c, tab, cw, prod);
+#pragma unroll
+    for (int k = 0; k < kTerms; ++k) {
+        slot[k * kRingRow + lane] = prod[k];
+    }
+    return ok;
+}
+
+// Sum over the 64 lanes of a wave by a butterfly (the throughput mode's reduction: a fixed order, but not the reference's).
+__device__ __forceinline__ void wave_sum5(float (&v)[kTerms]) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < kTerms; ++k) {
+            v[k] += __shfl_xor(v[k], off, kWave);
+        }
+    }
 }
 
 // Exact ceil(2^20 / d) for 1 <= d <= 4096: q = (i * m) >> 20 equals i / d for i < 2^20 / d... (i * d < 2^20)
@@ -330,7 +355,11 @@ __device__ __forceinline__ void pb_sync(bool solo) {
 // HR / HC: the half patch sizes as compile-time constants (the common ones are instantiated below), or 0 / 0 for "as passed":
 // the whole patch / window / lattice geometry then folds into immediates (klt_fill_geometry) instead of being ~40 SGPR-resident
 // kernel arguments, most of which the register allocator spills to vector lanes (106 SGPRs + 104 spills in the generic form).
-template <bool SOLO, int HR, int HC>
+// TREE: the throughput mode (ftk_set_reduction_mode, KltParams::tree) — every wave samples and keeps per-lane partial sums of the
+// five products, a butterfly and a fixed-order sum over the waves replace the ring and the consumer's exact-order chain.  Same
+// products, different summation order: NOT bit-identical to the reference; a separate instantiation so that the contract path's
+// code is untouched by it.
+template <bool SOLO, int HR, int HC, bool TREE>
 __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument (p_arg.ref / p_arg.cur): a local copy whose
     // arrays are indexed with a run-time level would be placed in scratch memory (measured: the kernel twice as slow).
@@ -407,7 +436,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     const bool producer = (b.nwaves == 1) || b.wave > 0;
     const bool consumer = b.wave == 0;
     const int pw = (b.nwaves == 1) ? 0 : b.wave - 1;  // producer index
-    float4 *const my_tab = c.ctab + pw * 2 * (p.patch_rows + p.patch_cols);
+    float4 *const my_tab = c.ctab + (TREE ? b.wave : pw) * 2 * (p.patch_rows + p.patch_cols);
     const int n_chunks = (p.P + kChunk - 1) / kChunk;
     const int n_steps = (n_chunks + np - 1) / np;
     const int ring_mask = pb_ring_slots(b.nwaves) - 1;
@@ -577,53 +606,101 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 #endif
             uint32_t wave_valid = 0;
             float acc = 0.0f;
-            if (producer) {
+            if constexpr (TREE) {
+                // throughput mode: no ring, no chain — every wave samples chunks wave, wave + W, ... into five per-lane partial sums
+                float part[kTerms] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 cur_tables(b.lane, p, c, my_tab, cur, cw, cur_u, cur_v, n_c);
-                __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from reordering across
-            }
-            for (int s = 0; s < n_steps; ++s) {
-                if (producer) {
-                    const int chunk = s * np + pw;
-                    if (chunk < n_chunks) {
-                        const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & ring_mask) * np + pw) * kTerms * kRingRow);
-                        wave_valid += (uint32_t)__popcll(wave_ballot(ok));
+                __builtin_amdgcn_wave_barrier();
+                for (int chunk = b.wave; chunk < n_chunks; chunk += b.nwaves) {
+                    float prod[kTerms];
+                    const bool ok = chunk_products(b.lane, chunk, p, c, my_tab, cw, prod);
+#pragma unroll
+                    for (int k = 0; k < kTerms; ++k) {
+                        part[k] += prod[k];
                     }
-                    if (s == n_steps - 1 && b.lane == 0) {
-                        c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;
+                    wave_valid += (uint32_t)__popcll(wave_ballot(ok));
+                }
+                wave_sum5(part);
+                float *const wave_sums = c.ring;  // unused in this mode: [wave][kTerms]
+                if (b.lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < kTerms; ++k) {
+                        wave_sums[b.wave * kTerms + k] = part[k];
+                    }
+                    c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;
+                }
+                pb_sync(solo);
+                if (consumer) {
+                    float tot[kTerms];
+#pragma unroll
+                    for (int k = 0; k < kTerms; ++k) {
+                        tot[k] = wave_sums[k];
+                        for (int w = 1; w < b.nwaves; ++w) {
+                            tot[k] += wave_sums[w * kTerms + k];
+                        }
+                    }
+                    float m[2][2], bb[2], sol[2];
+                    m[0][0] = tot[0];
+                    m[1][1] = tot[1];
+                    m[0][1] = m[1][0] = tot[2];
+                    bb[0] = tot[3];
+                    bb[1] = tot[4];
+                    ldlt_solve<2>(m, bb, sol);
+                    if (b.lane == 0) {
+                        c.sol[0] = sol[0];
+                        c.sol[1] = sol[1];
                     }
                 }
                 pb_sync(solo);
-                if (consumer && b.lane < kTerms) {
-                    for (int q = 0; q < np; ++q) {
-                        if (s * np + q < n_chunks) {
-                            acc = chain_chunk(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + b.lane) * kRingRow);
+            } else {
+                if (producer) {
+                    cur_tables(b.lane, p, c, my_tab, cur, cw, cur_u, cur_v, n_c);
+                    __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered; keep the compiler from reordering across
+                }
+                for (int s = 0; s < n_steps; ++s) {
+                    if (producer) {
+                        const int chunk = s * np + pw;
+                        if (chunk < n_chunks) {
+                            const bool ok = produce_chunk(b.lane, chunk, p, c, my_tab, cw, c.ring + ((s & ring_mask) * np + pw) * kTerms * kRingRow);
+                            wave_valid += (uint32_t)__popcll(wave_ballot(ok));
+                        }
+                        if (s == n_steps - 1 && b.lane == 0) {
+                            c.slots[4 + 4 * (iter & 1u) + b.wave] = wave_valid;
+                        }
+                    }
+                    pb_sync(solo);
+                    if (consumer && b.lane < kTerms) {
+                        for (int q = 0; q < np; ++q) {
+                            if (s * np + q < n_chunks) {
+                                acc = chain_chunk(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + b.lane) * kRingRow);
+                            }
                         }
                     }
                 }
-            }
-#ifndef FTK_STAMPS_FINE
-            FTK_STAMP_END(b, 3);
-#endif
-            if (consumer) {
-                float m[2][2], bb[2], sol[2];
-                const int acc_bits = __float_as_int(acc);
-                m[0][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0));
-                m[1][1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
-                m[0][1] = m[1][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2));
-                bb[0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
-                bb[1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4));
-                ldlt_solve<2>(m, bb, sol);  // basic_klt.cpp:97
-                if (b.lane == 0) {
-                    c.sol[0] = sol[0];
-                    c.sol[1] = sol[1];
+    #ifndef FTK_STAMPS_FINE
+                FTK_STAMP_END(b, 3);
+    #endif
+                if (consumer) {
+                    float m[2][2], bb[2], sol[2];
+                    const int acc_bits = __float_as_int(acc);
+                    m[0][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0));
+                    m[1][1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
+                    m[0][1] = m[1][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2));
+                    bb[0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
+                    bb[1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4));
+                    ldlt_solve<2>(m, bb, sol);  // basic_klt.cpp:97
+                    if (b.lane == 0) {
+                        c.sol[0] = sol[0];
+                        c.sol[1] = sol[1];
+                    }
                 }
+                pb_sync(solo);  // B3: solution and valid counts visible
+    #ifndef FTK_STAMPS_FINE
+                FTK_STAMP_END(b, 5);
+    #endif
             }
-            pb_sync(solo);  // B3: solution and valid counts visible
-#ifndef FTK_STAMPS_FINE
-            FTK_STAMP_END(b, 5);
-#endif
             uint32_t n_valid = 0;
-            for (int w = (b.nwaves == 1 ? 0 : 1); w < b.nwaves; ++w) {
+            for (int w = ((b.nwaves == 1 || TREE) ? 0 : 1); w < b.nwaves; ++w) {
                 n_valid += c.slots[4 + 4 * (iter & 1u) + w];
             }
             if (n_valid == 0) {
@@ -695,6 +772,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 
 }  // namespace
 
+namespace {
+template <int HR, int HC>
+void (*pick_kernel(bool solo, bool tree))(const KltParams) {
+    if (tree) {
+        return solo ? klt_basic_inverse_pipelined_kernel<true, HR, HC, true> : klt_basic_inverse_pipelined_kernel<false, HR, HC, true>;
+    }
+    return solo ? klt_basic_inverse_pipelined_kernel<true, HR, HC, false> : klt_basic_inverse_pipelined_kernel<false, HR, HC, false>;
+}
+}  // namespace
+
 size_t klt_basic_pipelined_lds_bytes(const KltParams &p) {
     const size_t one = pb_lds_bytes(p, p.waves_per_feature);
     return p.features_per_group > 1 ? one * (size_t)p.features_per_group : one;
@@ -719,8 +806,9 @@ hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream)
     if (solo && p.features_per_group < 1) {
         p.features_per_group = 1;
     }
-    // compile-time geometry for the patch sizes of the BASELINE configurations and the reference's default (11x11, 13x13, 21x21)
-    void (*kernel)(const KltParams) = solo ? klt_basic_inverse_pipelined_kernel<true, 0, 0> : klt_basic_inverse_pipelined_kernel<false, 0, 0>;
+    // compile-time geometry for the patch sizes of the BASELINE configurations and the reference's default (11x11, 13x13, 21x21);
+    // the throughput mode (p.tree: reported, never the contract) has its own instantiations of the same set
+    void (*kernel)(const KltParams) = pick_kernel<0, 0>(solo, p.tree != 0);
     static const bool specialise = !(getenv("FTK_PB_SPECIALISE") && atoi(getenv("FTK_PB_SPECIALISE")) == 0);  // experiment switch
     if (specialise && p.half_rows == p.half_cols) {
         KltParams check = p;
@@ -728,9 +816,9 @@ hipError_t klt_basic_pipelined_launch(const KltParams &p_in, hipStream_t stream)
         const bool same = check.pb_cap_r == p.pb_cap_r && check.pb_cap_c == p.pb_cap_c && check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols;
         if (same) {
             switch (p.half_rows) {
-                case 5: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 5, 5> : klt_basic_inverse_pipelined_kernel<false, 5, 5>; break;
-                case 6: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 6, 6> : klt_basic_inverse_pipelined_kernel<false, 6, 6>; break;
-                case 10: kernel = solo ? klt_basic_inverse_pipelined_kernel<true, 10, 10> : klt_basic_inverse_pipelined_kernel<false, 10, 10>; break;
+                case 5: kernel = pick_kernel<5, 5>(solo, p.tree != 0); break;
+                case 6: kernel = pick_kernel<6, 6>(solo, p.tree != 0); break;
+                case 10: kernel = pick_kernel<10, 10>(solo, p.tree != 0); break;
                 default: break;
             }
         }

@@ -56,6 +56,7 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 struct Blk {
     int tid, nt, lane, wave, nwaves;
     bool solo = false;  // compile-time true in the one-wave instantiations: no workgroup barrier anywhere, cross-wave exchanges fold away
+    bool tree = false;  // throughput mode (KltParams::tree): sums by per-lane partials + a butterfly instead of the exact-order chain
 #ifdef FTK_STAMPS
     mutable unsigned long long stamp_t0 = 0;
     mutable unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -777,6 +778,36 @@ __device__ __forceinline__ float chain_lane(const float *row, int Ppad, float ac
     acc = chain_consume(acc, qa, rem);
     acc = chain_consume(acc, qb, rem - kChainRound);
     return acc;
+}
+
+// Throughput mode (ftk_set_reduction_mode): the sums of K term rows by ALL 64 lanes of one wave — lane l adds the terms
+// l, l + 64, ... of a row, a butterfly adds the lanes; four rows at a time so that the shuffles of one cover the latency of the
+// others.  A fixed order, not the reference's: the results are NOT bit-identical to the CPU path (reported, never asserted).
+__device__ __forceinline__ void tree_sums(const float *terms, int K, int Ppad, float *sums, int lane) {
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = lane; i < Ppad; i += kWave) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] += (k0 + j < K) ? terms[(k0 + j) * Ppad + i] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[j] += __shfl_xor(part[j], off, kWave);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k0 + j < K) {
+                    sums[k0 + j] = part[j];
+                }
+            }
+        }
+    }
 }
 
 // The same chain over a GROUPED layout: the terms of four consecutive pixels of one sum sit in one float4 and consecutive

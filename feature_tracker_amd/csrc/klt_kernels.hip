@@ -150,8 +150,12 @@ __device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int
     if (leading_barrier) {
         blk_sync(b);  // phase A's terms (and published counts) become visible
     }
-    if (b.wave == 0 && b.lane < K) {
-        sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
+    if (b.wave == 0) {
+        if (b.tree) {
+            tree_sums(terms, K, Ppad, sums, b.lane);  // throughput mode: not the reference's order
+        } else if (b.lane < K) {
+            sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
+        }
     }
     blk_sync(b);
 }
@@ -166,7 +170,10 @@ __device__ __forceinline__ void chain_then(const Blk &b, const float *terms, int
         blk_sync(b);  // phase A's terms (and published counts) become visible
     }
     if (b.wave == 0) {
-        if (b.lane < K) {
+        if (b.tree) {
+            tree_sums(terms, K, Ppad, sums, b.lane);  // throughput mode: not the reference's order
+            __builtin_amdgcn_wave_barrier();
+        } else if (b.lane < K) {
             sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
         }
         wave0_work();
@@ -1588,6 +1595,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     extern __shared__ float4 lds_raw[];
     Blk b;
     b.solo = SOLO;
+    b.tree = p.tree != 0;
     b.tid = SOLO ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
     b.nt = SOLO ? kWave : (int)blockDim.x;
     b.lane = b.tid & (kWave - 1);

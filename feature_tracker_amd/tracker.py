@@ -47,6 +47,11 @@ class Context:
         (mask of FTK_WARM_*: 1 KLT, 2 Hamming, 4 cosine, 8 direct method, 16 BRIEF / Harris)."""
         N.check(N.lib().ftk_warmup(self._h, int(what)), self._h)
 
+    def set_reduction(self, mode: str = "exact"):
+        """ftk_set_reduction_mode: "exact" (default, the contract: sums in the reference's order, bit-identical results) or "tree"
+        (throughput mode: same products, butterfly sums; reported next to the exact mode, never asserted)."""
+        N.check(N.lib().ftk_set_reduction_mode(self._h, {"exact": 0, "tree": 1}[mode]), self._h)
+
     def close(self):
         if self._h:
             N.lib().ftk_context_destroy(self._h)

@@ -106,6 +106,22 @@ enum { FTK_WARM_KLT = 1, FTK_WARM_HAMMING = 2, FTK_WARM_COSINE = 4, FTK_WARM_DIR
 int ftk_warmup(ftk_context *ctx, unsigned what);
 void ftk_default_klt_options(ftk_klt_options *opt);
 
+/*
+ * How the trackers sum their normal equations.
+ *   FTK_REDUCTION_EXACT (default, the contract): every sum in the reference's row-major pixel order, one dependent add per
+ *     term (basic_klt.cpp:139-144, affine_klt.cpp:229-256, lssd_klt.cpp:214-215) — results bit-identical to the CPU path.
+ *   FTK_REDUCTION_TREE (throughput mode; measured and reported, never asserted, never the default): the SAME per-pixel products,
+ *     summed as per-lane partials combined by a cross-lane butterfly.  The sums then differ from the reference's in the last
+ *     bits, and because the convergence test |v|^2 < kMaxConvergeStep turns such differences into an extra or a missing
+ *     iteration, a small fraction of the features moves by more than the 1e-3 px the contract allows (bench.py reports max /
+ *     p99 / fraction > 1e-3 px and status mismatches next to the speed).  It exists to show what bit-exactness costs.
+ *     Implemented for the Basic-KLT inverse kernel and for the variants whose sums go through the generic chain (Basic direct /
+ *     fast, affine fast, LSSD inverse / direct and LSSD fast with several waves or luminance scaling); the other variants and
+ *     the direct method ignore the setting and stay exact.
+ */
+enum { FTK_REDUCTION_EXACT = 0, FTK_REDUCTION_TREE = 1 };
+int ftk_set_reduction_mode(ftk_context *ctx, int mode);
+
 /* ---- image pyramids resident in HBM ------------------------------------------------------ */
 
 /* A level may have up to 2^24 - 1 rows / columns and fewer than 2^32 pixels (the trackers address pixels with 32-bit

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmcw_$W
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-upload-leg $*"
+BENCH="python3 $ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline --no-upload-leg --no-tree-leg $*"
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   name=$(echo "$grp" | tr ' ' '_' | cut -c1-30)

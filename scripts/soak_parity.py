@@ -4,6 +4,9 @@ time budget — every tracker variant, both descriptor matchers, the direct meth
 
     python scripts/soak_parity.py [seconds] [seed] [family]   prints one summary line per family, exits 1 on any mismatch
                                                               family: all (default) | matcher (both matchers only, larger sets)
+                                                              | tree (REPORTING mode: the trackers in the throughput mode,
+                                                                ftk_set_reduction_mode(TREE) — per-variant px-error statistics
+                                                                against the oracle, nothing asserted, exit code 0)
 
 Random axes: image size (odd sizes included), motion (translation / rotation / scale, up to ~15 px), pyramid depth,
 patch size (rectangular too), feature count, border features, predictions, incoming status, kMaxTrackPointsNumber,
@@ -26,6 +29,9 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 ONLY = sys.argv[3] if len(sys.argv) > 3 else "all"
 CLASSES = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}
 stats = {}
+tree_stats = {}
+if ONLY == "tree":
+    F.default_context().set_reduction("tree")  # the trackers of this process share the default context
 
 
 def note(family, ok, detail=""):
@@ -80,6 +86,19 @@ def klt_round():
             ok, c, s = klt.TrackFeatures(rp, cp, uv, pred, status)
             ok2, oc, os_, oit = O.klt_track_pyramid(model, rl, cl, uv, pred, status, prior=prior, consider_luminance=lum, method=method, half=half,
                                                     half_cols=half_c, max_points=max_points)
+            if ONLY == "tree":
+                fin = np.isfinite(oc).all(axis=1) & np.isfinite(c).all(axis=1)
+                d = np.linalg.norm(c[fin].astype(np.float64) - oc[fin].astype(np.float64), axis=1)
+                t = tree_stats.setdefault(f"klt/{model}/{method}", {"n": 0, "gt": 0, "max": 0.0, "status": 0, "nonfinite": 0, "identical": 0, "d": []})
+                t["n"] += int(fin.sum())
+                t["gt"] += int((d > 1e-3).sum())
+                t["max"] = max(t["max"], float(d.max()) if d.size else 0.0)
+                t["status"] += int((s != os_).sum())
+                t["nonfinite"] += int((~fin).sum() - (~np.isfinite(oc).all(axis=1)).sum())
+                t["identical"] += int((c.view(np.uint32) == oc.view(np.uint32)).all(axis=1).sum())
+                if len(t["d"]) < 400000:
+                    t["d"].extend(d.tolist())
+                continue
             same = ok == ok2 and np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and np.array_equal(klt.last_iterations, oit)
             note(f"klt/{model}/{method}", same, f"{w}x{h} L{levels} h{half}/{half_c} n{n} cap{max_points}")
 
@@ -166,6 +185,8 @@ t_report = time.time() + 60.0
 while time.time() < t_end:
     if ONLY == "matcher":
         matcher_round()
+    elif ONLY == "tree":
+        klt_round()
     else:
         klt_round()
         matcher_round()
@@ -174,6 +195,15 @@ while time.time() < t_end:
     if time.time() > t_report:  # a line a minute: the GPU box takes a silent command for a hung one
         print(f"soak: {rounds} rounds, {sum(v[0] for v in stats.values())} comparisons, {sum(v[1] for v in stats.values())} mismatches so far", flush=True)
         t_report = time.time() + 60.0
+if ONLY == "tree":
+    print("throughput mode (ftk_set_reduction_mode(TREE)) against the oracle: REPORT, nothing asserted")
+    print(f"{'variant':22s} {'features':>9s} {'identical':>10s} {'max px':>10s} {'p99 px':>10s} {'frac>1e-3':>10s} {'status !=':>10s}")
+    for fam in sorted(tree_stats):
+        t = tree_stats[fam]
+        d = np.array(t["d"]) if t["d"] else np.zeros(1)
+        print(f"{fam:22s} {t['n']:9d} {t['identical'] / max(t['n'], 1):10.4f} {t['max']:10.3g} {np.percentile(d, 99):10.3g} {t['gt'] / max(t['n'], 1):10.2e} {t['status']:10d}")
+    print(f"soak (tree, reporting): {rounds} rounds in {budget:.0f} s")
+    sys.exit(0)
 bad = 0
 for fam in sorted(stats):
     n, f, d = stats[fam]
