@@ -220,7 +220,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.features_per_group = 1;
     const bool pipelined_candidate = model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.patch_rows <= 64 && p.patch_cols <= 64;
     if (p.waves_per_feature == 1 && pipelined_candidate) {
-        int group = 1;  // measured (config 5): 2 / 4 per workgroup buy nothing — the SIMDs are already saturated at 4 waves
+        // measured (config 5 shard, 25 000 features): 1 / 2 / 3 / 4 per workgroup = 191 / 175 / 180 / 172 us.  (Round 2 measured no gain:
+        // that was before the compile-time geometry removed the SGPR spill traffic — the one-wave kernel is bound by how many
+        // features are in flight, not by vector issue: the throughput mode, which drops 20 % of its VALU work, runs no faster.)
+        int group = 4;
         if (const char *env = getenv("FTK_KLT_GROUP")) {
             group = atoi(env);  // experiment override
         }
@@ -258,7 +261,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     if (!p.pb_enabled) {
         p.features_per_group = 1;  // the generic kernel's workgroup is one feature ...
         if (p.waves_per_feature == 1) {
-            int group = 1;  // ... or, one-wave variants, a few features that never meet (measured on config 4: 2-4 buy nothing)
+            int group = 2;  // ... or, one-wave variants, a few features that never meet (config 4, 10 000 features: 153 / 140.5 / 141 us at 1 / 2 / 4)
             if (const char *env = getenv("FTK_KLT_GROUP")) {
                 group = atoi(env);  // experiment override
             }
