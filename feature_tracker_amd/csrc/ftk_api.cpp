@@ -497,6 +497,71 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
     if (what & FTK_WARM_FEATURES) {
         FTK_HIP(ctx, ftk::feature_warm(ctx->stream));
     }
+    // ... and one REAL launch of every kernel a default-configured object of the family would launch first: besides its code
+    // object a kernel's very first launch costs 0.2 - 1 ms of its own (measured: the first TrackFeatures of a process 0.41 / 1.33 ms
+    // on two boxes against 0.17 ms for the second tracker).  A 64 x 64 all-zero image, one feature / descriptor / point; results
+    // are discarded, failures ignored (warm-up is best effort and must not leave an error behind).
+    {
+        const std::string saved_error = ctx->error;
+        uint8_t *dummy = nullptr;
+        constexpr size_t kImg = 64 * 64, kOff = 8192;  // image | feature block | descriptors
+        if (hipMalloc(reinterpret_cast<void **>(&dummy), kOff + 8192) == hipSuccess &&
+            hipMemsetAsync(dummy, 0, kOff + 8192, ctx->stream) == hipSuccess) {
+            static_assert(kImg <= kOff, "dummy image fits in front of the feature block");
+            ftk_image level = {dummy, 64, 64};
+            ftk_pyramid *pyr = nullptr;
+            float *d_uv = reinterpret_cast<float *>(dummy + kOff);          // ref (u, v) = (0, 0): never dereferenced out of range
+            float *d_cur = d_uv + 2, *d_out = d_uv + 4;
+            uint8_t *d_st = dummy + kOff + 64, *d_sto = dummy + kOff + 128;
+            uint32_t *d_desc_ref = reinterpret_cast<uint32_t *>(dummy + kOff + 256), *d_desc_cur = d_desc_ref + 16;
+            int32_t *d_idx = reinterpret_cast<int32_t *>(dummy + kOff + 512);
+            float *d_fref = reinterpret_cast<float *>(dummy + kOff + 1024), *d_fcur = d_fref + 256;
+            if (ftk_pyramid_wrap_device(ctx, &level, 1, &pyr) == FTK_OK) {
+                if (what & FTK_WARM_KLT) {
+                    ftk_klt_options opt;
+                    ftk_default_klt_options(&opt);
+                    for (int model = FTK_MODEL_BASIC; model <= FTK_MODEL_LSSD; ++model) {
+                        for (int method = FTK_METHOD_INVERSE; method <= FTK_METHOD_FAST; ++method) {
+                            opt.method = method;
+                            (void)ftk_klt_track_device(ctx, model, &opt, pyr, pyr, d_uv, d_cur, d_out, d_st, d_sto, 1, nullptr, 0, 0, nullptr);
+                        }
+                    }
+                }
+                if (what & (FTK_WARM_HAMMING | FTK_WARM_FEATURES)) {
+                    (void)ftk_brief_compute_device(ctx, pyr, 0, d_uv, 1, 256, 8, d_desc_ref);
+                }
+                if (what & FTK_WARM_FEATURES) {
+                    float corner[2];
+                    int32_t found = 0;
+                    (void)ftk_harris_detect(ctx, pyr, 0, 1, 25, 40.0f, corner, &found);
+                }
+                if (what & FTK_WARM_DIRECT) {
+                    ftk_direct_options dopt;
+                    ftk_default_direct_options(&dopt);
+                    const float K[4] = {64.0f, 64.0f, 32.0f, 32.0f}, point[3] = {0.0f, 0.0f, 1.0f}, ruv[2] = {32.0f, 32.0f};
+                    float cuv[2] = {32.0f, 32.0f}, q[4] = {1.0f, 0.0f, 0.0f, 0.0f}, t[3] = {0.0f, 0.0f, 0.0f};
+                    uint8_t st = 0;
+                    (void)ftk_direct_track(ctx, &dopt, pyr, pyr, K, point, ruv, cuv, 1, q, t, &st, 0, nullptr);
+                }
+                ftk_pyramid_destroy(pyr);
+            }
+            if (what & FTK_WARM_HAMMING) {
+                (void)ftk_hamming_match_device(ctx, d_desc_ref, 1, d_desc_cur, 1, 8, 256, 60.0f, nullptr, nullptr, 40, 40, d_idx, nullptr);
+                (void)ftk_hamming_match_device(ctx, d_desc_ref, 1, d_desc_cur, 1, 8, 256, 60.0f, d_uv, d_cur, 40, 40, d_idx, nullptr);
+            }
+            if (what & FTK_WARM_COSINE) {
+                for (int dim : {256, 128}) {
+                    (void)ftk_cosine_match_device(ctx, d_fref, 1, d_fcur, 1, dim, 0.5f, nullptr, nullptr, 40, 40, d_idx);
+                    (void)ftk_cosine_match_device(ctx, d_fref, 1, d_fcur, 1, dim, 0.5f, d_uv, d_cur, 40, 40, d_idx);
+                }
+            }
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        if (dummy) {
+            (void)hipFree(dummy);
+        }
+        ctx->error = saved_error;
+    }
     if (ctx->pinned && ctx->scratch) {
         // first copies in both directions between the staging blocks (the copy path's first use is not free either)
         // (an image-sized one: copies beyond a few KB take another path in the runtime than small ones, and the first 361 KB

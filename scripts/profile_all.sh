@@ -23,7 +23,7 @@ for W in $WORKLOADS; do
   if [ "$W" = hamming ]; then
     CMD="python3 $ROOT/scripts/bench_configs.py --only match --quick"
   else
-    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline"
+    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline --no-upload-leg --no-tree-leg"
   fi
   echo "== $W: trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $CMD > "$D/trace_stdout.log" 2>&1 || echo "trace failed: $W" >> "$OUT/errors.log"
