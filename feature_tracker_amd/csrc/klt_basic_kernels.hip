@@ -407,6 +407,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     if (id >= (uint32_t)p.n) {
         return;
     }
+    const bool younger = 2u * id >= (uint32_t)p.n;  // launch slot in the later-dispatched half (set_level_priority)
     if (p.order) {
         id = (uint32_t)p.order[id];  // launch slot -> feature: longest first by the previous call's iteration counts
     }
@@ -470,7 +471,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     for (int level = p.n_levels - 1; level > -1; --level) {
         const DevImage ref = p_arg.ref[level];
         const DevImage cur = p_arg.cur[level];
-        set_level_priority(level);
+        set_level_priority(level, younger);
 #ifdef FTK_PB_CHAIN_PRIO
         if (b.nwaves > 1) {
             // the exact-order chain is the feature's critical path: its wave outranks the producers sharing the SIMD

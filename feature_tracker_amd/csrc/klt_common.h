@@ -91,16 +91,23 @@ __device__ __forceinline__ Blk opaque_blk(const Blk &b) {
 // alone at single-wave issue rate.  Waves therefore raise their own priority while they are
 // behind (coarse pyramid level) and lower it as they advance: the co-resident features progress
 // evenly and the last one finishes ~10 % earlier (measured: 53.9 -> 49.3 us span at 2000 features).
-__device__ __forceinline__ void set_level_priority(int level) {
+// `younger`: the workgroup sits in the later-dispatched half of the launch.  With 2 000 identical features the finishing time
+// still correlates 0.87 with the launch slot (31 us for the first 250 workgroups, 36 for the last 250, all started within
+// 0.4 us: scripts/stamps_placement.py), so the younger half runs one step above the older half of the same level:
+// config 2 40.4 -> 39.0 us per step, 300 / 1 000-feature launches -3.5 %, config 5 shard -1.7 %, config 1 +-0.  (Rotating or
+// purely age-based priorities, and a finer split, all lose: docs/LAB_NOTES.md.)
+__device__ __forceinline__ void set_level_priority(int level, bool younger = false) {
 #ifdef FTK_NO_LEVEL_PRIO
     (void)level;
+    (void)younger;
     return;
 #endif
-    if (level >= 3) {
+    const int pr = (level >= 3 ? 3 : level) + (younger ? 1 : 0);
+    if (pr >= 3) {
         __builtin_amdgcn_s_setprio(3);
-    } else if (level == 2) {
+    } else if (pr == 2) {
         __builtin_amdgcn_s_setprio(2);
-    } else if (level == 1) {
+    } else if (pr == 1) {
         __builtin_amdgcn_s_setprio(1);
     } else {
         __builtin_amdgcn_s_setprio(0);

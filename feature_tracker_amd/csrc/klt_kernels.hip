@@ -1690,6 +1690,8 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         const Blk b = opaque_blk(b0);  // per-thread index math stays inside the level (see opaque())
         // the features the launch order put first are the ones expected to run longest — the launch ends when they do — so
         // they keep the top issue priority on their SIMDs at every level
+        // (the later-dispatched-half boost of the pipelined kernel was measured here too: Basic direct / fast -2...-4 %, the affine and
+        // LSSD variants +1 % — their launches end with their longest feature, not with their youngest; not taken)
         set_level_priority((p.order && slot_id < (uint32_t)kLongFeatureSlots) ? 3 : level);
         if (MODEL == FTK_MODEL_BASIC) {
             if (METHOD == FTK_METHOD_FAST) {
