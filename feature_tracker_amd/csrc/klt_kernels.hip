@@ -1779,9 +1779,10 @@ template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
     void (*kernel)(const KltParams) = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0> : klt_track_kernel<MODEL, METHOD, false, 0>;
     static const bool specialise = !(getenv("FTK_KLT_SPECIALISE") && atoi(getenv("FTK_KLT_SPECIALISE")) == 0);  // experiment switch
-    // (measured per variant, 13 x 13: Basic -6...-14 %, LSSD -16...-21 %, affine fast -16 %; the non-fast affine variants — 24 sums per
-    // pixel, at the register cap already — get 9...18 % SLOWER with the geometry folded in and keep the run-time form)
-    constexpr bool gains = !(MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST);
+    // (measured per variant, 13 x 13: Basic -6...-14 %, LSSD -16...-21 %, affine fast -16 %, affine inverse / direct -8...-9 % — the
+    // latter only once chain_groups' loop is kept rolled: with a compile-time round count the compiler unrolled it fully and the
+    // kernel went from 81 to 128 VGPRs and 9...18 % SLOWER)
+    constexpr bool gains = true;
     if constexpr (gains) {
         if (specialise && p.half_rows == 6 && p.half_cols == 6) {
             KltParams check = p;
