@@ -8,6 +8,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stddef.h>
 
 #include <type_traits>
 
@@ -84,6 +85,19 @@ __device__ __forceinline__ Blk opaque_blk(const Blk &b) {
     o.tid = opaque(b.tid);
     o.lane = opaque(b.lane);
     return o;
+}
+
+// A kernel argument read where it is USED instead of at kernel entry.  The compiler loads every field of the by-value argument
+// block up front and keeps it in SGPRs for the whole kernel; the pointers that are only needed when a feature retires (outputs,
+// iteration counts) then occupy ten SGPRs through every loop of a kernel that spills scalar registers to vector lanes.  The
+// argument block is the kernel's only parameter, so a field sits at its offsetof() behind the kernarg segment pointer; the asm
+// barrier keeps the load from being hoisted.
+#define FTK_LATE_ARG(field) ftk_late_arg<decltype(KltParams::field)>(offsetof(KltParams, field))
+template <typename T>
+__device__ __forceinline__ T ftk_late_arg(size_t offset) {
+    const char __attribute__((address_space(4))) *base = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<const T __attribute__((address_space(4))) *>(base + offset);
 }
 
 // All features of a call are resident at once and the hardware arbitrates oldest-wave-first, which
