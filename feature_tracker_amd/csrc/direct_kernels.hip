@@ -109,6 +109,10 @@ __device__ __forceinline__ float dm_chain_chunk(float acc, const float *row) {
     return acc;
 }
 
+// TREE: the throughput mode (ftk_set_reduction_mode) — all eight waves sample, every lane keeps 27 partial sums, a butterfly and a
+// fixed-order sum over the waves replace the ring and wave 0's exact-order chains (50 700 dependent adds per iteration at the
+// reference's 300 points x 13 x 13).  Same products, another summation order: NOT bit-identical to the scalar loop; reported only.
+template <bool TREE>
 __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const DirectParams pp) {
     extern __shared__ float4 dm_lds[];
     const DirectProblem pr = pp.problems[blockIdx.x];
@@ -164,53 +168,106 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                 }
                 __syncthreads();
 
+                // the 1 x 6 Jacobian row and the residual of term `lane` of a 64-term chunk of the (feature, pixel) stream (:144-168)
+                auto chunk_terms = [&](int chunk, float (&jac)[6], float &residual) {
+                    const long long g = (long long)chunk * kDmChunk + lane;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        jac[r] = 0.0f;
+                    }
+                    residual = 0.0f;
+                    if (chunk < n_chunks && g < total_terms) {
+                        const int i = (int)(g / P);
+                        const int pix = (int)(g - (long long)i * P);
+                        const int prow = pix / pp.patch_cols, pcol = pix - prow * pp.patch_cols;
+                        const float4 f = feat[i];
+                        if (f.z != 0.0f) {
+                            const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
+                            const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
+                            const float row_i = drow + scaled_rv, col_i = dcol + scaled_ru;
+                            const float row_j = drow + f.y, col_j = dcol + f.x;
+                            float t0, t1, t2, t3, t4, t5;
+                            // all six must be valid (:160-162); evaluation order does not matter for the result
+                            bool ok = tap_global(cur, row_j, col_j - 1.0f, t0);
+                            ok = tap_global(cur, row_j, col_j + 1.0f, t1) && ok;
+                            ok = tap_global(cur, row_j - 1.0f, col_j, t2) && ok;
+                            ok = tap_global(cur, row_j + 1.0f, col_j, t3) && ok;
+                            ok = tap_global(ref, row_i, col_i, t4) && ok;
+                            ok = tap_global(cur, row_j, col_j, t5) && ok;
+                            if (ok) {
+                                const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+                                const float zi = 1.0f / prz;
+                                const float z2i = zi * zi;
+                                // jacobian_pixel_xi, :145-148 — operator precedence as written
+                                const float j00 = fx * zi, j01 = 0.0f, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i,
+                                            j05 = -fx * pry * zi;
+                                const float j10 = 0.0f, j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i,
+                                            j15 = fy * prx * zi;
+                                const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
+                                residual = t5 - t4;
+                                jac[0] = gx * j00 + gy * j10;
+                                jac[1] = gx * j01 + gy * j11;
+                                jac[2] = gx * j02 + gy * j12;
+                                jac[3] = gx * j03 + gy * j13;
+                                jac[4] = gx * j04 + gy * j14;
+                                jac[5] = gx * j05 + gy * j15;
+                            }
+                        }
+                    }
+                };
                 // ---- the (feature, pixel) stream in rounds of kDmProducers chunks ----
                 float acc = 0.0f;
+                if constexpr (TREE) {
+                    float part[kDmTerms];
+#pragma unroll
+                    for (int k = 0; k < kDmTerms; ++k) {
+                        part[k] = 0.0f;
+                    }
+                    for (int chunk = wave; chunk < n_chunks; chunk += kDmWaves) {
+                        float jac[6], residual;
+                        chunk_terms(chunk, jac, residual);
+                        int k = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                            for (int c = r; c < 6; ++c) {
+                                part[k] += jac[r] * jac[c];
+                                ++k;
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            part[21 + r] += residual * jac[r];
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                        for (int k = 0; k < kDmTerms; ++k) {
+                            part[k] += __shfl_xor(part[k], off, kWave);
+                        }
+                    }
+                    float *const wave_sums = ring;  // unused in this mode: [wave][kDmTerms]
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < kDmTerms; ++k) {
+                            wave_sums[wave * kDmTerms + k] = part[k];
+                        }
+                    }
+                    __syncthreads();
+                    if (consumer && lane < kDmTerms) {
+                        acc = wave_sums[lane];
+                        for (int w = 1; w < kDmWaves; ++w) {
+                            acc += wave_sums[w * kDmTerms + lane];
+                        }
+                    }
+                } else {
                 for (int round = 0; round < n_rounds; ++round) {
                     if (!consumer) {
                         const int chunk = round * kDmProducers + (wave - 1);
                         float *slot = ring + (((round & 1) * kDmProducers + (wave - 1)) * kDmTerms) * kDmRow;
-                        const long long g = (long long)chunk * kDmChunk + lane;
-                        float jac[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        float residual = 0.0f;
-                        if (chunk < n_chunks && g < total_terms) {
-                            const int i = (int)(g / P);
-                            const int pix = (int)(g - (long long)i * P);
-                            const int prow = pix / pp.patch_cols, pcol = pix - prow * pp.patch_cols;
-                            const float4 f = feat[i];
-                            if (f.z != 0.0f) {
-                                const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
-                                const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
-                                const float row_i = drow + scaled_rv, col_i = dcol + scaled_ru;
-                                const float row_j = drow + f.y, col_j = dcol + f.x;
-                                float t0, t1, t2, t3, t4, t5;
-                                // all six must be valid (:160-162); evaluation order does not matter for the result
-                                bool ok = tap_global(cur, row_j, col_j - 1.0f, t0);
-                                ok = tap_global(cur, row_j, col_j + 1.0f, t1) && ok;
-                                ok = tap_global(cur, row_j - 1.0f, col_j, t2) && ok;
-                                ok = tap_global(cur, row_j + 1.0f, col_j, t3) && ok;
-                                ok = tap_global(ref, row_i, col_i, t4) && ok;
-                                ok = tap_global(cur, row_j, col_j, t5) && ok;
-                                if (ok) {
-                                    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
-                                    const float zi = 1.0f / prz;
-                                    const float z2i = zi * zi;
-                                    // jacobian_pixel_xi, :145-148 — operator precedence as written
-                                    const float j00 = fx * zi, j01 = 0.0f, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i,
-                                                j05 = -fx * pry * zi;
-                                    const float j10 = 0.0f, j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i,
-                                                j15 = fy * prx * zi;
-                                    const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
-                                    residual = t5 - t4;
-                                    jac[0] = gx * j00 + gy * j10;
-                                    jac[1] = gx * j01 + gy * j11;
-                                    jac[2] = gx * j02 + gy * j12;
-                                    jac[3] = gx * j03 + gy * j13;
-                                    jac[4] = gx * j04 + gy * j14;
-                                    jac[5] = gx * j05 + gy * j15;
-                                }
-                            }
-                        }
+                        float jac[6], residual;
+                        chunk_terms(chunk, jac, residual);
                         // an unused pixel contributes exact zeros (x + (+-0) == x, and the sums start at +0)
                         int k = 0;
 #pragma unroll
@@ -234,6 +291,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                             }
                         }
                     }
+                }
                 }
                 if (consumer) {
                     // wave 0: sums -> full symmetric H in LDS -> lane-parallel LDLT (klt_common.h) -> dx in LDS
@@ -315,7 +373,7 @@ hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t m
         return hipSuccess;
     }
     const size_t lds = direct_lds_bytes(max_features);
-    auto kernel = direct_track_kernel;
+    void (*kernel)(const DirectParams) = p.tree ? direct_track_kernel<true> : direct_track_kernel<false>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

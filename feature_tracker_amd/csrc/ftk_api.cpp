@@ -1682,6 +1682,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ftk::DirectParams p;
     p.problems = static_cast<const ftk::DirectProblem *>(ctx->direct_table);
+    p.tree = ctx->reduction == FTK_REDUCTION_TREE ? 1 : 0;
     p.n_levels = n_levels;
     p.max_track_points = opt->max_track_points;
     p.max_iteration = opt->max_iteration;

@@ -209,6 +209,7 @@ struct DirectProblem {
 constexpr uint32_t kDirectLdsFeatures = 3072;  // tracked features whose projection table still fits in LDS beside the ring
 struct DirectParams {
     const DirectProblem *problems;  // device memory, one per workgroup
+    int32_t tree;                   // throughput mode (ftk_set_reduction_mode): butterfly sums instead of the scalar loop's order
     int32_t n_levels;
     uint32_t max_track_points, max_iteration;
     int32_t half_rows, half_cols, patch_rows, patch_cols;

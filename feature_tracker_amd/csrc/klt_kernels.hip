@@ -1458,6 +1458,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         // which this variant does not serve): one flag per lane and one ballot per iteration instead of two per chunk
         bool seen_cur = false, seen_valid = false;
         float acc = 0.0f;
+        float part[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // throughput mode only (b.tree is a compile-time constant)
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const int pxi = chunk * kChunkPixels + b.lane;
             const bool in = pxi < p.P;
@@ -1511,10 +1512,29 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             seen_cur = seen_cur || ok_cur;
             seen_valid = seen_valid || ok;
             blk_sync(b);  // one wave: LDS operations run in program order; this keeps the compiler from reordering across
-            if (b.lane < 9) {
+            if (b.tree) {
+                // throughput mode: every lane adds ITS pixel's nine products to nine partial sums (combined by a butterfly below)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    part[k] += ring[k * kChunkRow + b.lane];
+                }
+            } else if (b.lane < 9) {
                 acc = chain_chunk(acc, ring + b.lane * kChunkRow);
             }
             blk_sync(b);
+        }
+        if (b.tree) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    part[k] += __shfl_xor(part[k], off, kWave);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                acc = (b.lane == k) ? part[k] : acc;  // the sums where the exact path leaves them: lanes 0..8
+            }
         }
         FTK_STAMP_END(b, 3);  // window check + the chunks (sampling, products, chains)
         if (wave_ballot(seen_cur) == 0ull || wave_ballot(seen_valid) == 0ull) {
@@ -1581,7 +1601,11 @@ constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest firs
 // the patch of BASELINE configurations 3 and 4, is instantiated — or 0 for "as passed".  With it the patch / window geometry
 // folds into immediates (klt_fill_geometry, the function the host filled the argument with) instead of occupying SGPRs, most
 // of which the register allocator otherwise spills to vector lanes.
-template <int MODEL, int METHOD, bool SOLO, int H>
+// TREE: the throughput mode (ftk_set_reduction_mode; KltParams::tree) as a compile-time property, so that the contract path's
+// instantiations contain none of its code: the chain helpers and the chunked LSSD level sum by per-lane partials + a butterfly
+// instead of in the reference's order.  The non-fast affine variants ignore it (their 24 sums of 169 terms already run as 24
+// parallel chains; a butterfly over so few pixels is not faster) and stay exact.  Run-time geometry only (H == 0).
+template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false>
 __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument: a local copy whose arrays are indexed
     // with a run-time level would live in scratch memory
@@ -1595,7 +1619,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     extern __shared__ float4 lds_raw[];
     Blk b;
     b.solo = SOLO;
-    b.tree = p.tree != 0;
+    b.tree = TREE;
     b.tid = SOLO ? (int)(threadIdx.x & (kWave - 1)) : (int)threadIdx.x;
     b.nt = SOLO ? kWave : (int)blockDim.x;
     b.lane = b.tid & (kWave - 1);
@@ -1778,13 +1802,16 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
 template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
     void (*kernel)(const KltParams) = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0> : klt_track_kernel<MODEL, METHOD, false, 0>;
+    if (p.tree) {  // throughput mode (reported, never the contract): its own instantiations, run-time geometry
+        kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0, true> : klt_track_kernel<MODEL, METHOD, false, 0, true>;
+    }
     static const bool specialise = !(getenv("FTK_KLT_SPECIALISE") && atoi(getenv("FTK_KLT_SPECIALISE")) == 0);  // experiment switch
     // (measured per variant, 13 x 13: Basic -6...-14 %, LSSD -16...-21 %, affine fast -16 %, affine inverse / direct -8...-9 % — the
     // latter only once chain_groups' loop is kept rolled: with a compile-time round count the compiler unrolled it fully and the
     // kernel went from 81 to 128 VGPRs and 9...18 % SLOWER)
     constexpr bool gains = true;
     if constexpr (gains) {
-        if (specialise && p.half_rows == 6 && p.half_cols == 6) {
+        if (!p.tree && specialise && p.half_rows == 6 && p.half_cols == 6) {
             KltParams check = p;
             klt_fill_geometry(check);  // what the specialised kernel recomputes: it must be what the caller passed
             if (check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols && check.Ppad == p.Ppad && check.rwin_cols == p.rwin_cols) {

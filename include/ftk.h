@@ -115,9 +115,9 @@ void ftk_default_klt_options(ftk_klt_options *opt);
  *     bits, and because the convergence test |v|^2 < kMaxConvergeStep turns such differences into an extra or a missing
  *     iteration, a small fraction of the features moves by more than the 1e-3 px the contract allows (bench.py reports max /
  *     p99 / fraction > 1e-3 px and status mismatches next to the speed).  It exists to show what bit-exactness costs.
- *     Implemented for the Basic-KLT inverse kernel and for the variants whose sums go through the generic chain (Basic direct /
- *     fast, affine fast, LSSD inverse / direct and LSSD fast with several waves or luminance scaling); the other variants and
- *     the direct method ignore the setting and stay exact.
+ *     Implemented for every tracker variant except the two non-fast affine ones (24 sums of a 13 x 13 patch already run as 24
+ *     parallel chains; they ignore the setting and stay exact) and for the direct method (ftk_direct_track*), whose 50 700-term
+ *     chains per iteration are where the summation order costs most.
  */
 enum { FTK_REDUCTION_EXACT = 0, FTK_REDUCTION_TREE = 1 };
 int ftk_set_reduction_mode(ftk_context *ctx, int mode);

@@ -174,6 +174,18 @@ def direct_round():
     with np.errstate(all="ignore"):
         ok, c, q, p, s = dm.TrackFeatures(F.ImagePyramid.from_host_levels(rl), F.ImagePyramid.from_host_levels(cl), K, pts, uv, None, q0, p0)
         ok2, oc, oq, op, os_, oit = O.direct_track(rl, cl, K, pts, uv, None, q0, p0, half=half, max_points=cap)
+    if ONLY == "tree":
+        t = tree_stats.setdefault("direct (pixels)", {"n": 0, "gt": 0, "max": 0.0, "status": 0, "nonfinite": 0, "identical": 0, "d": []})
+        fin = np.isfinite(oc).all(axis=1) & np.isfinite(c).all(axis=1)
+        d = np.linalg.norm(c[fin].astype(np.float64) - oc[fin].astype(np.float64), axis=1)
+        t["n"] += int(fin.sum())
+        t["gt"] += int((d > 1e-3).sum())
+        t["max"] = max(t["max"], float(d.max()) if d.size else 0.0)
+        t["status"] += int((s != os_).sum())
+        t["identical"] += int((c.view(np.uint32) == oc.view(np.uint32)).all(axis=1).sum())
+        if len(t["d"]) < 400000:
+            t["d"].extend(d.tolist())
+        return
     same = (ok == ok2 and dm.last_iterations == oit and np.array_equal(s, os_) and np.array_equal(c.view(np.uint32), oc.view(np.uint32)) and
             np.array_equal(q.view(np.uint32), oq.view(np.uint32)) and np.array_equal(p.view(np.uint32), op.view(np.uint32)))
     note("direct", same, f"{w}x{h} L{levels} h{half} n{n} cap{cap}")
@@ -187,6 +199,7 @@ while time.time() < t_end:
         matcher_round()
     elif ONLY == "tree":
         klt_round()
+        direct_round()
     else:
         klt_round()
         matcher_round()
