@@ -1631,7 +1631,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     uint32_t block = blockIdx.x;
     if (p.sort_iters) {
         if (block == 0) {
-            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw));
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1);
             return;
         }
         block -= 1;

@@ -492,3 +492,52 @@ def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model,
     for name, (g_uv, g_st) in (("first", first), ("second", again[0]), ("third", again[1]), ("fourth", again[2]), ("stale history", stale)):
         assert np.array_equal(g_st, s), name
         assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("n", [4603, 8192])
+def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle, n, monkeypatch, tmp_path):
+    """Without a tail in the iteration counts the launch order is by image region, dealt XCD-major (klt_common.h klt_order_block,
+    xcd_major_slot): it must be a permutation for feature counts that do and do not fill the last workgroup, the slots of one XCD
+    (workgroup index mod 8) must come in runs that each cover a compact part of the image, and the results stay the oracle's."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "translation")
+    uv = synth.make_features(n, 320, 240, margin=24.0, border_fraction=0.0, half=5)
+    dump = tmp_path / "order.bin"
+    monkeypatch.setenv("FTK_KLT_SCHED_DUMP", str(dump))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = D.context_on_stream(stream, 0)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = "inverse", 5, 5, n
+    with torch.cuda.stream(stream):
+        klt = D.DeviceKlt("basic", opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        outs = []
+        for _ in range(4):
+            d_out, d_so = torch.empty_like(d_ref), torch.empty(n, dtype=torch.uint8, device=dev)
+            klt.track(d_ref, d_ref.clone(), d_st, d_out, d_so)
+            stream.synchronize()
+            outs.append((d_out.cpu().numpy(), d_so.cpu().numpy()))
+    ok, c, s, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, uv, uv, np.zeros(n, np.uint8), method="inverse", half=5, max_points=n)
+    for g_uv, g_st in outs:
+        assert np.array_equal(g_st, s)
+        assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32))
+    d = np.fromfile(dump, dtype=np.int32)
+    order, iters = d[:n], d[n:]
+    assert np.array_equal(np.sort(order), np.arange(n)), "not a permutation"
+    if np.array_equal(order, np.arange(n)):
+        pytest.skip("the iteration counts of this scene have a tail: the order is by count, not by region")
+    group, run = 4, 64  # one-wave features, four per workgroup (ftk_api.cpp default); kOrderRunGroups workgroups per run
+    dealt = (n // group) // (8 * run) * (8 * run)
+    assert dealt > 0
+    w = np.arange(dealt)                    # workgroup index -> (XCD, position among that XCD's workgroups)
+    run_of = (w % 8) + 8 * ((w // 8) // run)
+    area_all = uv[:, 0].std() * uv[:, 1].std()
+    areas = []
+    for r in np.unique(run_of):
+        slots = (w[run_of == r][:, None] * group + np.arange(group)[None, :]).ravel()
+        pts = uv[order[slots]]
+        areas.append(pts[:, 0].std() * pts[:, 1].std())
+    assert np.median(areas) < 0.25 * area_all, (np.median(areas), area_all)
