@@ -96,7 +96,10 @@ __host__ __device__ constexpr void klt_fill_geometry(KltParams &p) {
     p.magic_exc = klt_div_magic(p.ex_cols);
     p.rwin_rows = p.patch_rows + 3;
     p.rwin_cols = (p.patch_cols + 3 + 3) & ~3;  // pixel-pair columns, rounded up to a multiple of 4 (8-byte LDS stores)
-    p.cwin_margin = 2;
+#ifndef FTK_CWIN_MARGIN
+#define FTK_CWIN_MARGIN 2
+#endif
+    p.cwin_margin = FTK_CWIN_MARGIN;
     p.cwin_rows = p.rwin_rows + 2 * p.cwin_margin;
     p.cwin_cols = (p.patch_cols + 3 + 2 * p.cwin_margin + 3) & ~3;
     p.magic_rwc = klt_div_magic(p.rwin_cols);

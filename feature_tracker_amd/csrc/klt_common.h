@@ -135,6 +135,9 @@ struct Win {
     const uint16_t *data;
     int r_lo, c_lo;
     int rows, cols;  // wave-uniform
+    // floor(v) in [cover[0], cover[1]] and floor(u) in [cover[2], cover[3]]: the footprint of a patch centred at (u, v) lies inside
+    // this window (win_set_cover; an empty interval when the window's origin is too large for the test to be exact in fp32)
+    float cover[4];
 };
 
 __device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols);
@@ -614,35 +617,51 @@ __device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane);
 
 __device__ __forceinline__ Ldlt6 ldlt6_factor(const float *a_lds, int lane) { return ldlt6_factor_of(Ldlt6Dense{a_lds}, lane); }
 
+// my_ad: |A(i, i)| on lane i < 6 (anything elsewhere); ad_all[j]: the same six magnitudes, wave-uniform.  Callers that hold the
+// diagonal in registers (the non-fast affine trackers: the chain lanes' accumulators) pass it in and save two LDS round trips.
+template <typename Elem>
+__device__ __forceinline__ Ldlt6 ldlt6_factor_diag(float my_ad, const float (&ad_all)[6], const Elem &elem, int lane);
+
 template <typename Elem>
 __device__ __forceinline__ Ldlt6 ldlt6_factor_of(const Elem &elem, int lane) {
+    const int me0 = lane < 6 ? lane : 5;
+    const float my_ad = fabsf(elem(me0, me0));
+    float ad_all[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        ad_all[j] = bcast_lane(my_ad, j);
+    }
+    return ldlt6_factor_diag(my_ad, ad_all, elem, lane);
+}
+
+template <typename Elem>
+__device__ __forceinline__ Ldlt6 ldlt6_factor_diag(float my_ad, const float (&ad_all)[6], const Elem &elem, int lane) {
     // ---- pivot order, replayed on the diagonal ----
     // Distinct, non-NaN magnitudes (the normal case): selection with swaps is then simply the descending order,
     // and lane i finds its own position as the number of larger magnitudes — six broadcasts instead of a serial
     // selection sort.  Ties, NaN or an all-zero diagonal take the literal replay (first maximum, position swaps).
-    const int me0 = lane < 6 ? lane : 5;
-    const float my_ad = fabsf(elem(me0, me0));
     int rank = 0, equal = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const float aj = bcast_lane(my_ad, j);
-        rank += (aj > my_ad) ? 1 : 0;
-        equal += (aj == my_ad) ? 1 : 0;
+        rank += (ad_all[j] > my_ad) ? 1 : 0;
+        equal += (ad_all[j] == my_ad) ? 1 : 0;
     }
-    const bool irregular = wave_ballot(lane < 6 && (equal != 1)) != 0ull;  // equal == 0: NaN; > 1: a tie
+    rank = lane < 6 ? rank : 99;  // lanes that hold no row never match a position
+    equal = lane < 6 ? equal : 1;
+    const bool irregular = wave_ballot(equal != 1) != 0ull;  // equal == 0: NaN; > 1: a tie
     int pos[6];
     bool degenerate = false;
     if (!irregular) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            pos[k] = (int)__ffsll((long long)wave_ballot(lane < 6 && rank == k)) - 1;
+            pos[k] = __builtin_ctzll(wave_ballot(rank == k));  // exactly one lane holds each rank here: v_cmp + s_ff1
         }
         // the largest magnitude is positive here (six distinct non-negative numbers), so the first pivot is valid
     } else {
         float ad[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            ad[i] = fabsf(elem(i, i));
+            ad[i] = ad_all[i];
             pos[i] = i;
         }
 #pragma unroll
@@ -749,10 +768,20 @@ __device__ __forceinline__ void ldlt6_solve(const Ldlt6 &f, const float *b_lds, 
 #endif
 constexpr int kChainRound = FTK_CHAIN_ROUND;
 
+// The reads of a round are issued LAST-CONSUMED FIRST: LDS data returns in issue order, so the wait in front of the round's first
+// add (its float4 was issued last) covers the whole round — one s_waitcnt per round instead of one per float4.  A lone wave issues
+// one instruction of ANY kind per 4 cycles (scripts/microbench/dep_add_latency.hip: a dependent v_add_f32 costs 4, an s_nop or
+// s_waitcnt in between 4 more), so the waits were a ninth of the chain loop's instructions.
+#ifdef FTK_CHAIN_FORWARD_ISSUE
+constexpr bool kChainReversedIssue = false;
+#else
+constexpr bool kChainReversedIssue = true;
+#endif
 __device__ __forceinline__ void chain_load(float4 (&q)[kChainRound], const float4 *t) {
 #pragma unroll
     for (int d = 0; d < kChainRound; ++d) {
-        q[d] = t[d];
+        const int e = kChainReversedIssue ? kChainRound - 1 - d : d;
+        q[e] = t[e];
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -840,7 +869,8 @@ template <int kStride4>
 __device__ __forceinline__ void chain_load_groups(float4 (&q)[kChainRound], const float4 *t) {
 #pragma unroll
     for (int d = 0; d < kChainRound; ++d) {
-        q[d] = t[d * kStride4];
+        const int e = kChainReversedIssue ? kChainRound - 1 - d : d;
+        q[e] = t[e * kStride4];
     }
     __builtin_amdgcn_sched_barrier(0);
 }

@@ -217,6 +217,18 @@ __device__ __forceinline__ void stage_both_inside(const Blk &b, const KltParams 
     }
 }
 
+// The per-iteration form of "does the current window still cover the patch footprint" as four float compares: with
+// need = floor(x) - (half + 1) the integer test need >= lo && need + 2 half + 4 <= lo + extent (+ 1 for columns, whose last pair
+// reaches one pixel further) is floor(x) in [lo + half + 1, lo + extent - half - 3 (+ 1)] — exact in fp32 while the bounds are small
+// integers; for a window whose origin is not (a feature far outside the image) the interval is empty and the integer test decides.
+__device__ __forceinline__ void win_set_cover(const KltParams &p, Win &w) {
+    const bool small = (unsigned)(w.r_lo + (1 << 22)) < (1u << 23) && (unsigned)(w.c_lo + (1 << 22)) < (1u << 23);
+    w.cover[0] = small ? (float)(w.r_lo + p.half_rows + 1) : 1.0f;
+    w.cover[1] = small ? (float)(w.r_lo + w.rows - p.half_rows - 3) : 0.0f;
+    w.cover[2] = small ? (float)(w.c_lo + p.half_cols + 1) : 1.0f;
+    w.cover[3] = small ? (float)(w.c_lo + w.cols - p.half_cols - 2) : 0.0f;
+}
+
 // Level entry: stages the reference footprint of (ref_u, ref_v) and the current footprint (+ margin)
 // of (cur_u, cur_v) back to back with a single barrier, so the global round trips overlap.
 __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
@@ -232,6 +244,7 @@ __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParam
     cw.rows = p.cwin_rows;
     cw.cols = p.cwin_cols;
     cw.data = c.cur_win;
+    win_set_cover(p, cw);
     if (ref_axis_variants > 0) {
         build_axis_tables(b, p, ref, rw, ref_u, ref_v, ref_axis_variants, reinterpret_cast<float4 *>(c.a0));
     }
@@ -248,6 +261,10 @@ __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParam
 // it (with cwin_margin pixels of slack on every side) when it does not.  Wave-uniform decision.
 __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams &p, const DevImage &cur, float u, float v, Carve &c, Win &w,
                                                   bool &staged) {
+    const float fu = floorf(u), fv = floorf(v);
+    if (staged && fv >= w.cover[0] && fv <= w.cover[1] && fu >= w.cover[2] && fu <= w.cover[3]) {
+        return;  // the usual case: a handful of compares (NaN and huge coordinates fail them and take the integer test below)
+    }
     int need_r, need_c;
     footprint_origin(p, u, v, need_r, need_c);
     const long long nr = need_r, nc = need_c;
@@ -259,6 +276,7 @@ __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams 
         w.rows = p.cwin_rows;
         w.cols = p.cwin_cols;
         w.data = c.cur_win;
+        win_set_cover(p, w);
         stage_any(b, cur, c.cur_win, w.r_lo, w.c_lo, w.rows, w.cols, p.magic_cwc, p.magic_cwq);
         blk_sync(b);
         staged = true;
@@ -413,6 +431,11 @@ __device__ __forceinline__ bool nonfast_gather(const DevImage &cur, const Win &c
     if (MODE == kGatherHoisted) {
         miss = miss || (valid && !hit);
     }
+#ifdef FTK_STAMPS
+    if (MODE == kGatherInline) {
+        miss = miss || (valid && !hit);  // diagnostic: the affine levels count the passes that left the window (stamp slot 2)
+    }
+#endif
     return ok && valid;
 }
 
@@ -564,13 +587,14 @@ __device__ __forceinline__ void basic_level(const Blk &b, const KltParams &p, co
             ldlt_solve<2>(m, bb, sol);
             c.sums[16] = sol[0];
             c.sums[17] = sol[1];
+            reinterpret_cast<uint32_t *>(c.sums)[18] = collect_count(b, c.wave_cnt, iter);  // travels with the solution: one LDS round trip after the barrier
         });
         FTK_STAMP_END(b, 5);
-        n_valid = collect_count(b, c.wave_cnt, iter);
+        n_valid = reinterpret_cast<const uint32_t *>(c.sums)[18];
+        const float v[2] = {c.sums[16], c.sums[17]};
         if (n_valid == 0) {
             break;
         }
-        const float v[2] = {c.sums[16], c.sums[17]};
         if (isnan(v[0]) || isnan(v[1])) {
             status = FTK_NUMERIC_ERROR;
             break;
@@ -667,12 +691,13 @@ __device__ __forceinline__ void basic_level_fast(const Blk &b, const KltParams &
             ldlt_solve<2>(m, bb, sol);
             c.sums[16] = sol[0];
             c.sums[17] = sol[1];
+            reinterpret_cast<uint32_t *>(c.sums)[18] = collect_count(b, c.wave_cnt, iter);  // travels with the solution: one LDS round trip after the barrier
         });
-        n_valid = collect_count(b, c.wave_cnt, iter);
+        n_valid = reinterpret_cast<const uint32_t *>(c.sums)[18];
+        const float v[2] = {c.sums[16], c.sums[17]};
         if (n_valid == 0) {
             break;
         }
-        const float v[2] = {c.sums[16], c.sums[17]};
         if (isnan(v[0]) || isnan(v[1])) {
             status = FTK_NUMERIC_ERROR;
             break;
@@ -735,20 +760,34 @@ __device__ __forceinline__ void affine_bias_terms(const KltParams &p, float *ter
     terms[(first_bias_chain + 5) * p.Ppad + pxi] = ok ? -(dt * dy) : 0.0f;
 }
 
-// Chain index of H(i, j), row-major (H(1,2) = H(0,3), H(1,4) = H(0,5), H(3,4) = H(2,3): the aliases of affine_klt.cpp:264-270 and
-// the (sic) of :245): what Ldlt6Mapped reads the 18 sums through.  Five bits per entry, twelve entries per 64-bit word.
-__device__ __forceinline__ uint8_t affine_h_index(int e) {
-    // row 0: 0 1 2 3 4 5 | row 1: 1 6 3 7 5 8 | row 2: 2 3 9 10 11 12 | row 3: 3 7 10 13 10 14 | row 4: 4 5 11 10 15 16 | row 5: 5 8 12 14 16 17
-    constexpr unsigned long long w0 = 0ull | (1ull << 5) | (2ull << 10) | (3ull << 15) | (4ull << 20) | (5ull << 25) | (1ull << 30) | (6ull << 35) | (3ull << 40) |
-                                      (7ull << 45) | (5ull << 50) | (8ull << 55);
-    constexpr unsigned long long w1 = 2ull | (3ull << 5) | (9ull << 10) | (10ull << 15) | (11ull << 20) | (12ull << 25) | (3ull << 30) | (7ull << 35) | (10ull << 40) |
-                                      (13ull << 45) | (10ull << 50) | (14ull << 55);
-    constexpr unsigned long long w2 = 4ull | (5ull << 5) | (11ull << 10) | (10ull << 15) | (15ull << 20) | (16ull << 25) | (5ull << 30) | (8ull << 35) | (12ull << 40) |
-                                      (14ull << 45) | (16ull << 50) | (17ull << 55);
-    const int word = e >= 24 ? 2 : (e >= 12 ? 1 : 0);
-    const unsigned long long w = word == 2 ? w2 : (word == 1 ? w1 : w0);
-    return (uint8_t)((w >> (5 * (e - 12 * word))) & 31ull);
+// Where chain lane s < 18 stores its sum in the dense row-major 6 x 6 Hessian (H(1,2) = H(0,3), H(1,4) = H(0,5), H(3,4) = H(2,3): the
+// aliases of affine_klt.cpp:264-270 and the (sic) of :245): up to four entries e = 6 i + j per sum, one byte each (sums with fewer
+// entries repeat one).  Row i of chain indices: 0 1 2 3 4 5 | 1 6 3 7 5 8 | 2 3 9 10 11 12 | 3 7 10 13 10 14 | 4 5 11 10 15 16 | 5 8 12 14 16 17.
+__device__ __forceinline__ uint32_t affine_dense_slots(int sum) {
+    constexpr uint32_t kSlots[18] = {
+        0x00000000u | 0u * 0x01010101u,                           //  0: H00
+        1u | 6u << 8 | 1u << 16 | 6u << 24,                       //  1: H01 H10
+        2u | 12u << 8 | 2u << 16 | 12u << 24,                     //  2: H02 H20
+        3u | 18u << 8 | 8u << 16 | 13u << 24,                     //  3: H03 H30 H12 H21
+        4u | 24u << 8 | 4u << 16 | 24u << 24,                     //  4: H04 H40
+        5u | 30u << 8 | 10u << 16 | 25u << 24,                    //  5: H05 H50 H14 H41
+        7u * 0x01010101u,                                         //  6: H11
+        9u | 19u << 8 | 9u << 16 | 19u << 24,                     //  7: H13 H31
+        11u | 31u << 8 | 11u << 16 | 31u << 24,                   //  8: H15 H51
+        14u * 0x01010101u,                                        //  9: H22
+        15u | 20u << 8 | 22u << 16 | 27u << 24,                   // 10: H23 H32 H34 H43
+        16u | 26u << 8 | 16u << 16 | 26u << 24,                   // 11: H24 H42
+        17u | 32u << 8 | 17u << 16 | 32u << 24,                   // 12: H25 H52
+        21u * 0x01010101u,                                        // 13: H33
+        23u | 33u << 8 | 23u << 16 | 33u << 24,                   // 14: H35 H53
+        28u * 0x01010101u,                                        // 15: H44
+        29u | 34u << 8 | 29u << 16 | 34u << 24,                   // 16: H45 H54
+        35u * 0x01010101u,                                        // 17: H55
+    };
+    return kSlots[sum < 18 ? sum : 17];
 }
+// chain lanes that hold the diagonal H(j, j), j = 0..5
+constexpr int kAffineDiagLane[6] = {A_XX_DXDX, A_XX_DYDY, A_YY_DXDX, A_YY_DYDY, A_DXDX, A_DYDY};
 
 // The 24 products of one pixel of the non-fast affine variants (affine_klt.cpp:229-256).  An unused pixel contributes exact zeros
 // to every sum: zeroing the five factors does that with five selects instead of one per product — every product is then +0 or
@@ -844,9 +883,7 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
     nonfast_level_setup<METHOD, true>(b, p, ref, rw, ref_u, ref_v, c);
     FTK_STAMP_END(b, 1);
     const bool staged = !b.solo && b.nwaves > 1 && p.P > b.nt;
-    if (b.tid < 36) {
-        reinterpret_cast<uint8_t *>(c.sums + 32)[b.tid] = affine_h_index(b.tid);  // visible to wave 0 after the first barrier below
-    }
+    const uint32_t dense_slots = affine_dense_slots(b.lane);  // chain lane -> its entries of the dense Hessian (wave 0)
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
         FTK_STAMP_BEGIN(b);
@@ -887,6 +924,9 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
                 const bool ok = produce(b.tid);  // P > nt: every lane has a pixel
                 n_valid += (uint32_t)__popcll(wave_ballot(ok));
             }
+#ifdef FTK_STAMPS
+            b.stamp_acc[2] += (unsigned long long)__popcll(wave_ballot(miss_unused));  // lanes of wave 0's pass that sampled global memory
+#endif
             blk_sync(b);  // the products of pixels [0, nt) are visible
             FTK_STAMP_END(b, 3);
             if (b.wave == 0) {
@@ -909,24 +949,45 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             }
         }
         if (b.wave == 0) {
-            if (b.lane < A_COUNT) {
+            // The chain lanes publish their sums as the DENSE row-major Hessian (sums[32..68), every alias written by the lane that
+            // owns the sum) and the six bias sums; the diagonal the pivot search needs is read from the accumulators themselves.
+            float *const dense = c.sums + 32;
+            if (b.lane < 18) {
+                dense[dense_slots & 0xffu] = acc;
+                dense[(dense_slots >> 8) & 0xffu] = acc;
+                dense[(dense_slots >> 16) & 0xffu] = acc;
+                dense[dense_slots >> 24] = acc;
+            } else if (b.lane < A_COUNT) {
                 c.sums[b.lane] = acc;
             }
             FTK_STAMP_END(b, 4);
-            // the lane-parallel LDLT (klt_common.h: rows on lanes 0..5) reads H(i, j) straight from the 18 sums through the index
-            // map in sums[32..] (written once per level below): no 6 x 6 copy is made
+            float ad_all[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                ad_all[j] = fabsf(bcast_lane(acc, kAffineDiagLane[j]));
+            }
+            float my_ad = ad_all[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                my_ad = (b.lane == j) ? ad_all[j] : my_ad;
+            }
             __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
-            const Ldlt6 fac = ldlt6_factor_of(Ldlt6Mapped{c.sums, reinterpret_cast<const uint8_t *>(c.sums + 32)}, b.lane);
+            const Ldlt6 fac = ldlt6_factor_diag(my_ad, ad_all, Ldlt6Dense{dense}, b.lane);
             ldlt6_solve(fac, c.sums + A_B0, c.sums + A_COUNT, b.lane);
+            // every wave's count was published before the barrier in front of the last chain segment: their total travels with
+            // the solution, so that the waves read both with one LDS round trip after the barrier below
+            if (b.lane == 0) {
+                reinterpret_cast<uint32_t *>(c.sums)[A_COUNT + 6] = collect_count(b, c.wave_cnt, iter);
+            }
             FTK_STAMP_END(b, 5);
         }
         blk_sync(b);  // the solution is visible
         FTK_STAMP_END(b, 6);
-        n_valid = collect_count(b, c.wave_cnt, iter);
+        n_valid = reinterpret_cast<const uint32_t *>(c.sums)[A_COUNT + 6];
+        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         if (n_valid == 0) {
             break;
         }
-        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         float v[2];
         v[0] = (z[0] * s.cur_u + z[2] * s.cur_v) + z[4];
         v[1] = (z[1] * s.cur_u + z[3] * s.cur_v) + z[5];
@@ -1025,12 +1086,17 @@ __device__ __forceinline__ void affine_level_fast(const Blk &b, const KltParams 
             n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
         publish_count(b, n_valid, c.wave_cnt, iter);
-        chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() { ldlt6_solve(fac, c.sums, c.sums + A_COUNT, b.lane); });
-        n_valid = collect_count(b, c.wave_cnt, iter);
+        chain_then(b, c.terms, 6, p.Ppad, c.sums, true, [&]() {
+            ldlt6_solve(fac, c.sums, c.sums + A_COUNT, b.lane);
+            if (b.lane == 0) {
+                reinterpret_cast<uint32_t *>(c.sums)[A_COUNT + 6] = collect_count(b, c.wave_cnt, iter);  // travels with the solution
+            }
+        });
+        n_valid = reinterpret_cast<const uint32_t *>(c.sums)[A_COUNT + 6];
+        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         if (n_valid == 0) {
             break;
         }
-        const float z[6] = {c.sums[A_COUNT], c.sums[A_COUNT + 1], c.sums[A_COUNT + 2], c.sums[A_COUNT + 3], c.sums[A_COUNT + 4], c.sums[A_COUNT + 5]};
         if (isnan(z[0]) || isnan(z[1]) || isnan(z[2]) || isnan(z[3]) || isnan(z[4]) || isnan(z[5])) {
             status = FTK_NUMERIC_ERROR;
             break;

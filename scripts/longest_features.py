@@ -61,5 +61,8 @@ with torch.cuda.stream(stream):
     for k in sorted({1, 8, K, 256}):
         t, it = run(uv[order[:k]], 30)
         print(f"  the {k:4d} longest features alone: {t:7.1f} us per launch (iterations {it.min()}..{it.max()})")
+    for k in (1, 8, 64):  # the launch WITHOUT its k longest features: what the tail costs
+        t, it = run(uv[np.sort(order[k:])], 30)
+        print(f"  all but the {k:3d} longest features: {t:7.1f} us per launch (iterations {it.min()}..{it.max()})")
     t, it = run(uv[order[-256:]], 30)
     print(f"  the  256 shortest features alone: {t:7.1f} us per launch (iterations {it.min()}..{it.max()})")
