@@ -499,6 +499,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         cw.c_lo = wadd(need_c, -p.cwin_margin);
         cw.rows = p.cwin_rows;
         cw.cols = p.cwin_cols;
+        win_set_cover(p, cw);
         int nr_lo = 0, nc_lo = 0;
         if (level > 0) {
             footprint_origin(p, ref_u * 2.0f, ref_v * 2.0f, nr_lo, nc_lo);
@@ -589,7 +590,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
             ++iters;
             FTK_STAMP_BEGIN(b);
-            if (iter > 0) {
+            if (iter > 0 && !win_covers(cw, cur_u, cur_v)) {  // four float compares in the usual case (klt_common.h win_set_cover)
                 // restage the current window when the patch has left it (wave-uniform)
                 footprint_origin(p, cur_u, cur_v, need_r, need_c);
                 const long long nr = need_r, nc = need_c;
@@ -598,6 +599,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (!covered) {
                     cw.r_lo = wadd(need_r, -p.cwin_margin);
                     cw.c_lo = wadd(need_c, -p.cwin_margin);
+                    win_set_cover(p, cw);
                     stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
                     pb_sync(solo);
                 }
@@ -700,6 +702,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 FTK_STAMP_END(b, 5);
     #endif
             }
+            const float v0 = c.sol[0], v1 = c.sol[1];  // read together with the counts: one LDS round trip, not two
             uint32_t n_valid = 0;
             for (int w = ((b.nwaves == 1 || TREE) ? 0 : 1); w < b.nwaves; ++w) {
                 n_valid += c.slots[4 + 4 * (iter & 1u) + w];
@@ -707,7 +710,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             if (n_valid == 0) {
                 break;  // basic_klt.cpp:94
             }
-            const float v0 = c.sol[0], v1 = c.sol[1];
             if (isnan(v0) || isnan(v1)) {
                 status = FTK_NUMERIC_ERROR;
                 break;

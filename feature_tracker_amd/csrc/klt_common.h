@@ -950,6 +950,23 @@ __device__ __forceinline__ void footprint_origin(const KltParams &p, float u, fl
     c_lo = __builtin_amdgcn_readfirstlane(wadd(f2i(floorf(u)), -(p.half_cols + 1)));
 }
 
+// The per-iteration form of "does the current window still cover the patch footprint" as four float compares: with
+// need = floor(x) - (half + 1) the integer test need >= lo && need + 2 half + 4 <= lo + extent (+ 1 for columns, whose last pair
+// reaches one pixel further) is floor(x) in [lo + half + 1, lo + extent - half - 3 (+ 1)] — exact in fp32 while the bounds are small
+// integers; for a window whose origin is not (a feature far outside the image) the interval is empty and the integer test decides.
+__device__ __forceinline__ void win_set_cover(const KltParams &p, Win &w) {
+    const bool small = (unsigned)(w.r_lo + (1 << 22)) < (1u << 23) && (unsigned)(w.c_lo + (1 << 22)) < (1u << 23);
+    w.cover[0] = small ? (float)(w.r_lo + p.half_rows + 1) : 1.0f;
+    w.cover[1] = small ? (float)(w.r_lo + w.rows - p.half_rows - 3) : 0.0f;
+    w.cover[2] = small ? (float)(w.c_lo + p.half_cols + 1) : 1.0f;
+    w.cover[3] = small ? (float)(w.c_lo + w.cols - p.half_cols - 2) : 0.0f;
+}
+
+__device__ __forceinline__ bool win_covers(const Win &w, float u, float v) {
+    const float fu = floorf(u), fv = floorf(v);
+    return fv >= w.cover[0] && fv <= w.cover[1] && fu >= w.cover[2] && fu <= w.cover[3];  // NaN and huge coordinates fail
+}
+
 // One pixel-pair element of a window: (img[clamp(r)][clamp(c)], img[clamp(r)][clamp(c + 1)]).
 __device__ __forceinline__ uint16_t window_element(const DevImage &im, int r_lo, int c_lo, int idx, int wcols, uint32_t magic_cols) {
     const int r = (int)__umulhi((unsigned)idx, magic_cols);

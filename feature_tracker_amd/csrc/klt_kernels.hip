@@ -217,18 +217,6 @@ __device__ __forceinline__ void stage_both_inside(const Blk &b, const KltParams 
     }
 }
 
-// The per-iteration form of "does the current window still cover the patch footprint" as four float compares: with
-// need = floor(x) - (half + 1) the integer test need >= lo && need + 2 half + 4 <= lo + extent (+ 1 for columns, whose last pair
-// reaches one pixel further) is floor(x) in [lo + half + 1, lo + extent - half - 3 (+ 1)] — exact in fp32 while the bounds are small
-// integers; for a window whose origin is not (a feature far outside the image) the interval is empty and the integer test decides.
-__device__ __forceinline__ void win_set_cover(const KltParams &p, Win &w) {
-    const bool small = (unsigned)(w.r_lo + (1 << 22)) < (1u << 23) && (unsigned)(w.c_lo + (1 << 22)) < (1u << 23);
-    w.cover[0] = small ? (float)(w.r_lo + p.half_rows + 1) : 1.0f;
-    w.cover[1] = small ? (float)(w.r_lo + w.rows - p.half_rows - 3) : 0.0f;
-    w.cover[2] = small ? (float)(w.c_lo + p.half_cols + 1) : 1.0f;
-    w.cover[3] = small ? (float)(w.c_lo + w.cols - p.half_cols - 2) : 0.0f;
-}
-
 // Level entry: stages the reference footprint of (ref_u, ref_v) and the current footprint (+ margin)
 // of (cur_u, cur_v) back to back with a single barrier, so the global round trips overlap.
 __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
@@ -261,8 +249,7 @@ __device__ __forceinline__ void stage_level_windows(const Blk &b, const KltParam
 // it (with cwin_margin pixels of slack on every side) when it does not.  Wave-uniform decision.
 __device__ __forceinline__ void ensure_cur_window(const Blk &b, const KltParams &p, const DevImage &cur, float u, float v, Carve &c, Win &w,
                                                   bool &staged) {
-    const float fu = floorf(u), fv = floorf(v);
-    if (staged && fv >= w.cover[0] && fv <= w.cover[1] && fu >= w.cover[2] && fu <= w.cover[3]) {
+    if (staged && win_covers(w, u, v)) {
         return;  // the usual case: a handful of compares (NaN and huge coordinates fail them and take the integer test below)
     }
     int need_r, need_c;
