@@ -1092,7 +1092,63 @@ __device__ __forceinline__ int wave_bin_claim(int *bins, int bin, bool active) {
     return slot;
 }
 
-constexpr int kOrderLdsBytes = (256 + 256 + 4) * 4;
+// Counting only (nothing returns, so nothing waits): ONE LDS atomic for all the lanes that share the lowest active lane's bin, one
+// each for the rest.
+__device__ __forceinline__ void wave_bin_count(int *bins, int bin, bool active) {
+    const unsigned long long todo = wave_ballot(active);
+    if (todo == 0ull) {
+        return;
+    }
+    const int leader = __builtin_ctzll(todo);
+    const int leader_bin = __builtin_amdgcn_readlane(bin, leader);
+    const bool with_leader = active && bin == leader_bin;
+    const unsigned long long same = wave_ballot(with_leader);
+    if ((int)(threadIdx.x & 63) == leader) {
+        (void)__hip_atomic_fetch_add(&bins[leader_bin], __popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (active && !with_leader) {
+        (void)__hip_atomic_fetch_add(&bins[bin], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// wave_bin_claim for U independent elements per lane with TWO waits instead of 2 U: the U leader atomics are issued back to back,
+// then the U atomics of the remaining lanes.  Slots stay unique (LDS atomics of a wave execute in order; other waves interleave
+// atomically); which of two equal-bin features gets the earlier slot is not defined, as before.
+template <int U>
+__device__ __forceinline__ void wave_bin_claim_batch(int *bins, const int (&bin)[U], const bool (&active)[U], int (&slot)[U]) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int leader[U], leader_bin[U], base[U];
+    unsigned long long same[U];
+    bool with_leader[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long long todo = wave_ballot(active[u]);
+        leader[u] = todo != 0ull ? __builtin_ctzll(todo) : 0;
+        leader_bin[u] = __builtin_amdgcn_readlane(bin[u], leader[u]);
+        with_leader[u] = active[u] && bin[u] == leader_bin[u];
+        same[u] = wave_ballot(with_leader[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        base[u] = 0;
+        if (same[u] != 0ull && lane == leader[u]) {
+            base[u] = atomicAdd(&bins[leader_bin[u]], __popcll(same[u]));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        base[u] = __builtin_amdgcn_readlane(base[u], leader[u]);
+        slot[u] = with_leader[u] ? base[u] + __popcll(same[u] & below) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (active[u] && !with_leader[u]) {
+            slot[u] = atomicAdd(&bins[bin[u]], 1);
+        }
+    }
+}
+
+constexpr int kOrderLdsBytes = (4 * 256 + 4) * 4;  // two histograms (iteration counts, image tiles) with their scans + a flag
 
 // Rank in tile order -> launch slot.  Workgroups go to the eight XCDs round robin (workgroup w -> XCD w mod 8, each with its own
 // L2), so runs of kOrderRunGroups consecutive workgroup ranks (one small image region) are dealt to ONE XCD, run after run round
@@ -1118,14 +1174,11 @@ __device__ __forceinline__ int xcd_major_slot(int rank, int n, int group) {
     return (xcd + 8 * j) * group + sub;
 }
 
-// 16 x 16 tiles of the level-0 image in Morton order: 256 bins
-__device__ __forceinline__ int morton_tile(float u, float v, float inv_tile_u, float inv_tile_v) {
+// 16 x 16 tiles of the level-0 image, row by row: 256 bins.  (A run of the launch order — kOrderRunGroups workgroups — holds two
+// or three tiles' features, so a squarer Morton walk over the tiles would buy nothing, and this key is three instructions.)
+__device__ __forceinline__ int image_tile(float u, float v, float inv_tile_u, float inv_tile_v) {
     const int tx = (int)fminf(fmaxf(u * inv_tile_u, 0.0f), 15.0f), ty = (int)fminf(fmaxf(v * inv_tile_v, 0.0f), 15.0f);  // NaN -> 0
-    int key = 0;
-    for (int bit = 0; bit < 4; ++bit) {
-        key |= ((tx >> bit) & 1) << (2 * bit) | ((ty >> bit) & 1) << (2 * bit + 1);
-    }
-    return key;
+    return ty * 16 + tx;
 }
 
 // exclusive scan of the 256 bin counts into bin_start by one wave, four bins per lane
@@ -1149,91 +1202,101 @@ __device__ __forceinline__ void order_scan_bins(const int *bin_count, int *bin_s
 // feature takes about as long): in space — features of one image region next to each other AND on one XCD, so that the window
 // loads of a level entry find their lines in that XCD's L2 instead of every L2 fetching the whole pyramid (`ref_uv`: this call's
 // reference pixels at level 0, `cols` x `rows` that level; `group`: features per workgroup of the launch the order is for).
+//
+// ONE workgroup does this beside the feature workgroups of a launch, so it must not outlast them: two passes over the list, both
+// histograms (256 iteration bins, 256 image tiles) counted in the first, and the global loads of kOrderBatch elements per thread
+// in flight together (one load per trip had made each pass a chain of ~100 dependent L2 round trips: 137 us for 25 000 features
+// and 1.16 ms for 200 000 — longer than the 200 000-feature launch itself).
+constexpr int kOrderBatch = 8;
+
 __device__ __forceinline__ void klt_order_block(const uint32_t *iters, int32_t *order, int n, int *lds, const float *ref_uv, int cols, int rows, int group) {
-    int *bin_count = lds, *bin_start = lds + 256, *flat = lds + 512;
+    int *bin_count = lds, *bin_start = lds + 256, *tile_count = lds + 512, *tile_start = lds + 768, *flat = lds + 1024;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const bool spatial = ref_uv != nullptr && cols >= 16 && rows >= 16;
+    const float inv_tile_u = 16.0f / (float)(cols > 0 ? cols : 1), inv_tile_v = 16.0f / (float)(rows > 0 ? rows : 1);
+    const float2 *uv2 = reinterpret_cast<const float2 *>(ref_uv);
     for (int k = tid; k < 256; k += nt) {
         bin_count[k] = 0;
+        tile_count[k] = 0;
     }
     __syncthreads();
-    for (int base = 0; base < n; base += nt) {
-        const int i = base + tid;
-        const bool active = i < n;
-        const int bin = active ? 255 - (int)min(iters[i], 255u) : 0;
-        (void)wave_bin_claim(bin_count, bin, active);
+    for (int base = 0; base < n; base += nt * kOrderBatch) {
+        uint32_t it[kOrderBatch];
+        float2 uv[kOrderBatch];
+#pragma unroll
+        for (int u = 0; u < kOrderBatch; ++u) {
+            // unconditional loads of a clamped index through 32-bit byte offsets from the uniform bases: two instructions of address
+            const uint32_t i = (uint32_t)min(base + u * nt + tid, n - 1);
+            it[u] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(iters) + i * 4u);
+            uv[u] = spatial ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(uv2) + i * 8u) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < kOrderBatch; ++u) {
+            const bool active = base + u * nt + tid < n;
+            wave_bin_count(bin_count, active ? 255 - (int)min(it[u], 255u) : 0, active);
+            if (spatial && active) {
+                // tile keys are spread over the bins: one plain LDS atomic per lane, nothing returned
+                (void)__hip_atomic_fetch_add(&tile_count[image_tile(uv[u].x, uv[u].y, inv_tile_u, inv_tile_v)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
     __syncthreads();
     if (tid < 64) {
-        // exclusive scan of 256 bins by one wave: four bins per lane; and the no-tail test
+        // exclusive scans of both histograms by one wave: four bins per lane; and the no-tail test on the iteration counts
         const int l = tid;
         const int c0 = bin_count[4 * l], c1 = bin_count[4 * l + 1], c2 = bin_count[4 * l + 2], c3 = bin_count[4 * l + 3];
-        int run = c0 + c1 + c2 + c3;
         // bin k holds count 255 - k: weighted sum and largest count over the tracked features (count > 0: bins 0..254)
         long long weighted = (long long)c0 * (255 - 4 * l) + (long long)c1 * (254 - 4 * l) + (long long)c2 * (253 - 4 * l) + (long long)c3 * (252 - 4 * l);
-        int tracked = run - (l == 63 ? c3 : 0);
+        int tracked = c0 + c1 + c2 + c3 - (l == 63 ? c3 : 0);
         int largest = c0 ? 255 - 4 * l : (c1 ? 254 - 4 * l : (c2 ? 253 - 4 * l : (c3 ? 252 - 4 * l : 0)));
         for (int off = 32; off >= 1; off >>= 1) {
             weighted += __shfl_xor(weighted, off);
             tracked += __shfl_xor(tracked, off);
             largest = max(largest, __shfl_xor(largest, off));
         }
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(run, off);
-            if (l >= off) {
-                run += up;
-            }
-        }
-        const int before = run - (c0 + c1 + c2 + c3);
-        bin_start[4 * l] = before;
-        bin_start[4 * l + 1] = before + c0;
-        bin_start[4 * l + 2] = before + c0 + c1;
-        bin_start[4 * l + 3] = before + c0 + c1 + c2;
+        order_scan_bins(bin_count, bin_start, l);
+        order_scan_bins(tile_count, tile_start, l);
         if (l == 0) {
             *flat = (tracked == 0 || 2ll * largest * tracked <= 3ll * weighted) ? 1 : 0;  // largest <= 1.5 x mean
         }
     }
     __syncthreads();
-    if (*flat) {
-        if (ref_uv == nullptr || cols < 16 || rows < 16) {
-            for (int i = tid; i < n; i += nt) {
-                order[i] = i;
-            }
-            return;
-        }
-        const float inv_tile_u = 16.0f / (float)cols, inv_tile_v = 16.0f / (float)rows;
-        for (int k = tid; k < 256; k += nt) {
-            bin_count[k] = 0;
-        }
-        __syncthreads();
-        for (int base = 0; base < n; base += nt) {
-            const int i = base + tid;
-            const bool active = i < n;
-            const int bin = active ? morton_tile(ref_uv[2 * i], ref_uv[2 * i + 1], inv_tile_u, inv_tile_v) : 0;
-            (void)wave_bin_claim(bin_count, bin, active);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            order_scan_bins(bin_count, bin_start, tid);
-        }
-        __syncthreads();
-        for (int base = 0; base < n; base += nt) {
-            const int i = base + tid;
-            const bool active = i < n;
-            const int bin = active ? morton_tile(ref_uv[2 * i], ref_uv[2 * i + 1], inv_tile_u, inv_tile_v) : 0;
-            const int rank = wave_bin_claim(bin_start, bin, active);
-            if (active) {
-                order[xcd_major_slot(rank, n, group)] = i;
-            }
+    const bool by_tile = *flat != 0 && spatial;
+    if (*flat != 0 && !spatial) {
+        for (int i = tid; i < n; i += nt) {
+            order[i] = i;
         }
         return;
     }
-    for (int base = 0; base < n; base += nt) {
-        const int i = base + tid;
-        const bool active = i < n;
-        const int bin = active ? 255 - (int)min(iters[i], 255u) : 0;
-        const int slot = wave_bin_claim(bin_start, bin, active);
-        if (active) {
-            order[slot] = i;
+    for (int base = 0; base < n; base += nt * kOrderBatch) {
+        uint32_t it[kOrderBatch];
+        float2 uv[kOrderBatch];
+#pragma unroll
+        for (int u = 0; u < kOrderBatch; ++u) {
+            const uint32_t i = (uint32_t)min(base + u * nt + tid, n - 1);
+            it[u] = by_tile ? 0u : *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(iters) + i * 4u);
+            uv[u] = by_tile ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(uv2) + i * 8u) : make_float2(0.0f, 0.0f);
+        }
+        int bin[kOrderBatch], slot[kOrderBatch];
+        bool active[kOrderBatch];
+#pragma unroll
+        for (int u = 0; u < kOrderBatch; ++u) {
+            active[u] = base + u * nt + tid < n;
+            bin[u] = !active[u] ? 0 : (by_tile ? image_tile(uv[u].x, uv[u].y, inv_tile_u, inv_tile_v) : 255 - (int)min(it[u], 255u));
+        }
+        if (by_tile) {
+#pragma unroll
+            for (int u = 0; u < kOrderBatch; ++u) {
+                slot[u] = active[u] ? atomicAdd(&tile_start[bin[u]], 1) : 0;  // all in flight before the first is used
+            }
+        } else {
+            wave_bin_claim_batch<kOrderBatch>(bin_start, bin, active, slot);
+        }
+#pragma unroll
+        for (int u = 0; u < kOrderBatch; ++u) {
+            if (active[u]) {
+                order[by_tile ? xcd_major_slot(slot[u], n, group) : slot[u]] = base + u * nt + tid;
+            }
         }
     }
 }
