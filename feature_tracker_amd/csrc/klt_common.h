@@ -87,19 +87,6 @@ __device__ __forceinline__ Blk opaque_blk(const Blk &b) {
     return o;
 }
 
-// A kernel argument read where it is USED instead of at kernel entry.  The compiler loads every field of the by-value argument
-// block up front and keeps it in SGPRs for the whole kernel; the pointers that are only needed when a feature retires (outputs,
-// iteration counts) then occupy ten SGPRs through every loop of a kernel that spills scalar registers to vector lanes.  The
-// argument block is the kernel's only parameter, so a field sits at its offsetof() behind the kernarg segment pointer; the asm
-// barrier keeps the load from being hoisted.
-#define FTK_LATE_ARG(field) ftk_late_arg<decltype(KltParams::field)>(offsetof(KltParams, field))
-template <typename T>
-__device__ __forceinline__ T ftk_late_arg(size_t offset) {
-    const char __attribute__((address_space(4))) *base = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(base));
-    return *reinterpret_cast<const T __attribute__((address_space(4))) *>(base + offset);
-}
-
 // All features of a call are resident at once and the hardware arbitrates oldest-wave-first, which
 // lets the first-dispatched features finish early and leaves the youngest ones to run the tail
 // alone at single-wave issue rate.  Waves therefore raise their own priority while they are
@@ -600,16 +587,11 @@ struct Ldlt6 {
 
 __device__ __forceinline__ float bcast_lane(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
 
-// Element (i, j) of the symmetric matrix, wherever it lives: a row-major 6 x 6 in LDS, or a set of sums addressed through a
-// 36-byte index map (the affine trackers keep their 18 distinct Hessian sums and never materialise the matrix).
+// Element (i, j) of the symmetric matrix: a row-major 6 x 6 in LDS (the non-fast affine trackers' chain lanes store their 18
+// distinct Hessian sums straight into it, klt_kernels.hip affine_dense_slots).
 struct Ldlt6Dense {
     const float *a;
     __device__ __forceinline__ float operator()(int i, int j) const { return a[i * 6 + j]; }
-};
-struct Ldlt6Mapped {
-    const float *values;
-    const uint8_t *map;  // 36 entries, row-major: index into `values`
-    __device__ __forceinline__ float operator()(int i, int j) const { return values[map[i * 6 + j]]; }
 };
 
 template <typename Elem>
@@ -1061,36 +1043,9 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
 // Launch order of a later call, computed by ONE extra workgroup of the tracker launch itself (block 0: it starts first and
 // runs beside the feature workgroups, so the sort costs no launch and no time of its own): the feature indices sorted by the
 // iteration counts of the PREVIOUS call, longest first — a counting sort over min(count, 255) with the workgroup's dynamic LDS
-// as its 2 x 256 bins.  It walks the list in index order, so inside a bin the features keep list order at workgroup
-// granularity.  When the counts have no tail (largest <= 1.5 x the mean of the tracked features) an order would buy nothing
-// and the identity is written.  Any permutation yields the same tracking results; only the schedule differs.
+// as its bins.  When the counts have no tail (largest <= 1.5 x the mean of the tracked features) the same counting sort runs over
+// image tiles instead (klt_order_block).  Any permutation yields the same tracking results; only the schedule differs.
 // ---------------------------------------------------------------------------------------------
-
-// A slot in its bin for every active lane.  One round of "the lowest active lane's bin: ONE LDS atomic for all the lanes that
-// share it" — iteration counts cluster, and a call whose features all took 5 iterations would otherwise serialise thousands
-// of atomics on one address — then one atomic per remaining lane (counts spread over many bins: little contention).
-__device__ __forceinline__ int wave_bin_claim(int *bins, int bin, bool active) {
-    int slot = 0;
-    const unsigned long long todo = wave_ballot(active);
-    if (todo == 0ull) {
-        return 0;
-    }
-    const int leader = __ffsll((long long)todo) - 1;
-    const int leader_bin = __builtin_amdgcn_readlane(bin, leader);
-    const bool with_leader = active && bin == leader_bin;
-    const unsigned long long same = wave_ballot(with_leader);
-    int base = 0;
-    if ((int)(threadIdx.x & 63) == leader) {
-        base = atomicAdd(&bins[leader_bin], __popcll(same));
-    }
-    base = __builtin_amdgcn_readlane(base, leader);
-    if (with_leader) {
-        slot = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
-    } else if (active) {
-        slot = atomicAdd(&bins[bin], 1);
-    }
-    return slot;
-}
 
 // Counting only (nothing returns, so nothing waits): ONE LDS atomic for all the lanes that share the lowest active lane's bin, one
 // each for the rest.
@@ -1110,9 +1065,12 @@ __device__ __forceinline__ void wave_bin_count(int *bins, int bin, bool active) 
     }
 }
 
-// wave_bin_claim for U independent elements per lane with TWO waits instead of 2 U: the U leader atomics are issued back to back,
-// then the U atomics of the remaining lanes.  Slots stay unique (LDS atomics of a wave execute in order; other waves interleave
-// atomically); which of two equal-bin features gets the earlier slot is not defined, as before.
+// A slot in its bin for every active lane, for U independent elements per lane.  Per element one round of "the lowest active
+// lane's bin: ONE LDS atomic for all the lanes that share it" — iteration counts cluster, and a call whose features all took 5
+// iterations would otherwise serialise thousands of atomics on one address — then one atomic per remaining lane (counts spread
+// over many bins: little contention).  The U leader atomics are issued back to back, then the U atomics of the remaining lanes:
+// two waits instead of 2 U.  Slots are unique (LDS atomics of a wave execute in order; other waves interleave atomically); which
+// of two equal-bin features gets the earlier slot is not defined.
 template <int U>
 __device__ __forceinline__ void wave_bin_claim_batch(int *bins, const int (&bin)[U], const bool (&active)[U], int (&slot)[U]) {
     const int lane = (int)(threadIdx.x & 63);
