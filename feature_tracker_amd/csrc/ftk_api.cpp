@@ -748,9 +748,6 @@ int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image,
         return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_update: only pyramids that own their level 0 (ftk_pyramid_upload, ftk_pyramid_build of a host image) can be refilled");
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t bytes0 = (size_t)pyr->levels[0].rows * pyr->levels[0].cols;
-    FTK_HIP(ctx, hipMemcpyAsync(pyr->owned, image, bytes0, image_location == FTK_IMAGE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                ctx->stream));
     uint8_t *level_ptr[FTK_MAX_LEVELS] = {nullptr};
     bool halves = true;  // every level is the floor-half of the one above it (true for every pyramid this library builds)
     for (int i = 1; i < pyr->n_levels; ++i) {
@@ -760,7 +757,27 @@ int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image,
     if (!halves) {
         return fail(ctx, FTK_E_UNSUPPORTED, "pyramid_update: the levels of this pyramid are not successive halves (uploaded with another geometry)");
     }
-    FTK_HIP(ctx, ftk::pyramid_build_levels_launch(pyr->levels[0].data, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream));
+    // A frame in PINNED host memory (FTK_IMAGE_HOST_ASYNC) is read by the pyramid launch itself when the device can address it:
+    // the copy engine takes ~20 us per 300 KB frame, the kernel's own PCIe read a third of that, and a launch gap goes with it.
+    // FTK_PYRAMID_ZEROCOPY=0 keeps the copy (experiment switch); pageable or unmapped memory takes it anyway.
+    const uint8_t *direct_src = nullptr;
+    static const bool zero_copy_allowed = !(getenv("FTK_PYRAMID_ZEROCOPY") && atoi(getenv("FTK_PYRAMID_ZEROCOPY")) == 0);
+    if (image_location == FTK_IMAGE_HOST_ASYNC && zero_copy_allowed && pyr->n_levels >= 2 && ftk::pyramid_fused_enabled()) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, image) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr) {
+            direct_src = static_cast<const uint8_t *>(attr.devicePointer);
+        } else {
+            (void)hipGetLastError();  // not an error of this call: the copy path below serves the pointer
+        }
+    }
+    if (direct_src != nullptr) {
+        FTK_HIP(ctx, ftk::pyramid_build_levels_launch(direct_src, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream, pyr->owned));
+    } else {
+        const size_t bytes0 = (size_t)pyr->levels[0].rows * pyr->levels[0].cols;
+        FTK_HIP(ctx, hipMemcpyAsync(pyr->owned, image, bytes0, image_location == FTK_IMAGE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                    ctx->stream));
+        FTK_HIP(ctx, ftk::pyramid_build_levels_launch(pyr->levels[0].data, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream));
+    }
     if (image_location == FTK_IMAGE_HOST) {
         FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller may release or rewrite the host image on return
     }

@@ -249,7 +249,11 @@ hipError_t unpack_klt_shards_launch(const uint8_t *d_gathered, int32_t n, int32_
                                     uint8_t *d_status_out, hipStream_t stream);
 hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32_t src_cols, uint8_t *dst, hipStream_t stream);
 // Levels 1 .. n_levels - 1 from level 0 (dst[l] = level l, l >= 1): one fused launch (pyramid_fused_kernel), deeper levels one by one.
-hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream);
+// level0_keep (needs pyramid_fused_enabled() and n_levels >= 2): `level0` is a device-visible source outside the pyramid (pinned host
+// memory) and the same launch stores it as the pyramid's level 0.
+hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream,
+                                       uint8_t *level0_keep = nullptr);
+bool pyramid_fused_enabled();
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);
 

@@ -72,7 +72,9 @@ constexpr int kTile = 64;
 constexpr int kFusedMaxLevels = 7;  // levels 1..6 below a 64 x 64 tile; deeper pyramids finish with the per-level kernel
 
 struct PyramidLevels {
-    uint8_t *dst[kFusedMaxLevels];  // [l]: level l (l >= 1); [0] unused
+    uint8_t *dst[kFusedMaxLevels];  // [l]: level l (l >= 1); [0]: null, or where to KEEP level 0 when `src` is not the pyramid's own
+                                    // level 0 — the frame read straight from pinned host memory (ftk_pyramid_update): the copy engine's
+                                    // ~20 us per 300 KB frame become one PCIe read inside this launch
     int32_t n_levels;               // levels to produce here incl. level 0: 2..kFusedMaxLevels
 };
 
@@ -99,6 +101,16 @@ __global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__
             }
         }
         *reinterpret_cast<uint4 *>(&tile[0][r * kTile + seg]) = v;
+        if (lv.dst[0] != nullptr && gr < rows && gc < cols) {
+            uint8_t *o = lv.dst[0] + (size_t)gr * (size_t)cols + (size_t)gc;
+            if (gc + 16 <= cols) {
+                __builtin_memcpy(o, &v, 16);  // unaligned 16-byte store
+            } else {
+                for (int i = 0; gc + i < cols; ++i) {
+                    o[i] = reinterpret_cast<const uint8_t *>(&v)[i];
+                }
+            }
+        }
     }
     __syncthreads();
     int lrows = rows, lcols = cols;
@@ -222,11 +234,22 @@ hipError_t pyramid_downsample_launch(const uint8_t *src, int32_t src_rows, int32
 
 // Levels 1 .. n_levels - 1 of a pyramid whose level 0 is `level0` (rows x cols): one fused launch for the first six, the
 // per-level kernel for anything deeper.  dst[l] / out_rows / out_cols describe level l (entries >= 1 are used).
-hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream) {
+bool pyramid_fused_enabled() {
+    static const bool fused = !(getenv("FTK_PYRAMID_FUSED") && atoi(getenv("FTK_PYRAMID_FUSED")) == 0);  // experiment switch
+    return fused;
+}
+
+// `level0_keep` (optional, fused launch only — pyramid_fused_enabled() and n_levels >= 2): `level0` is a source OUTSIDE the pyramid
+// (device-visible pinned host memory) and the launch also writes it to level0_keep, the pyramid's own level 0.
+hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int32_t cols, uint8_t *const *dst, int32_t n_levels, hipStream_t stream,
+                                       uint8_t *level0_keep) {
     if (n_levels <= 1) {
         return hipSuccess;
     }
-    static const bool fused = !(getenv("FTK_PYRAMID_FUSED") && atoi(getenv("FTK_PYRAMID_FUSED")) == 0);  // experiment switch
+    const bool fused = pyramid_fused_enabled();
+    if (level0_keep != nullptr && !fused) {
+        return hipErrorInvalidValue;
+    }
     int done = 1;  // levels that exist so far
     if (fused) {
         PyramidLevels lv;
@@ -234,6 +257,7 @@ hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int3
         for (int l = 0; l < kFusedMaxLevels; ++l) {
             lv.dst[l] = (l >= 1 && l < lv.n_levels) ? dst[l] : nullptr;
         }
+        lv.dst[0] = level0_keep;
         const dim3 grid((unsigned)((cols + kTile - 1) / kTile), (unsigned)((rows + kTile - 1) / kTile));
         hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(kBlock), 0, stream, level0, rows, cols, lv);
         hipError_t e = hipGetLastError();
@@ -243,7 +267,7 @@ hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int3
         done = lv.n_levels;
     }
     for (int l = done; l < n_levels; ++l) {
-        const hipError_t e = pyramid_downsample_launch(l == 1 ? level0 : dst[l - 1], rows >> (l - 1), cols >> (l - 1), dst[l], stream);
+        const hipError_t e = pyramid_downsample_launch(l == 1 ? (level0_keep ? level0_keep : level0) : dst[l - 1], rows >> (l - 1), cols >> (l - 1), dst[l], stream);
         if (e != hipSuccess) {
             return e;
         }

@@ -262,9 +262,13 @@ def test_pyramid_update_refills_an_existing_pyramid(ftk, oracle):
     for i in range(levels):
         assert np.array_equal(pyr.download_level(i), ref_a[i]), i
     pinned = torch.from_numpy(img_b.copy()).pin_memory()
-    pyr.update(pinned.data_ptr(), "host_async")
+    pyr.update(pinned.data_ptr(), "host_async")  # device-visible pinned memory: read by the pyramid launch itself, no copy
     for i in range(levels):  # download_level synchronises the context's stream
         assert np.array_equal(pyr.download_level(i), ref_b[i]), i
+    pageable = np.ascontiguousarray(img_a.copy())
+    pyr.update(int(pageable.ctypes.data), "host_async")  # not pinned: served by the copy path
+    for i in range(levels):
+        assert np.array_equal(pyr.download_level(i), ref_a[i]), i
     # an uploaded pyramid owns its level 0 too; a wrapped / device-borrowed one does not
     up = ftk.ImagePyramid.from_host_levels(ref_a)
     up.update(img_b)
