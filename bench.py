@@ -164,7 +164,7 @@ def with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur
         lat.append(time.perf_counter() - t1)
     return {"value": n * steps / elapsed, "unit": "tracked features/s", "ms_per_call": elapsed / steps * 1e3, "calls_timed": steps,
             "ms_per_call_synchronised": float(np.median(lat)) * 1e3,
-            "includes": f"H2D of two {ref_img.shape[1]}x{ref_img.shape[0]} frames from pinned host memory + device 2x2 downsample of levels 1..{levels - 1} "
+            "includes": f"two {ref_img.shape[1]}x{ref_img.shape[0]} frames in pinned host memory, read over PCIe by the pyramid launches themselves (no copy-engine transfer) + device 2x2 downsample of levels 1..{levels - 1} "
                         "of both pyramids (ftk_pyramid_update) + the tracker launch; inputs are NOT resident when the region starts",
             "result_uv": out_views[0], "result_st": out_views[1]}
 
