@@ -143,7 +143,7 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
  * buffer is free again on return), FTK_IMAGE_DEVICE (device memory, stream-ordered), FTK_IMAGE_HOST_ASYNC (PINNED host memory
  * that stays valid and unchanged until the stream has passed this call; no synchronisation — when the device can address the
  * buffer (hipHostMalloc / hipHostRegister memory) the pyramid launch reads the frame itself over PCIe, without a copy-engine
- * transfer first; otherwise it is copied as with FTK_IMAGE_HOST).  Only pyramids that own their level 0 (ftk_pyramid_upload,
+ * transfer first; otherwise it is copied as with FTK_IMAGE_HOST, stream-ordered).  Only pyramids that own their level 0 (ftk_pyramid_upload,
  * ftk_pyramid_build of a host image) can be refilled. */
 enum { FTK_IMAGE_HOST = 0, FTK_IMAGE_DEVICE = 1, FTK_IMAGE_HOST_ASYNC = 2 };
 int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image, int image_location);
