@@ -69,6 +69,41 @@ int ensure_pinned(ftk_context *ctx, size_t bytes) {
     return FTK_OK;
 }
 
+// The next image-staging slot, free and at least `bytes` large (ftk_internal.h ImageStage); *out stays null when the device cannot
+// address pinned host memory (the callers then take their copy paths).
+int acquire_image_stage(ftk_context *ctx, size_t bytes, ftk_context::ImageStage **out) {
+    *out = nullptr;
+    ftk_context::ImageStage &st = ctx->image_stage[ctx->image_stage_next];
+    if (st.busy) {
+        FTK_HIP(ctx, hipEventSynchronize(st.done));  // normally long past: two frames per tracker call
+        st.busy = false;
+    }
+    if (st.bytes < bytes) {
+        if (st.host) {
+            FTK_HIP(ctx, hipHostFree(st.host));
+            st.host = nullptr;
+            st.bytes = 0;
+        }
+        const size_t want = align_up(bytes, 1u << 20);
+        void *h = nullptr, *d = nullptr;
+        FTK_HIP(ctx, hipHostMalloc(&h, want, hipHostMallocDefault));
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || d == nullptr) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            return FTK_OK;  // *out == nullptr
+        }
+        st.host = static_cast<uint8_t *>(h);
+        st.device_view = static_cast<const uint8_t *>(d);
+        st.bytes = want;
+    }
+    if (!st.done) {
+        FTK_HIP(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    }
+    ctx->image_stage_next ^= 1;
+    *out = &st;
+    return FTK_OK;
+}
+
 int ensure_match_keys(ftk_context *ctx, size_t count) {
     if (count <= ctx->match_keys_count) {
         return FTK_OK;
@@ -412,6 +447,14 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
     }
+    for (auto &st : ctx->image_stage) {
+        if (st.done) {
+            (void)hipEventDestroy(st.done);
+        }
+        if (st.host) {
+            (void)hipHostFree(st.host);
+        }
+    }
     if (ctx->pinned) {
         (void)hipHostFree(ctx->pinned);
     }
@@ -465,6 +508,11 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
         int rc = ensure_scratch(ctx, 4u << 20);
         if (rc == FTK_OK) {
             rc = ensure_pinned(ctx, 4u << 20);
+        }
+        // ... and the two pinned slots host images pass through on their way into a pyramid (1 MB each: up to 1024 x 1024)
+        for (int k = 0; k < 2 && rc == FTK_OK; ++k) {
+            ftk_context::ImageStage *stage = nullptr;
+            rc = acquire_image_stage(ctx, 1u << 20, &stage);
         }
         if (rc != FTK_OK) {
             return rc;
@@ -703,10 +751,27 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
     }
     pyr->n_levels = n_levels;
     hipError_t e = hipSuccess;
+    // A host image goes through a pinned staging slot: the CPU copies it there (the caller's buffer is free on return), the
+    // pyramid launch reads the slot over PCIe and keeps level 0 — no staged hipMemcpy of pageable memory, no stream
+    // synchronisation (CreateImagePyramid x 2 sits inside the reference's timed region, test_optical_flow.cpp:69-73: 57 us per
+    // build before).  One-level pyramids and FTK_PYRAMID_ZEROCOPY=0 / FTK_PYRAMID_FUSED=0 keep the copy.
+    ftk_context::ImageStage *stage = nullptr;
+    static const bool stage_allowed = !(getenv("FTK_PYRAMID_ZEROCOPY") && atoi(getenv("FTK_PYRAMID_ZEROCOPY")) == 0);
+    if (!image_on_device && stage_allowed && n_levels >= 2 && ftk::pyramid_fused_enabled()) {
+        rc = acquire_image_stage(ctx, (size_t)rows * cols, &stage);
+        if (rc != FTK_OK) {
+            ftk_pyramid_destroy(pyr);
+            return rc;
+        }
+    }
     if (image_on_device) {
         pyr->levels[0].data = image;
     } else {
-        e = hipMemcpyAsync(pyr->owned, image, (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream);
+        if (stage) {
+            memcpy(stage->host, image, (size_t)rows * cols);
+        } else {
+            e = hipMemcpyAsync(pyr->owned, image, (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream);
+        }
         pyr->levels[0].data = pyr->owned;
     }
     pyr->levels[0].rows = rows;
@@ -719,9 +784,17 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
         pyr->levels[i].cols = lcols[i];
     }
     if (e == hipSuccess) {
-        e = ftk::pyramid_build_levels_launch(pyr->levels[0].data, rows, cols, level_ptr, n_levels, ctx->stream);  // one launch for all levels
+        if (stage) {
+            e = ftk::pyramid_build_levels_launch(stage->device_view, rows, cols, level_ptr, n_levels, ctx->stream, pyr->owned);
+            if (e == hipSuccess) {
+                e = hipEventRecord(stage->done, ctx->stream);
+                stage->busy = e == hipSuccess;
+            }
+        } else {
+            e = ftk::pyramid_build_levels_launch(pyr->levels[0].data, rows, cols, level_ptr, n_levels, ctx->stream);  // one launch for all levels
+        }
     }
-    if (e == hipSuccess && !image_on_device) {
+    if (e == hipSuccess && !image_on_device && !stage) {
         e = hipStreamSynchronize(ctx->stream);  // host image may be released by the caller
     }
     if (e != hipSuccess) {
@@ -769,6 +842,21 @@ int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image,
         } else {
             (void)hipGetLastError();  // not an error of this call: the copy path below serves the pointer
         }
+    }
+    ftk_context::ImageStage *stage = nullptr;
+    if (image_location == FTK_IMAGE_HOST && zero_copy_allowed && pyr->n_levels >= 2 && ftk::pyramid_fused_enabled()) {
+        // a pageable frame: CPU copy into a pinned slot (the caller's buffer is free on return), read by the launch; no synchronisation
+        const int rc = acquire_image_stage(ctx, (size_t)pyr->levels[0].rows * pyr->levels[0].cols, &stage);
+        if (rc != FTK_OK) {
+            return rc;
+        }
+    }
+    if (stage != nullptr) {
+        memcpy(stage->host, image, (size_t)pyr->levels[0].rows * pyr->levels[0].cols);
+        FTK_HIP(ctx, ftk::pyramid_build_levels_launch(stage->device_view, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream, pyr->owned));
+        FTK_HIP(ctx, hipEventRecord(stage->done, ctx->stream));
+        stage->busy = true;
+        return FTK_OK;
     }
     if (direct_src != nullptr) {
         FTK_HIP(ctx, ftk::pyramid_build_levels_launch(direct_src, pyr->levels[0].rows, pyr->levels[0].cols, level_ptr, pyr->n_levels, ctx->stream, pyr->owned));

@@ -57,6 +57,17 @@ struct ftk_context {
     int32_t brief_bits = 0, brief_half = 0;
     // FTK_REDUCTION_EXACT (default) or FTK_REDUCTION_TREE: how the trackers' normal-equation sums are formed (ftk_set_reduction_mode)
     int32_t reduction = 0;
+    // Two pinned, device-visible slots through which host images reach the pyramid launches (ftk_pyramid_build / _update of a
+    // pageable image: a CPU copy into the slot, then the launch reads the slot over PCIe — no staged hipMemcpy, no stream
+    // synchronisation; a slot is reused only after the event recorded behind its last reader has passed)
+    struct ImageStage {
+        uint8_t *host = nullptr;
+        const uint8_t *device_view = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } image_stage[2];
+    int image_stage_next = 0;
 };
 
 struct ftk_pyramid {
