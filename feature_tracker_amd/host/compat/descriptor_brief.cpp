@@ -4,6 +4,7 @@
 
 #include <string>
 
+#include "bit_words.h"
 #include "device_runtime.h"
 #include "ftk.h"
 #include "slam_log_reporter.h"
@@ -39,14 +40,9 @@ bool BriefDescriptor::Compute(const GrayImage &image, const std::vector<Vec2> &p
         ReportError("[BriefDescriptor] " << ftk_last_error(ctx));
         return false;
     }
-    descriptor.reserve(pixel_uv.size());
+    descriptor.resize(pixel_uv.size());
     for (int32_t f = 0; f < n; ++f) {
-        BriefType bits(static_cast<size_t>(options_.kLength), false);
-        const uint32_t *w = &words[static_cast<size_t>(f) * n_words];
-        for (int32_t i = 0; i < options_.kLength; ++i) {
-            bits[i] = ((w[i >> 5] >> (i & 31)) & 1u) != 0;
-        }
-        descriptor.emplace_back(std::move(bits));
+        feature_tracker::bit_words::Unpack(&words[static_cast<size_t>(f) * n_words], static_cast<size_t>(options_.kLength), descriptor[f]);
     }
     return true;
 }

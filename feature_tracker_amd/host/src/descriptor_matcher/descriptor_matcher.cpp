@@ -8,6 +8,7 @@
 
 #include <string>
 
+#include "bit_words.h"
 #include "device_runtime.h"
 #include "ftk.h"
 #include "slam_log_reporter.h"
@@ -22,6 +23,20 @@ float HammingDistance(const std::vector<bool> &a, const std::vector<bool> &b) {
         return static_cast<float>(kMaxInt32);
     }
     int32_t distance = 0;
+#if FTK_BIT_WORDS_FAST
+    if (a.size() == b.size()) {  // whole words of the two containers: xor + popcount (the padding bits of the last word masked out)
+        const unsigned long *pa = a.begin()._M_p, *pb = b.begin()._M_p;
+        constexpr size_t kWordBits = 8 * sizeof(unsigned long);
+        const size_t full = a.size() / kWordBits, tail = a.size() % kWordBits;
+        for (size_t w = 0; w < full; ++w) {
+            distance += __builtin_popcountl(pa[w] ^ pb[w]);
+        }
+        if (tail) {
+            distance += __builtin_popcountl((pa[full] ^ pb[full]) & ((1ul << tail) - 1ul));
+        }
+        return static_cast<float>(distance);
+    }
+#endif
     for (size_t i = 0; i < a.size(); ++i) {
         distance += (a[i] != b[i]) ? 1 : 0;
     }
@@ -30,15 +45,10 @@ float HammingDistance(const std::vector<bool> &a, const std::vector<bool> &b) {
 
 namespace {
 void PackBits(const std::vector<std::vector<bool>> &descriptors, int32_t n_words, std::vector<uint32_t> &words) {
-    words.assign(descriptors.size() * static_cast<size_t>(n_words), 0u);
+    words.resize(descriptors.size() * static_cast<size_t>(n_words));
     for (size_t i = 0; i < descriptors.size(); ++i) {
-        uint32_t *out = &words[i * n_words];
-        const std::vector<bool> &d = descriptors[i];
-        for (size_t b = 0; b < d.size(); ++b) {
-            if (d[b]) {
-                out[b >> 5] |= 1u << (b & 31);
-            }
-        }
+        // a descriptor longer than the first one's n_words cannot occur here (the caller's length check), a shorter one is zero padded
+        bit_words::Pack(descriptors[i], &words[i * n_words], static_cast<size_t>(n_words));
     }
 }
 }  // namespace
