@@ -545,3 +545,26 @@ def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle
         pts = uv[order[slots]]
         areas.append(pts[:, 0].std() * pts[:, 1].std())
     assert np.median(areas) < 0.25 * area_all, (np.median(areas), area_all)
+
+
+def test_host_images_reach_the_pyramid_launch_through_the_pinned_slots(ftk, oracle):
+    """ftk_pyramid_build / ftk_pyramid_update of a PAGEABLE host image: a CPU copy into one of two pinned slots, read by the pyramid
+    launch, no synchronisation.  Back-to-back builds (a slot is reused by the third: its event gates the copy), growing and
+    shrinking images (the slots are reallocated), buffers overwritten right after the call returns — every level == the oracle's."""
+    rs = np.random.RandomState(7)
+    pyramids, expected = [], []
+    for (h, w, levels) in ((120, 160, 3), (1080, 1920, 4), (97, 131, 2), (1200, 1600, 5), (64, 64, 2), (480, 752, 4)):
+        img = rs.randint(0, 256, size=(h, w), dtype=np.uint8)
+        expected.append(oracle.create_pyramid(img.copy(), levels))  # (the oracle's level 0 is a view of its argument)
+        pyramids.append(ftk.ImagePyramid.build(img, levels))
+        img[:] = 0  # the caller's buffer is free as soon as the call returns
+    for pyr, exp in zip(pyramids, expected):
+        for i, level in enumerate(exp):
+            assert np.array_equal(pyr.download_level(i), level), (level.shape, i)
+    # the synchronous update entry takes the same route
+    img = rs.randint(0, 256, size=(480, 752), dtype=np.uint8)
+    exp = oracle.create_pyramid(img.copy(), 4)
+    pyramids[-1].update(img)
+    img[:] = 255
+    for i, level in enumerate(exp):
+        assert np.array_equal(pyramids[-1].download_level(i), level), i
