@@ -8,6 +8,8 @@
 //    exposed because the reference makes it a public method; one wave per call.
 #include "ftk_device.h"
 
+#include <string.h>
+
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -78,13 +80,19 @@ struct PyramidLevels {
     int32_t n_levels;               // levels to produce here incl. level 0: 2..kFusedMaxLevels
 };
 
+// TW x TH: the level-0 tile of a workgroup, 4096 pixels either way.  64 x 64 serves up to seven levels; 256 x 16 serves up to five
+// (16 = 2^4) and reads level 0 in 256-byte row pieces instead of 64-byte ones — what matters when the source is pinned HOST
+// memory and every piece is a PCIe read (ftk_pyramid_update / ftk_pyramid_build of host images).
+template <int TW, int TH>
 __global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__restrict__ src, int rows, int cols, PyramidLevels lv) {
-    __shared__ uint8_t tile[2][kTile * kTile];  // ping-pong: level l in tile[l & 1], pitch kTile >> l
+    static_assert(TW * TH == kTile * kTile && TW % 16 == 0, "4096-pixel tiles, rows loaded 16 bytes per lane");
+    __shared__ uint8_t tile[2][TW * TH];  // ping-pong: level l in tile[l & 1], pitch TW >> l
     const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
-    const int r0 = ty * kTile, c0 = tx * kTile;
-    // level 0 -> LDS: 256 threads x 16 bytes per pass, rows of 64 bytes; pixels beyond the image are never read by a valid output
-    for (int k = tid; k < kTile * kTile / 16; k += kBlock) {
-        const int r = k >> 2, seg = (k & 3) << 4;
+    const int r0 = ty * TH, c0 = tx * TW;
+    constexpr int kSegs = TW / 16;  // 16-byte pieces per tile row
+    // level 0 -> LDS: 256 threads x 16 bytes per pass; pixels beyond the image are never read by a valid output
+    for (int k = tid; k < TW * TH / 16; k += kBlock) {
+        const int r = k / kSegs, seg = (k % kSegs) << 4;
         const int gr = r0 + r, gc = c0 + seg;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (gr < rows) {
@@ -100,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__
                 __builtin_memcpy(&v, tmp, 16);
             }
         }
-        *reinterpret_cast<uint4 *>(&tile[0][r * kTile + seg]) = v;
+        *reinterpret_cast<uint4 *>(&tile[0][r * TW + seg]) = v;
         if (lv.dst[0] != nullptr && gr < rows && gc < cols) {
             uint8_t *o = lv.dst[0] + (size_t)gr * (size_t)cols + (size_t)gc;
             if (gc + 16 <= cols) {
@@ -117,14 +125,14 @@ __global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__
     for (int l = 1; l < lv.n_levels; ++l) {
         lrows >>= 1;
         lcols >>= 1;
-        const int side = kTile >> l, prev_pitch = kTile >> (l - 1);
+        const int w = TW >> l, h = TH >> l, prev_pitch = TW >> (l - 1);
         const uint8_t *in = tile[(l - 1) & 1];
         uint8_t *out = tile[l & 1];
         const int lr0 = r0 >> l, lc0 = c0 >> l;
         uint8_t *g = lv.dst[l];
         // four horizontally adjacent outputs per thread where the level is wide enough: one 32-bit store
-        const int quads = side >= 4 ? side >> 2 : 1, per = side >= 4 ? 4 : side;
-        for (int k = tid; k < side * quads; k += kBlock) {
+        const int quads = w >= 4 ? w >> 2 : 1, per = w >= 4 ? 4 : w;
+        for (int k = tid; k < h * quads; k += kBlock) {
             const int r = k / quads, q = (k - r * quads) * per;
             uint32_t packed = 0;
 #pragma unroll 4
@@ -132,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_fused_kernel(const uint8_t *__
                 const uint8_t *t = in + (2 * r) * prev_pitch + 2 * (q + i);
                 const uint32_t sum = (uint32_t)t[0] + t[1] + t[prev_pitch] + t[prev_pitch + 1];
                 const uint32_t m = sum >> 2;
-                out[r * side + q + i] = (uint8_t)m;
+                out[r * w + q + i] = (uint8_t)m;
                 packed |= m << (8 * i);
             }
             const int gr = lr0 + r, gc = lc0 + q;
@@ -258,8 +266,18 @@ hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int3
             lv.dst[l] = (l >= 1 && l < lv.n_levels) ? dst[l] : nullptr;
         }
         lv.dst[0] = level0_keep;
-        const dim3 grid((unsigned)((cols + kTile - 1) / kTile), (unsigned)((rows + kTile - 1) / kTile));
-        hipLaunchKernelGGL(pyramid_fused_kernel, grid, dim3(kBlock), 0, stream, level0, rows, cols, lv);
+        // wide tiles (256-byte row pieces) for a source in host memory, when five levels are enough for them (16 rows = 2^4);
+        // FTK_PYRAMID_TILE=wide|square forces one (experiment switch)
+        static const char *tile_env = getenv("FTK_PYRAMID_TILE");
+        const bool wide_ok = lv.n_levels <= 5;
+        const bool wide = wide_ok && (tile_env ? !strcmp(tile_env, "wide") : level0_keep != nullptr);
+        if (wide) {
+            const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 15) / 16));
+            hipLaunchKernelGGL((pyramid_fused_kernel<256, 16>), grid, dim3(kBlock), 0, stream, level0, rows, cols, lv);
+        } else {
+            const dim3 grid((unsigned)((cols + kTile - 1) / kTile), (unsigned)((rows + kTile - 1) / kTile));
+            hipLaunchKernelGGL((pyramid_fused_kernel<kTile, kTile>), grid, dim3(kBlock), 0, stream, level0, rows, cols, lv);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             return e;
