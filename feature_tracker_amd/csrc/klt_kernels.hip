@@ -1723,6 +1723,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     }
     Carve c = carve_lds(lds_mine, K, p);
     if (MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) {
+        c.a0 = c.terms;  // the level setup's axis tables share the head of the product groups (a0_floats == 0: ftk_api.cpp)
         // grouped layout (affine_all_terms): the pixels behind the patch up to the end of the last round of groups, all 24 sums
         const int first = p.P, end = affine_group_rounds(p.Ppad) * (4 * kChainRound);
         for (int idx = b.tid; idx < A_COUNT * (end - first); idx += b.nt) {
