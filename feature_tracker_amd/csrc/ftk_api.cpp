@@ -121,6 +121,7 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
 }
 
 constexpr uint32_t kSchedMinFeatures = 4096;  // below this every feature is resident from the start: nothing to order
+constexpr size_t kSchedTableWords = (2u << 16) + 2;  // two position tables of 2^16 entries (klt_common.h kSchedTableSize) + the two "no tail" flags behind them
 constexpr int32_t kSchedMaxFeatures = 1 << 18;  // the sort block walks the list alone; beyond this it could outlast the launch
 
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
@@ -450,6 +451,12 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
+    }
+    if (ctx->sched_grid) {
+        (void)hipFree(ctx->sched_grid);
+    }
+    if (ctx->sched_claim) {
+        (void)hipFree(ctx->sched_claim);
     }
     for (auto &st : ctx->image_stage) {
         if (st.done) {
@@ -968,9 +975,20 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                         ctx->sched_order[k] = nullptr;
                     }
                 }
+                if (ctx->sched_claim) {
+                    (void)hipFree(ctx->sched_claim);
+                    ctx->sched_claim = nullptr;
+                }
                 ctx->sched_capacity = 0;
                 ctx->sched_n = 0;
                 const size_t cap = ((size_t)n + 4095) / 4096 * 4096;
+                // position-keyed slot swaps: a claim word per launch slot, and (once) the two tables of iteration counts by position
+                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_claim), sizeof(uint32_t) * cap));
+                FTK_HIP(ctx, hipMemsetAsync(ctx->sched_claim, 0, sizeof(uint32_t) * cap, ctx->stream));
+                if (!ctx->sched_grid) {
+                    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_grid), sizeof(uint32_t) * kSchedTableWords));
+                    FTK_HIP(ctx, hipMemsetAsync(ctx->sched_grid, 0, sizeof(uint32_t) * kSchedTableWords, ctx->stream));
+                }
                 for (int k = 0; k < 2; ++k) {
                     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_iters[k]), sizeof(uint32_t) * cap));
                     FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_order[k]), sizeof(int32_t) * cap));
@@ -985,6 +1003,40 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                 ctx->sched_calls = 0;
             }
             const uint32_t k = ctx->sched_calls++;
+            // Position-keyed swaps ride on every such call, whatever the list did since the last one (FTK_KLT_SWAP=0: off).  Call
+            // numbers start at 4 (an all-zero grid / claim word is never "recent") and tag 23 bits of a claim word: the claims are
+            // wiped before a tag could repeat.
+            static const bool swap_allowed = !(getenv("FTK_KLT_SWAP") && atoi(getenv("FTK_KLT_SWAP")) == 0);
+            // (never inside a stream capture: a replayed launch would carry this call's number again and read its own old claims)
+            hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) {
+                (void)hipGetLastError();
+                capture = hipStreamCaptureStatusActive;  // unknown: be safe
+            }
+            // (nor when the results overwrite the reference positions: both sides of a trade must read the same positions)
+            const char *ref_lo = reinterpret_cast<const char *>(p.ref_uv), *out_lo = reinterpret_cast<const char *>(p.cur_uv_out);
+            const size_t uv_span = sizeof(float) * 2 * (size_t)n;
+            const bool ref_untouched = ref_lo + uv_span <= out_lo || out_lo + uv_span <= ref_lo;
+            // Multi-wave features only: there a feature is tens of microseconds long and iteration counts have heavy tails
+            // (config 3: 192 / 207 -> 149 / 166 us with no / a stale launch order, +0.5 % with a fitting one); the one-wave kernels
+            // run 10 000 - 25 000 cheap features, every late one of which would pay a table look-up for a 3 % gain at best
+            // (config 4: +2.9 % with a fitting order, -3 % without; config 5: +1 %).
+            if (swap_allowed && p.waves_per_feature >= 2 && ref_untouched && capture == hipStreamCaptureStatusNone && ctx->sched_grid && ctx->sched_claim &&
+                n > 1024 + 512) {
+                if (ctx->sched_call < 4u) {
+                    ctx->sched_call = 4u;
+                }
+                ++ctx->sched_call;
+                if ((ctx->sched_call & 0x7FFFFFu) < 4u) {
+                    FTK_HIP(ctx, hipMemsetAsync(ctx->sched_claim, 0, sizeof(uint32_t) * ctx->sched_capacity, ctx->stream));
+                    FTK_HIP(ctx, hipMemsetAsync(ctx->sched_grid, 0, sizeof(uint32_t) * kSchedTableWords, ctx->stream));
+                    ctx->sched_call += 4u;
+                }
+                p.sched_grid = ctx->sched_grid;
+                p.sched_flags = ctx->sched_grid + (2u << 16);
+                p.sched_claim = ctx->sched_claim;
+                p.sched_call = ctx->sched_call;
+            }
             p.sched_iters = ctx->sched_iters[k & 1];          // this call's counts
             if (k >= 1) {                                     // sort the previous call's counts beside this call's features
                 p.sort_iters = ctx->sched_iters[(k - 1) & 1];
@@ -992,6 +1044,24 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             }
             if (k >= 2) {                                     // made during the previous call from the counts before it
                 p.order = ctx->sched_order[k & 1];
+            }
+            if (const char *dump = getenv("FTK_KLT_SWAP_DUMP")) {  // diagnostic: how many trades the PREVIOUS launch of this context made
+                if (p.sched_claim != nullptr && ctx->sched_call > 5u) {
+                    std::vector<uint32_t> h((size_t)n);
+                    FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_claim, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+                    FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    const uint32_t last = (ctx->sched_call - 1u) & 0x7FFFFFu;
+                    size_t trades = 0, own = 0;
+                    for (uint32_t w : h) {
+                        if ((w >> 9) == last) {
+                            ((w & 0x1FFu) == 0x1FFu ? own : trades) += 1;
+                        }
+                    }
+                    if (FILE *f = fopen(dump, "w")) {
+                        fprintf(f, "%zu %zu\n", trades, own);
+                        fclose(f);
+                    }
+                }
             }
             if (const char *dump = getenv("FTK_KLT_SCHED_DUMP")) {  // diagnostic: the permutation in use and the counts it came from
                 if (k >= 2) {

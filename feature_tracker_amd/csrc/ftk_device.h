@@ -34,6 +34,12 @@ struct KltParams {
     uint32_t *iters;       // may be null
     const int32_t *order;  // may be null: launch slot -> feature index (a permutation of [0, n) made by an earlier launch's sort block)
     uint32_t *sched_iters; // may be null: iteration counts kept by the context for the launch order of later calls
+    // Position-keyed slot swaps (klt_common.h klt_resolve_feature), all null / 0 when off: a coarse grid over the level-0 image in
+    // which every feature leaves its iteration count, tagged with the call number; one claim word per launch slot; this call's number
+    uint32_t *sched_grid;
+    uint32_t *sched_claim;
+    uint32_t *sched_flags;  // [2]: (call number << 1 | "the counts that call sorted had no tail"), written by the sort block of a launch
+    uint32_t sched_call;
     const uint32_t *sort_iters;  // may be null: the previous call's counts; one extra workgroup (block 0) sorts them ...
     int32_t *sort_order_out;     // ... into this permutation, longest first (klt_common.h, klt_order_block)
     int32_t n;             // features in the buffers

@@ -44,6 +44,10 @@ struct ftk_context {
     // sort block of the tracker launches makes from them, double-buffered
     uint32_t *sched_iters[2] = {nullptr, nullptr};
     int32_t *sched_order[2] = {nullptr, nullptr};
+    // position-keyed slot swaps (klt_common.h sched_resolve_slot): iteration counts by position (two hash tables), one claim word per launch slot
+    uint32_t *sched_grid = nullptr;
+    uint32_t *sched_claim = nullptr;
+    uint32_t sched_call = 0;     // calls that used the grid so far (tags its entries and the claims)
     size_t sched_capacity = 0;   // features each buffer holds
     int32_t sched_n = 0;         // feature count of the calls counted in sched_calls
     uint32_t sched_calls = 0;    // consecutive calls with that feature count so far

@@ -378,7 +378,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     uint32_t block = blockIdx.x;
     if (p.sort_iters) {
         if (block == 0) {
-            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1);
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
+                            p.sched_flags, p.sched_call);
             return;
         }
         block -= 1;
@@ -408,6 +409,25 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         return;
     }
     const bool younger = 2u * id >= (uint32_t)p.n;  // launch slot in the later-dispatched half (set_level_priority)
+    if (p.sched_claim != nullptr) {
+        // a trade of places between an early slot and a late one whose POSITION predicts many iterations (klt_common.h
+        // sched_resolve_slot; one wave decides for the workgroup)
+        bool swapped_in = false;
+        if (SOLO) {
+            id = sched_resolve_slot(p, id, swapped_in);
+        } else {
+            uint32_t *const shared = reinterpret_cast<uint32_t *>(lds_raw);
+            if (b.wave == 0) {
+                const uint32_t r = sched_resolve_slot(p, id, swapped_in);
+                if (b.lane == 0) {
+                    shared[0] = r;
+                }
+            }
+            __syncthreads();
+            id = shared[0];
+            __syncthreads();  // the word belongs to the carve below
+        }
+    }
     if (p.order) {
         id = (uint32_t)p.order[id];  // launch slot -> feature: longest first by the previous call's iteration counts
     }
@@ -749,6 +769,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (p.iters) {
             p.iters[id] = iters;
         }
+        sched_grid_record(p, full_ref_u, full_ref_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }

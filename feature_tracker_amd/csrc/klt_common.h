@@ -1040,6 +1040,113 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// Position-keyed slot swaps.  The launch order above is a permutation of LIST INDICES made during an earlier call: a caller whose
+// feature list changes between frames (features re-detected, reshuffled) gets an arbitrary order, and a feature that needs dozens
+// of iterations starts wherever it happens to sit — the launch then ends that much later (config 3: 146 us with a fitting order,
+// 208 with a stale one).  Iteration counts are therefore ALSO remembered by POSITION: every tracked feature leaves
+// (call number, count) in a hash table keyed by its level-0 position (atomicMax: the newest call wins, then the largest count;
+// one table is written by this call while the other, last call's, is only read).  At the start of a launch the first kSchedHeadSlots slots — resident from the first microsecond — each look through
+// their share of the LATE slots (>= kSchedLateSlot: the ones that may have to wait for a free CU), pick the one whose position
+// predicts the most iterations, and, if that is kSchedSwapMargin more than their own feature's prediction, trade places with
+// it: the head runs the long feature now, the late slot runs the head's feature when its turn comes.  A claim word per late
+// slot, taken with a compare-and-swap by whichever of the two gets there first, guarantees that every feature is processed
+// exactly once whatever the timing; nobody waits for anybody.  Which slot runs a feature changes nothing in its arithmetic.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSchedTableBits = 16;
+constexpr int kSchedTableSize = 1 << kSchedTableBits;  // entries per table; two tables (written by this call / read from the last)
+constexpr int kSchedHeadFirst = 256;   // the heads are the slots [kSchedHeadFirst, kSchedHeadFirst + kSchedHeadSlots): resident from the
+constexpr int kSchedHeadSlots = 256;   // first microsecond, but NOT the very first ones — with a fitting launch order those hold the
+constexpr int kSchedLateSlot = 1024;   // longest features, which must not start a scan's 2 - 3 us later
+constexpr uint32_t kSchedLongCount = 12;   // a late slot is a candidate from this predicted count on ...
+constexpr uint32_t kSchedSwapMargin = 8;   // ... and a head trades with it if that is this much above its own feature's prediction
+constexpr uint32_t kSchedSelf = 0x1FFu;    // claim code "the slot runs its own feature"; 0 .. kSchedHeadSlots - 1: the head (by number) it trades with
+
+// positions are remembered at 4-pixel resolution (a feature that crosses such a boundary between two frames is simply not predicted)
+__device__ __forceinline__ uint32_t sched_table_slot(float u, float v) {
+    const uint32_t qx = (uint32_t)(int)fminf(fmaxf(u * 0.25f, 0.0f), 1048575.0f), qy = (uint32_t)(int)fminf(fmaxf(v * 0.25f, 0.0f), 1048575.0f);  // NaN -> 0
+    return ((qx * 73856093u) ^ (qy * 19349663u)) & (uint32_t)(kSchedTableSize - 1);
+}
+
+// What the LAST call left at this position (the table this call only reads: every wave of a launch sees the same predictions)
+__device__ __forceinline__ uint32_t sched_prediction(const KltParams &p, float u, float v) {
+    const uint32_t word = p.sched_grid[(((p.sched_call - 1u) & 1u) << kSchedTableBits) + sched_table_slot(u, v)];
+    return (word >> 8) == ((p.sched_call - 1u) & 0xFFFFFFu) ? (word & 0xFFu) : 0u;
+}
+
+__device__ __forceinline__ void sched_grid_record(const KltParams &p, float ref_u, float ref_v, uint32_t iters) {
+    if (p.sched_grid != nullptr) {
+        atomicMax(&p.sched_grid[((p.sched_call & 1u) << kSchedTableBits) + sched_table_slot(ref_u, ref_v)],
+                  ((p.sched_call & 0xFFFFFFu) << 8) | (iters < 255u ? iters : 255u));
+    }
+}
+
+// Called by ONE wave on behalf of a launch slot (every lane with the same arguments): the list slot whose feature this launch
+// slot runs — `slot` itself, or the slot it traded places with.  `swapped_in` tells a head that it now runs a predicted-long feature.
+__device__ __forceinline__ uint32_t sched_resolve_slot(const KltParams &p, uint32_t slot, bool &swapped_in) {
+    swapped_in = false;
+    const uint32_t n = (uint32_t)p.n, call = p.sched_call & 0x7FFFFFu;
+    const int lane = (int)(threadIdx.x & 63);
+    // The sort block of the LAST launch found no tail in the counts it sorted: nobody trades, and nobody pays for looking (one
+    // word, the same for every slot of this launch: this launch's own sort block writes the other one).
+    if (p.sched_flags[(p.sched_call - 1u) & 1u] == ((((p.sched_call - 1u) & 0x7FFFFFFFu) << 1) | 1u)) {
+        return slot;
+    }
+    if (slot >= (uint32_t)kSchedLateSlot) {
+        // A late slot.  Heads only ever claim slots whose prediction reaches kSchedLongCount, and predictions come from a table
+        // nobody writes during this launch: a slot below that knows, without asking, that it runs its own feature.
+        const uint32_t f = p.order ? (uint32_t)p.order[slot] : slot;
+        if (sched_prediction(p, p.ref_uv[2 * f], p.ref_uv[2 * f + 1]) < kSchedLongCount) {
+            return slot;
+        }
+        uint32_t word = 0;
+        if (lane == 0) {
+            uint32_t seen = __hip_atomic_load(&p.sched_claim[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((seen >> 9) != call) {
+                const uint32_t mine = (call << 9) | kSchedSelf;
+                const uint32_t prev = atomicCAS(&p.sched_claim[slot], seen, mine);
+                seen = prev == seen ? mine : prev;  // lost the race: only a head of THIS call writes here
+            }
+            word = seen;
+        }
+        word = (uint32_t)__builtin_amdgcn_readfirstlane((int)word);
+        const uint32_t code = word & 0x1FFu;
+        return ((word >> 9) == call && code != kSchedSelf) ? (uint32_t)kSchedHeadFirst + code : slot;
+    }
+    if (slot < (uint32_t)kSchedHeadFirst || slot >= (uint32_t)(kSchedHeadFirst + kSchedHeadSlots) || n <= (uint32_t)kSchedLateSlot) {
+        return slot;
+    }
+    // a head: my share of the late slots, one per lane and pass
+    const uint32_t head = slot - (uint32_t)kSchedHeadFirst;
+    const uint32_t late = n - (uint32_t)kSchedLateSlot, share = (late + kSchedHeadSlots - 1) / kSchedHeadSlots;
+    const uint32_t first = (uint32_t)kSchedLateSlot + head * share, last = min(first + share, n);
+    const uint32_t own_feature = p.order ? (uint32_t)p.order[slot] : slot;
+    const uint32_t own = sched_prediction(p, p.ref_uv[2 * own_feature], p.ref_uv[2 * own_feature + 1]);
+    uint32_t best = 0;  // (prediction << 20) | slot: the most iterations, then the highest slot
+    for (uint32_t s = first + (uint32_t)lane; s < last; s += 64u) {
+        const uint32_t f = p.order ? (uint32_t)p.order[s] : s;
+        best = max(best, (sched_prediction(p, p.ref_uv[2 * f], p.ref_uv[2 * f + 1]) << 20) | s);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        best = max(best, (uint32_t)__shfl_xor((int)best, off));
+    }
+    const uint32_t pred = best >> 20, target = best & 0xFFFFFu;
+    if (pred < kSchedLongCount || pred < own + kSchedSwapMargin || target < first) {
+        return slot;
+    }
+    uint32_t won = 0;
+    if (lane == 0) {
+        const uint32_t seen = __hip_atomic_load(&p.sched_claim[target], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((seen >> 9) != call) {
+            won = atomicCAS(&p.sched_claim[target], seen, (call << 9) | head) == seen ? 1u : 0u;
+        }
+    }
+    won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+    swapped_in = won != 0u;
+    return won != 0u ? target : slot;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launch order of a later call, computed by ONE extra workgroup of the tracker launch itself (block 0: it starts first and
 // runs beside the feature workgroups, so the sort costs no launch and no time of its own): the feature indices sorted by the
 // iteration counts of the PREVIOUS call, longest first — a counting sort over min(count, 255) with the workgroup's dynamic LDS
@@ -1167,7 +1274,8 @@ __device__ __forceinline__ void order_scan_bins(const int *bin_count, int *bin_s
 // and 1.16 ms for 200 000 — longer than the 200 000-feature launch itself).
 constexpr int kOrderBatch = 8;
 
-__device__ __forceinline__ void klt_order_block(const uint32_t *iters, int32_t *order, int n, int *lds, const float *ref_uv, int cols, int rows, int group) {
+__device__ __forceinline__ void klt_order_block(const uint32_t *iters, int32_t *order, int n, int *lds, const float *ref_uv, int cols, int rows, int group,
+                                                uint32_t *sched_flags, uint32_t sched_call) {
     int *bin_count = lds, *bin_start = lds + 256, *tile_count = lds + 512, *tile_start = lds + 768, *flat = lds + 1024;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const bool spatial = ref_uv != nullptr && cols >= 16 && rows >= 16;
@@ -1219,6 +1327,9 @@ __device__ __forceinline__ void klt_order_block(const uint32_t *iters, int32_t *
         }
     }
     __syncthreads();
+    if (tid == 0 && sched_flags != nullptr) {
+        sched_flags[sched_call & 1u] = ((sched_call & 0x7FFFFFFFu) << 1) | (*flat != 0 ? 1u : 0u);  // for the NEXT launch's slots (sched_resolve_slot)
+    }
     const bool by_tile = *flat != 0 && spatial;
     if (*flat != 0 && !spatial) {
         for (int i = tid; i < n; i += nt) {

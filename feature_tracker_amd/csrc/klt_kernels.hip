@@ -1684,7 +1684,8 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     uint32_t block = blockIdx.x;
     if (p.sort_iters) {
         if (block == 0) {
-            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1);
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
+                            p.sched_flags, p.sched_call);
             return;
         }
         block -= 1;
@@ -1694,7 +1695,29 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     if (slot_id >= (uint32_t)p.n) {
         return;
     }
-    const uint32_t id = p.order ? (uint32_t)p.order[slot_id] : slot_id;
+    // ... and, for callers whose list changes between frames, a trade of places between an early slot and a late one whose
+    // POSITION predicts many iterations (klt_common.h sched_resolve_slot; one wave decides for the workgroup)
+    uint32_t list_slot = slot_id;
+    bool swapped_in = false;
+    if (p.sched_claim != nullptr) {
+        if (SOLO) {
+            list_slot = sched_resolve_slot(p, slot_id, swapped_in);
+        } else {
+            uint32_t *const shared = reinterpret_cast<uint32_t *>(lds_raw);
+            if (b.wave == 0) {
+                const uint32_t r = sched_resolve_slot(p, slot_id, swapped_in);
+                if (b.lane == 0) {
+                    shared[0] = r;
+                    shared[1] = swapped_in ? 1u : 0u;
+                }
+            }
+            __syncthreads();
+            list_slot = shared[0];
+            swapped_in = shared[1] != 0u;
+            __syncthreads();  // the words belong to the carve below
+        }
+    }
+    const uint32_t id = p.order ? (uint32_t)p.order[list_slot] : list_slot;
     const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
     uint8_t status = p.status_in[id];
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through
@@ -1770,7 +1793,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         // they keep the top issue priority on their SIMDs at every level
         // (the later-dispatched-half boost of the pipelined kernel was measured here too: Basic direct / fast -2...-4 %, the affine and
         // LSSD variants +1 % — their launches end with their longest feature, not with their youngest; not taken)
-        set_level_priority((p.order && slot_id < (uint32_t)kLongFeatureSlots) ? 3 : level);
+        set_level_priority(((p.order && slot_id < (uint32_t)kLongFeatureSlots) || swapped_in) ? 3 : level);
         if (MODEL == FTK_MODEL_BASIC) {
             if (METHOD == FTK_METHOD_FAST) {
                 basic_level_fast(b, p, ref, cur, ref_u, ref_v, bs, status, iters, c);
@@ -1839,6 +1862,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         if (p.iters) {
             p.iters[id] = iters;
         }
+        sched_grid_record(p, full_ref_u, full_ref_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }

@@ -568,3 +568,40 @@ def test_host_images_reach_the_pyramid_launch_through_the_pinned_slots(ftk, orac
     img[:] = 255
     for i, level in enumerate(exp):
         assert np.array_equal(pyramids[-1].download_level(i), level), i
+
+
+def test_position_keyed_trades_of_launch_slots_process_every_feature_once(ftk, oracle, monkeypatch, tmp_path):
+    """A list that is reshuffled between calls: the launch order (by list index) is stale, and early launch slots trade places with
+    late ones whose POSITION predicts many iterations (klt_common.h sched_resolve_slot; multi-wave trackers, >= 4096 features).
+    Trades must happen here, and every feature must come out exactly as the oracle has it — whichever slot ran it."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "hard", "similarity")
+    n = 4700
+    uv = synth.make_features(n, 320, 240, margin=20.0, border_fraction=0.02, half=6)
+    dump = tmp_path / "trades.txt"
+    monkeypatch.setenv("FTK_KLT_SWAP_DUMP", str(dump))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = D.context_on_stream(stream, 0)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = "inverse", 6, 6, n
+    rs = np.random.RandomState(3)
+    lists = [uv] + [np.ascontiguousarray(uv[rs.permutation(n)]) for _ in range(4)]
+    results = []
+    with torch.cuda.stream(stream):
+        klt = D.DeviceKlt("affine", opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        for pts in lists:
+            d_ref = torch.from_numpy(pts).to(dev)
+            d_out, d_so = torch.empty_like(d_ref), torch.empty(n, dtype=torch.uint8, device=dev)
+            klt.track(d_ref, d_ref.clone(), d_st, d_out, d_so)
+            stream.synchronize()
+            results.append((d_out.cpu().numpy(), d_so.cpu().numpy()))
+    for pts, (g_uv, g_st) in zip(lists, results):
+        ok, c, s, it = oracle.klt_track_pyramid("affine", ref_levels, cur_levels, pts, pts, np.zeros(n, np.uint8), method="inverse", half=6, max_points=n)
+        assert np.array_equal(g_st, s)
+        assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32))
+    assert int(it.max()) >= 20, "the scene has no long feature: nothing to trade"
+    trades, own = (int(x) for x in dump.read_text().split())
+    assert trades > 0, "no early slot traded places with a late one"
