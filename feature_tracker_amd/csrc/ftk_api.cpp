@@ -1042,7 +1042,9 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                 p.sort_iters = ctx->sched_iters[(k - 1) & 1];
                 p.sort_order_out = ctx->sched_order[(k - 1) & 1];
             }
-            if (k >= 2) {                                     // made during the previous call from the counts before it
+            static const int order_mode = getenv("FTK_KLT_ORDER") ? atoi(getenv("FTK_KLT_ORDER")) : -1;  // experiment: 0 = never, 1 = always
+            const bool use_order = order_mode >= 0 ? order_mode != 0 : true;
+            if (k >= 2 && use_order) {                        // made during the previous call from the counts before it
                 p.order = ctx->sched_order[k & 1];
             }
             if (const char *dump = getenv("FTK_KLT_SWAP_DUMP")) {  // diagnostic: how many trades the PREVIOUS launch of this context made
