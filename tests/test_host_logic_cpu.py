@@ -261,3 +261,12 @@ def test_stale_id_file_is_not_mistaken_for_this_launch(tmp_path):
     assert _comm_cli(["nonce"]).stdout.strip() == ""
     # no temporary files are left next to the id file
     assert sorted(os.listdir(tmp_path)) == ["rccl_id.bin"]
+
+
+def test_vector_bool_word_conversions_match_the_per_bit_definition():
+    """host/compat/bit_words.h moves std::vector<bool> descriptors a word at a time (libstdc++ internals on a little-endian host,
+    per-bit loops elsewhere): every length 0..300, random contents, dirty padding — against the per-bit definition, on the CPU."""
+    exe = os.path.join(ROOT, "feature_tracker_amd", "host", "build", "bit_words_selftest")
+    assert os.path.exists(exe), "host layer not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
