@@ -52,14 +52,14 @@ def algorithmic_bytes(iters: np.ndarray, levels: int, half: int, method: str) ->
     return int(iters.size * (levels * r + 26) + int(iters.astype(np.int64).sum()) * c)
 
 
-# Vector-ALU issue peak: 256 CUs x 4 SIMD-32.  The datasheet rate is one wave64 instruction per 2 cycles per SIMD
-# (MI355X_MICROARCH.md, cycle constants); what a SATURATED SIMD actually sustains on this chip, measured with
-# scripts/microbench/int_valu_rate.hip (profiles/r2_microbench_int_valu.txt: 8 waves per SIMD, independent v_add_f32 /
-# v_xor_b32), is 2.5 cycles per wave-instruction.  The fraction is quoted against the MEASURED rate (against the
-# datasheet's 2 it understates how close an issue-bound kernel is); the datasheet peak is given beside it.
+# Vector-ALU issue peak: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md, cycle
+# constants) — `peak` and `frac` of roofline_valu are quoted against THIS figure in every round (round 3 had moved
+# them to a self-measured rate, which made fractions incomparable across rounds).  What a saturated SIMD was MEASURED to sustain
+# on this chip (scripts/microbench/int_valu_rate.hip, profiles/r2_microbench_int_valu.txt: 2.5 cycles per wave-instruction) is
+# reported beside it as the secondary field frac_of_measured_peak.
 VALU_CYCLES_PER_WAVE_INST_MEASURED = 2.5
-VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / VALU_CYCLES_PER_WAVE_INST_MEASURED
 VALU_PEAK_DATASHEET = 1024 * 2.4e9 / 2.0
+VALU_PEAK_MEASURED = 1024 * 2.4e9 / VALU_CYCLES_PER_WAVE_INST_MEASURED
 
 
 def pmc_profile(workload: str, source_hash: str):
@@ -169,6 +169,153 @@ def with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur
             "result_uv": out_views[0], "result_st": out_views[1]}
 
 
+def _scene(cfg, synth):
+    if cfg["model"] == "basic":
+        ref_img, cur_img = synth.make_image_pair(cfg["width"], cfg["height"], (3.3, -2.1))
+    else:
+        ref_img, cur_img = synth.make_image_pair(cfg["width"], cfg["height"], (3.3, -2.1), rotation_deg=1.5, scale=1.02)
+    return synth.build_pyramid(ref_img, cfg["levels"]), synth.build_pyramid(cur_img, cfg["levels"])
+
+
+def tracker_config_leg(name, cfg, steps, ctx, dev, stream, source_hash):
+    """One BASELINE.json configuration timed the way the headline is (K back-to-back launches on device-resident inputs, wall
+    clock around them, one synchronisation on each side), checked against the oracle on the same inputs.  Calls of >= 4096
+    features are launched through the launch order of an earlier call (ftk_klt_track_device): repeating ONE call makes that
+    predictor perfect, so the back-to-back figure is the "warm" regime; "cold" (no history: a call with another feature count in
+    between resets it; one bracketed call at a time) is given beside it."""
+    import torch
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+    from tests import oracle_lib
+
+    n, levels, half = cfg["n"], cfg["levels"], cfg["half"]
+    lum = bool(cfg.get("luminance", False))
+    ref_levels, cur_levels = _scene(cfg, synth)
+    uv = synth.make_features(n, cfg["width"], cfg["height"], half=half)
+    opt = F.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = cfg["method"], half, half, n
+    klt = D.DeviceKlt(cfg["model"], opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx, consider_luminance=lum)
+    d_ref = torch.from_numpy(uv).to(dev)
+    d_in, d_st = d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev)
+    outs = [(torch.empty_like(d_ref), torch.empty_like(d_st)) for _ in range(2)]
+    d_it = torch.zeros(n, dtype=torch.int32, device=dev)
+    klt.track(d_ref, d_in, d_st, outs[0][0], outs[0][1], d_it)
+    stream.synchronize()
+    iters = d_it.cpu().numpy().astype(np.uint32)
+    first_uv, first_st = outs[0][0].cpu().numpy().copy(), outs[0][1].cpu().numpy().copy()
+    launches = [klt.bind(d_ref, d_in, d_st, o[0], o[1], None) for o in outs]
+    for k in range(6):
+        launches[k & 1]()
+    stream.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        launches[k & 1]()
+    stream.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    last_uv, last_st = outs[(steps - 1) & 1][0].cpu().numpy(), outs[(steps - 1) & 1][1].cpu().numpy()
+    cold_ms = None
+    if n >= 4096:
+        lat = []
+        for _ in range(7):
+            klt.track(d_ref[: n - 1], d_in[: n - 1], d_st[: n - 1], outs[1][0][: n - 1], outs[1][1][: n - 1], None)  # another count: history reset
+            stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launches[0]()
+            e1.record(stream)
+            e1.synchronize()
+            lat.append(e0.elapsed_time(e1))
+        cold_ms = float(np.median(lat))
+    t0 = time.perf_counter()
+    ok, cpu_uv, cpu_st, cpu_it = oracle_lib.klt_track_pyramid(cfg["model"], ref_levels, cur_levels, uv, method=cfg["method"], half=half, max_points=n,
+                                                              consider_luminance=lum)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    same = lambda a, b: bool(np.array_equal(a[0].view(np.uint32), cpu_uv.view(np.uint32)) and np.array_equal(b, cpu_st))
+    algo = algorithmic_bytes(iters, levels, half, cfg["method"])
+    pmc, _refused = pmc_profile(name, source_hash)
+    valu = (pmc or {}).get("valu_insts_per_launch")
+    return {
+        "workload": f"{cfg['model']} KLT {cfg['method']}{' + consider_patch_luminance' if lum else ''}, {n} features, {cfg['width']}x{cfg['height']}, {levels}-level pyramid, "
+                    f"{2 * half + 1}x{2 * half + 1} patch",
+        "ms_per_step": ms, "features_per_s": n / (ms * 1e-3), "steps": steps, "regime": "warm" if n >= 4096 else "n/a (below 4096 features: list order)",
+        "cold_ms": cold_ms, "roofline_frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo,
+        "valu_frac": (valu / (ms * 1e-3) / VALU_PEAK_DATASHEET) if valu else None,
+        "bit_identical": same((first_uv,), first_st) and same((last_uv,), last_st) and bool(np.array_equal(iters, cpu_it)),
+        "mean_iterations_per_feature": float(iters.mean()), "cpu_ms": cpu_ms, "x_cpu": cpu_ms / ms,
+    }
+
+
+def matcher_config_leg(steps, ctx, dev, stream):
+    """BASELINE.json configs[3], second half: BRIEF-256 brute-force ForceMatch, 10 000 x 10 000, back to back like the trackers."""
+    import torch
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+    from tests import oracle_lib
+
+    n_ref = n_cur = 10000
+    ref, cur, _ = synth.make_descriptors(n_ref, n_cur, flips=20)
+    d_ref = torch.from_numpy(F.pack_brief(ref).view(np.int32)).to(dev)
+    d_cur = torch.from_numpy(F.pack_brief(cur).view(np.int32)).to(dev)
+    d_idx = torch.full((n_ref,), -1, dtype=torch.int32, device=dev)
+    for _ in range(4):
+        D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx)
+    stream.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx)
+    stream.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    gpu_idx = d_idx.cpu().numpy()
+    rows = 2000  # the oracle on a bounded sample of reference rows against ALL candidates
+    t0 = time.perf_counter()
+    ok, cidx = oracle_lib.force_match(ref[:rows], cur, 60.0)
+    cpu_ms_full = (time.perf_counter() - t0) * 1e3 * n_ref / rows
+    pairs = float(n_ref) * n_cur
+    return {
+        "workload": "BRIEF-256 ForceMatch, 10000 x 10000 descriptors (hamming_match_mfma_kernel + match_epilogue_kernel)",
+        "ms_per_step": ms, "pairs_per_s": pairs / (ms * 1e-3), "descriptors_per_s": n_ref / (ms * 1e-3), "steps": steps, "regime": "n/a",
+        "roofline_bound": "mfma (int8)", "roofline_frac": 2.0 * pairs * 256 / (ms * 1e-3) / 5.0e15, "valu_frac": None,
+        "bit_identical": bool(np.array_equal(gpu_idx[:rows], cidx)), "checked_rows": rows, "matched": int((gpu_idx >= 0).sum()),
+        "cpu_ms": cpu_ms_full, "x_cpu": cpu_ms_full / ms,
+    }
+
+
+def host_call_leg(cfg, ref_levels, cur_levels, uv, expect_uv, expect_st):
+    """SURVEY.md 8(d), literally: N / wall time of ONE TrackFeatures call — host vectors in, host vectors out, one synchronous
+    ftk_klt_track (H2D of ref_uv / cur_uv / status, the tracker launch, D2H) with both pyramids already resident
+    (optical_flow.cpp:6-26 takes ready-made pyramids).  Median over single synchronous calls; never the headline `value`."""
+    import feature_tracker_amd as F
+
+    klt = {"basic": F.OpticalFlowBasicKlt, "affine": F.OpticalFlowAffineKlt, "lssd": F.OpticalFlowLssdKlt}[cfg["model"]]()
+    o = klt.options()
+    o.kMethod, o.kPatchRowHalfSize, o.kPatchColHalfSize, o.kMaxTrackPointsNumber = cfg["method"], cfg["half"], cfg["half"], cfg["n"]
+    rp, cp = F.ImagePyramid.from_host_levels(ref_levels), F.ImagePyramid.from_host_levels(cur_levels)
+    for _ in range(5):
+        ok, c, st = klt.TrackFeatures(rp, cp, uv)
+    lat = []
+    for _ in range(60):
+        t0 = time.perf_counter()
+        ok, c, st = klt.TrackFeatures(rp, cp, uv)
+        lat.append(time.perf_counter() - t0)
+    med = float(np.median(lat))
+    return {"ms": med * 1e3, "features_per_s": cfg["n"] / med, "calls": len(lat), "p10_ms": float(np.percentile(lat, 10)) * 1e3, "p90_ms": float(np.percentile(lat, 90)) * 1e3,
+            "bit_identical_to_resident_path": bool(ok and np.array_equal(c.view(np.uint32), expect_uv.view(np.uint32)) and np.array_equal(st, expect_st)),
+            "what": "one synchronous ftk_klt_track per call through the Python mirror of feature_tracker.h (host float vectors in and out over PCIe, "
+                    "pyramids resident in HBM); the C++ class adds nothing to it"}
+
+
+def sharded_steps(slots, d_ref, d_in, d_st, steps, collective):
+    """The plain per-step loop of the strong-scaling path: step k launches this rank's block into result slot k & 1 and
+    all-gathers that slot's packed shard.  Shared by run_sharded (GPU) and the CPU rehearsal of --dry-launch --shard-total."""
+    for k in range(steps):
+        slots[k & 1].launch_local(d_ref, d_in, d_st)
+        slots[k & 1].gather(force_collective=collective)
+
+
 def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
     """Strong scaling: args.shard_total features of the workload's geometry, sharded over the ranks, one all-gather per step."""
     import torch
@@ -194,9 +341,7 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         d_ref = torch.from_numpy(uv).to(dev)
         d_in = d_ref.clone()
         d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
-        for k in range(max(2, args.warmup)):
-            slots[k & 1].launch_local(d_ref, d_in, d_st)
-            slots[k & 1].gather(force_collective=use_dist)
+        sharded_steps(slots, d_ref, d_in, d_st, max(2, args.warmup), use_dist)
         stream.synchronize()
         # As in the weak-scaling path: with a collective per step the K steps are captured ONCE into a HIP graph in which the
         # gather of step k runs on a side stream beside the kernel of step k + 1 (the kernel of step k + 2 waits for the gather
@@ -250,9 +395,7 @@ def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
         if graph is not None:
             graph.replay()
         else:
-            for k in range(args.steps):
-                slots[k & 1].launch_local(d_ref, d_in, d_st)
-                slots[k & 1].gather(force_collective=use_dist)
+            sharded_steps(slots, d_ref, d_in, d_st, args.steps, use_dist)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -433,13 +576,46 @@ def dry_launch(args, world: int, rank: int) -> None:
     gathered = FD.all_gather_results(packed, world, force_collective=True)
     per = FD.packed_bytes(n)
     shards_ok = all(bool((gathered[r * per:(r + 1) * per] == r).all()) for r in range(world))
+    sharded = None
+    if args.shard_total > 0:
+        # The strong-scaling path's bookkeeping (run_sharded: block bounds, per-rank capacity, packed shards in two alternating
+        # slots, one all-gather per step, unpacking in global feature order, the GLOBAL kMaxTrackPointsNumber) with N > 1 ranks
+        # before the first hardware run: the same ShardedKlt objects and the same step loop over gloo, around a stand-in for the
+        # device tracker that writes a known function of the GLOBAL feature index (rehearsal scaffolding of this flag only).
+        total, cap_global = args.shard_total, args.shard_total - args.shard_total // 7  # a cap that cuts into the last blocks
+
+        class _DryTracker:
+            max_track_points = cap_global
+
+            def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters, max_track_points=None):
+                m = ref_uv.shape[0]
+                limit = m if max_track_points is None else int(max_track_points)
+                tracked = torch.arange(m) < limit
+                cur_uv_out.copy_(torch.where(tracked[:, None], ref_uv * 2.0 + 1.0, cur_uv_in))
+                status_out.copy_(torch.where(tracked, (ref_uv[:, 0].to(torch.int64) % 3).to(torch.uint8), status_in))
+
+        idx = torch.arange(total, dtype=torch.float32)
+        d_ref = torch.stack([idx, -idx], dim=1).contiguous()
+        d_in, d_st = d_ref + 0.5, torch.full((total,), 9, dtype=torch.uint8)
+        slots = [FD.ShardedKlt(_DryTracker(), total, "cpu", world, rank) for _ in range(2)]
+        sharded_steps(slots, d_ref, d_in, d_st, max(2, args.steps), True)
+        results = [FD.unpack_gathered(sl.gathered, total, world) for sl in slots]
+        want_uv, want_st = torch.empty_like(d_ref), torch.empty_like(d_st)
+        _DryTracker().track(d_ref, d_in, d_st, want_uv, want_st, None, max_track_points=cap_global)
+        bounds = [FD.shard_bounds(total, world, r) for r in range(world)]
+        sharded = {"total": total, "global_cap": cap_global, "capacity": FD.shard_capacity(total, world), "packed_bytes": FD.packed_bytes(FD.shard_capacity(total, world)),
+                   "blocks_cover_the_list": bounds[0][0] == 0 and bounds[-1][1] == total and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1)),
+                   "gathered_equals_unsharded": all(bool(torch.equal(uv, want_uv) and torch.equal(st, want_st)) for uv, st in results)}
+        flag = torch.tensor([1 if (sharded["gathered_equals_unsharded"] and sharded["blocks_cover_the_list"]) else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank holds every rank's result: all must agree
+        sharded["all_ranks_agree"] = bool(flag.item() == 1)
     dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": int(dist.get_world_size()), "ranks_counted": int(ones.item()),
                           "backend": "gloo", "all_gather_ok": shards_ok, "self_launched": os.environ.get("FTK_BENCH_SELF_LAUNCHED") == "1",
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "sharded": sharded}), flush=True)
     dist.destroy_process_group()
-    if not shards_ok or int(ones.item()) != world:
+    if not shards_ok or int(ones.item()) != world or (sharded is not None and not sharded["all_ranks_agree"]):
         raise SystemExit(4)
 
 
@@ -452,6 +628,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tree-leg", action="store_true", help="skip the throughput_mode measurement (N = 1 only; it runs after the timed region)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the with_pyramid_upload measurement (N = 1 only; it runs after the timed region)")
+    ap.add_argument("--no-configs-leg", action="store_true", help="skip the `configs` object (the other BASELINE configurations, N = 1 only; after the timed region)")
+    ap.add_argument("--no-host-call-leg", action="store_true", help="skip the `host_call` object (one synchronous host-vector TrackFeatures call; N = 1 only)")
     ap.add_argument("--shard-total", type=int, default=0,
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
                          "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
@@ -686,6 +864,23 @@ def main():
         upload = None
         if world == 1 and args.features == 0 and not args.no_upload_leg:
             upload = with_pyramid_upload(args, cfg, ctx, klt, opt, ref_img, cur_img, d_ref, d_cur_in, d_st_in, n, levels, stream, views2[1])
+        configs_leg, host_call = None, None
+        if world == 1 and args.features == 0 and not args.no_configs_leg:
+            from feature_tracker_amd import _native as NL0
+            src_hash = NL0.build_info().get("source_hash")
+            k_cfg = max(20, min(args.steps, 100))
+            configs_leg = {}
+            t_cfg = time.perf_counter()
+            for name in ("config1", "config3", "config4", "config5_shard"):
+                if name == args.workload:
+                    continue
+                configs_leg[name if name != "config4" else "config4_tracker"] = tracker_config_leg(name, dict(synth.CONFIGS[name]), k_cfg, ctx, dev, stream, src_hash)
+            configs_leg["config4_matcher"] = matcher_config_leg(k_cfg, ctx, dev, stream)
+            configs_leg["config4_tracker_luminance"] = tracker_config_leg("config4_luminance", dict(synth.CONFIGS["config4"], luminance=True), k_cfg, ctx, dev, stream, src_hash)
+            configs_leg["basic_fast_2000_13x13"] = tracker_config_leg("basic_fast", dict(synth.CONFIGS["config2"], half=6, method="fast"), k_cfg, ctx, dev, stream, src_hash)
+            configs_leg["seconds_spent"] = time.perf_counter() - t_cfg
+        if world == 1 and args.features == 0 and not args.no_host_call_leg:
+            host_call = host_call_leg(cfg, ref_levels, cur_levels, uv, first_uv, first_st)
         if use_dist:
             # every rank must now hold every rank's result shard: spot-check the own shard inside the gathered buffer
             per = FD.packed_bytes(n)
@@ -737,11 +932,12 @@ def main():
         }
         if pmc.get("valu_insts_per_launch"):
             valu = pmc["valu_insts_per_launch"] / (kernel_ms * 1e-3)
-            out["roofline_valu"] = {"bound": "valu_issue", "achieved": valu, "peak": VALU_PEAK_WAVE_INSTS_PER_S, "unit": "wave64 VALU instructions/s",
-                                    "frac": valu / VALU_PEAK_WAVE_INSTS_PER_S, "valu_insts_per_launch": pmc["valu_insts_per_launch"],
-                                    "peak_is": f"1024 SIMDs x 2.4 GHz / {VALU_CYCLES_PER_WAVE_INST_MEASURED} cycles per wave64 instruction, the rate a saturated SIMD "
-                                               "sustains (scripts/microbench/int_valu_rate.hip, profiles/r2_microbench_int_valu.txt)",
-                                    "frac_of_datasheet_peak": valu / VALU_PEAK_DATASHEET,
+            out["roofline_valu"] = {"bound": "valu_issue", "achieved": valu, "peak": VALU_PEAK_DATASHEET, "unit": "wave64 VALU instructions/s",
+                                    "frac": valu / VALU_PEAK_DATASHEET, "valu_insts_per_launch": pmc["valu_insts_per_launch"],
+                                    "peak_is": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md cycle constants; the figure of rounds 1-2)",
+                                    "frac_of_measured_peak": valu / VALU_PEAK_MEASURED,
+                                    "measured_peak_is": f"1024 SIMDs x 2.4 GHz / {VALU_CYCLES_PER_WAVE_INST_MEASURED} cycles, the rate a saturated SIMD sustains "
+                                                        "(scripts/microbench/int_valu_rate.hip, profiles/r2_microbench_int_valu.txt)",
                                     "lds_bank_conflict_frac": pmc.get("lds_bank_conflict_frac"), "source": pmc.get("source")}
         else:
             out["roofline_valu"] = None  # no counters of THIS build: see roofline.traffic_refused
@@ -759,6 +955,17 @@ def main():
             up_uv, up_st = upload.pop("result_uv").cpu().numpy(), upload.pop("result_st").cpu().numpy()
             upload["bit_identical_to_resident_path"] = bool(np.array_equal(up_uv.view(np.uint32), first_uv.view(np.uint32)) and np.array_equal(up_st, first_st))
             out["with_pyramid_upload"] = upload
+        if host_call is not None:
+            out["host_call"] = host_call
+        if configs_leg is not None:
+            # the headline workload in the same shape, so that the object covers all five BASELINE configurations
+            configs_leg[args.workload] = {
+                "workload": out["config"]["workload"], "ms_per_step": out["ms_per_step"], "features_per_s": value, "steps": args.steps,
+                "regime": "n/a (below 4096 features: list order)" if n < 4096 else "warm", "cold_ms": None, "roofline_frac": out["roofline"]["frac"],
+                "algorithmic_bytes_per_launch": algo, "valu_frac": (out.get("roofline_valu") or {}).get("frac"),
+                "bit_identical": bool(out["parity"]["bit_identical"] and out["parity"]["last_launch_bit_identical"] and out["parity"]["iteration_counts_equal"]),
+                "mean_iterations_per_feature": float(iters.mean())}
+            out["configs"] = configs_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
         print(json.dumps(out), flush=True)

@@ -286,8 +286,12 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.terms_floats = ((p.Ppad / 4 + ftk::kAffineTermsRoundGroups - 1) / ftk::kAffineTermsRoundGroups) * ftk::kAffineTermsRoundGroups * ftk::kAffineTermsGroupFloats;  // products grouped by four pixels (klt_kernels.hip affine_all_terms)
         // The axis tables of the level setup are dead once the iterations start, and the head of the product groups is rewritten
         // by every iteration before it is read: the tables live THERE.  1.2 KB less per feature at 13 x 13 — 22.5 instead of
-        // 23.8 KB, i.e. seven instead of six features per CU.
-        p.a0_floats = 0;
+        // 23.8 KB, i.e. seven instead of six features per CU.  Not for patches of fewer than four pixels (1x1, 1x3, 3x1): their
+        // FIRST group holds zero padding (written once per launch) that the tables would overwrite; from 1x5 / 3x3 on the first
+        // group with padding starts behind the tables (group g at 100 g floats, tables 12 (rows + cols) floats).
+        if (p.P >= 4) {
+            p.a0_floats = 0;
+        }
     }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
@@ -1041,6 +1045,11 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             if (k >= 1) {                                     // sort the previous call's counts beside this call's features
                 p.sort_iters = ctx->sched_iters[(k - 1) & 1];
                 p.sort_order_out = ctx->sched_order[(k - 1) & 1];
+                // The spatial (tile) order reads the reference positions in two passes while the feature workgroups of the same
+                // launch write cur_uv_out: with one position buffer updated in place (ref == out, allowed by include/ftk.h) a
+                // feature crossing a tile boundary in between would make the histogram and the scatter disagree — duplicates,
+                // stale entries, a write past order[n - 1].  Such a call gets the iteration-count / identity order instead.
+                p.sort_ref_uv = ref_untouched ? p.ref_uv : nullptr;
             }
             static const int order_mode = getenv("FTK_KLT_ORDER") ? atoi(getenv("FTK_KLT_ORDER")) : -1;  // experiment: 0 = never, 1 = always
             const bool use_order = order_mode >= 0 ? order_mode != 0 : true;

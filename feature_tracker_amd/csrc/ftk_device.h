@@ -42,6 +42,8 @@ struct KltParams {
     uint32_t sched_call;
     const uint32_t *sort_iters;  // may be null: the previous call's counts; one extra workgroup (block 0) sorts them ...
     int32_t *sort_order_out;     // ... into this permutation, longest first (klt_common.h, klt_order_block)
+    const float *sort_ref_uv;    // reference positions the sort block may use for the spatial (tile) order: ref_uv, or null when this
+                                 // launch's outputs overwrite them (in-place position buffer: the two passes of the sort would disagree)
     int32_t n;             // features in the buffers
     uint32_t n_track;      // min(n, kMaxTrackPointsNumber)
     uint32_t max_iteration;

@@ -378,7 +378,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     uint32_t block = blockIdx.x;
     if (p.sort_iters) {
         if (block == 0) {
-            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.sort_ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
                             p.sched_flags, p.sched_call);
             return;
         }

@@ -1684,7 +1684,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     uint32_t block = blockIdx.x;
     if (p.sort_iters) {
         if (block == 0) {
-            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
+            klt_order_block(p.sort_iters, p.sort_order_out, p.n, reinterpret_cast<int *>(lds_raw), p.sort_ref_uv, p_arg.ref[0].cols, p_arg.ref[0].rows, SOLO ? max(p.features_per_group, 1) : 1,
                             p.sched_flags, p.sched_call);
             return;
         }
@@ -1746,7 +1746,9 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     }
     Carve c = carve_lds(lds_mine, K, p);
     if (MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) {
-        c.a0 = c.terms;  // the level setup's axis tables share the head of the product groups (a0_floats == 0: ftk_api.cpp)
+        if (p.a0_floats == 0) {
+            c.a0 = c.terms;  // the level setup's axis tables share the head of the product groups (a0_floats == 0: ftk_api.cpp)
+        }
         // grouped layout (affine_all_terms): the pixels behind the patch up to the end of the last round of groups, all 24 sums
         const int first = p.P, end = affine_group_rounds(p.Ppad) * (4 * kChainRound);
         for (int idx = b.tid; idx < A_COUNT * (end - first); idx += b.nt) {

@@ -1,5 +1,6 @@
 #include "device_runtime.h"
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -93,6 +94,7 @@ namespace {
 // previous (or crashed) run left under the same path: readers wait until a file with THEIR nonce appears.
 constexpr char kIdMagic[8] = {'F', 'T', 'K', 'I', 'D', '0', '0', '2'};
 constexpr size_t kNonceBytes = 64;
+constexpr int kMaxRankSkewSeconds = 120;  // how far apart the ranks of one launch may start (AwaitCommId waits this long for rank 0)
 struct IdFile {
     char magic[8];
     char nonce[kNonceBytes];
@@ -105,14 +107,78 @@ void PadNonce(const std::string &nonce, char out[kNonceBytes]) {
 }
 }  // namespace
 
+namespace {
+// "<pid>@<start time in clock ticks since boot>" of this process's parent (Linux: /proc/<pid>/stat, field 22), or "" when it
+// cannot be read.  The start time makes the pair unique for the life of the machine even when pids are reused.
+std::string ParentIdentity() {
+    const long ppid = static_cast<long>(getppid());
+    const std::string stat_path = "/proc/" + std::to_string(ppid) + "/stat";
+    std::string line;
+    if (FILE *f = std::fopen(stat_path.c_str(), "rb")) {
+        char buf[1024];
+        const size_t got = std::fread(buf, 1, sizeof(buf) - 1, f);
+        std::fclose(f);
+        line.assign(buf, got);
+    }
+    // the command name (field 2) is in parentheses and may contain spaces: count fields after the LAST ')'
+    const size_t close = line.rfind(')');
+    if (close == std::string::npos) {
+        return std::string();
+    }
+    size_t pos = close + 1;
+    std::string field;
+    for (int index = 3; index <= 22; ++index) {
+        while (pos < line.size() && line[pos] == ' ') {
+            ++pos;
+        }
+        const size_t end = line.find(' ', pos);
+        field = line.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+        if (end == std::string::npos && index < 22) {
+            return std::string();
+        }
+        pos = end == std::string::npos ? line.size() : end;
+    }
+    if (field.empty()) {
+        return std::string();
+    }
+    return std::to_string(ppid) + "@" + field;
+}
+
+const std::chrono::system_clock::time_point g_process_start = std::chrono::system_clock::now();
+}  // namespace
+
+// What tells THIS launch's id file from one an earlier (or crashed) run left under the same path.  FTK_COMM_NONCE, when the caller
+// sets it, is taken as is (ranks started from unrelated parents — two terminals, an MPI launcher with a shell per rank — need it).
+// Otherwise: the launcher's variables are NOT unique per launch under default torchrun (TORCHELASTIC_RUN_ID is "none",
+// MASTER_PORT 29500, every time), so under a launcher that forks all ranks of a node from one agent process (it exports
+// LOCAL_RANK / TORCHELASTIC_RUN_ID; this library shards over the GPUs of ONE node) the agent's identity — pid and start time —
+// and the restart count of an elastic agent are part of the nonce: the same for every rank of a launch, different for the next.
 std::string CommLaunchNonce() {
-    for (const char *name : {"FTK_COMM_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
-        const char *v = std::getenv(name);
-        if (v != nullptr && v[0] != '\0') {
-            return std::string(name) + "=" + v;
+    if (const char *v = std::getenv("FTK_COMM_NONCE")) {
+        if (v[0] != '\0') {
+            return std::string("FTK_COMM_NONCE=") + v;
         }
     }
-    return std::string();
+    std::string nonce;
+    for (const char *name : {"TORCHELASTIC_RUN_ID", "MASTER_PORT"}) {
+        const char *v = std::getenv(name);
+        if (v != nullptr && v[0] != '\0') {
+            nonce = std::string(name) + "=" + v;
+            break;
+        }
+    }
+    const char *local_rank = std::getenv("LOCAL_RANK");
+    const bool common_parent = (local_rank != nullptr && local_rank[0] != '\0') || std::getenv("TORCHELASTIC_RUN_ID") != nullptr;
+    if (common_parent) {
+        const std::string parent = ParentIdentity();
+        if (!parent.empty()) {
+            nonce += (nonce.empty() ? "" : ";") + std::string("parent=") + parent;
+        }
+        if (const char *restarts = std::getenv("TORCHELASTIC_RESTART_COUNT")) {
+            nonce += std::string(";restart=") + restarts;
+        }
+    }
+    return nonce;  // at most kNonceBytes - 1 characters take part (PadNonce)
 }
 
 bool PublishCommId(const std::string &path, const std::string &nonce, const unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error) {
@@ -146,8 +212,13 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
         if (FILE *f = std::fopen(path.c_str(), "rb")) {
             IdFile file;
             const bool whole = std::fread(&file, 1, sizeof(file), f) == sizeof(file) && std::memcmp(file.magic, kIdMagic, sizeof(kIdMagic)) == 0;
+            // ... and whatever the nonce says, a file written long before this process started is not this launch's: the ranks of a
+            // launch come up within the time a reader waits for rank 0 (kMaxRankSkewSeconds), so an older file is a leftover
+            struct stat st;
+            const bool fresh = fstat(fileno(f), &st) == 0 &&
+                               std::chrono::system_clock::from_time_t(st.st_mtime) + std::chrono::seconds(kMaxRankSkewSeconds) >= g_process_start;
             std::fclose(f);
-            if (whole && std::memcmp(file.nonce, want, kNonceBytes) == 0) {
+            if (whole && fresh && std::memcmp(file.nonce, want, kNonceBytes) == 0) {
                 std::memcpy(id, file.id, FTK_UNIQUE_ID_BYTES);
                 return true;
             }
@@ -224,7 +295,7 @@ ftk_comm *SharedComm(ftk_context *ctx, std::string *error) {
             PublishCommId(id_file, nonce, id, &g_comm_error);
         }
     } else {
-        AwaitCommId(id_file, nonce, 120000, id, &g_comm_error);  // up to two minutes for rank 0 to come up
+        AwaitCommId(id_file, nonce, kMaxRankSkewSeconds * 1000, id, &g_comm_error);  // up to two minutes for rank 0 to come up
     }
     if (g_comm_error.empty() && ftk_comm_create(ctx, rank, world, id, &g_comm) != FTK_OK) {
         g_comm = nullptr;

@@ -62,3 +62,28 @@ def test_a_failing_rank_ends_the_whole_launch_with_its_code():
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert _json_lines(res.stdout) == []
+
+
+def test_two_ranks_rehearse_config5_strong_scaling_bookkeeping():
+    # BASELINE.json configs[4]'s shape (200 000 features sharded over the ranks) through the SAME ShardedKlt objects and step loop as
+    # bench.py --shard-total on GPUs, over gloo with N > 1: blocks, capacity, packed shards, two result slots,
+    # the global kMaxTrackPointsNumber cutting into a block, unpacking in global order
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-launch", "--shard-total", "200000"], env=_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = _json_lines(res.stdout)[0]
+    sh = line["sharded"]
+    assert line["n_gpus"] == 2 and sh["total"] == 200000 and sh["capacity"] == 100000 and sh["packed_bytes"] == 900000
+    assert sh["blocks_cover_the_list"] and sh["gathered_equals_unsharded"] and sh["all_ranks_agree"]
+    # an odd total and three ranks: ragged blocks, padded capacity
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "3", "--steps", "2", "--dry-launch", "--shard-total", "100003"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=_env(WORLD_SIZE="3", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    sh = [l for o in outs for l in _json_lines(o[0])][0]["sharded"]
+    assert sh["capacity"] == 33335 and sh["gathered_equals_unsharded"] and sh["all_ranks_agree"]

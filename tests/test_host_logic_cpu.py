@@ -254,11 +254,29 @@ def test_stale_id_file_is_not_mistaken_for_this_launch(tmp_path):
     assert _comm_cli(["publish", path, "42"], FTK_COMM_NONCE="B").returncode == 0
     out, err = reader.communicate(timeout=30)
     assert reader.returncode == 0 and out.strip() == "42", err
-    # the nonce falls back to what torchrun exports
+    # the nonce falls back to what torchrun exports — which is the SAME on every default launch ("none", 29500: ADVICE r3), so
+    # under a launcher (LOCAL_RANK / TORCHELASTIC_RUN_ID present) the launching process's identity (pid @ start time) and the
+    # elastic restart count are part of it: equal for the ranks of one launch, different for the next launch
     assert _comm_cli(["nonce"], MASTER_PORT="29512").stdout.strip() == "MASTER_PORT=29512"
-    assert _comm_cli(["nonce"], MASTER_PORT="29512", TORCHELASTIC_RUN_ID="job7").stdout.strip() == "TORCHELASTIC_RUN_ID=job7"
     assert _comm_cli(["nonce"], MASTER_PORT="29512", FTK_COMM_NONCE="n").stdout.strip() == "FTK_COMM_NONCE=n"
     assert _comm_cli(["nonce"]).stdout.strip() == ""
+    mine = _comm_cli(["nonce"], MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1").stdout.strip()
+    assert mine.startswith("TORCHELASTIC_RUN_ID=none;parent=%d@" % os.getpid()), mine
+    assert _comm_cli(["nonce"], MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="0").stdout.strip() == mine  # a sibling rank
+    assert _comm_cli(["nonce"], MASTER_PORT="29500", LOCAL_RANK="0").stdout.strip().startswith("MASTER_PORT=29500;parent=%d@" % os.getpid())
+    restarted = _comm_cli(["nonce"], MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1", TORCHELASTIC_RESTART_COUNT="1").stdout.strip()
+    assert restarted == mine + ";restart=1"
+    # the same launcher variables under ANOTHER launching process (a shell in between) give another nonce
+    other = subprocess.run(["sh", "-c", COMM_CLI + " nonce; true"], capture_output=True, text=True, timeout=30,
+                           env=dict(base, MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1")).stdout.strip()
+    assert other.startswith("TORCHELASTIC_RUN_ID=none;parent=") and other != mine
+    # and whatever its nonce, a file written long before this process started is a leftover (ranks start within two minutes)
+    assert _comm_cli(["publish", path, "99"], FTK_COMM_NONCE="B").returncode == 0
+    old = time.time() - 600
+    os.utime(path, (old, old))
+    aged = _comm_cli(["await", path, "300"], FTK_COMM_NONCE="B")
+    assert aged.returncode == 2, aged.stdout
+    assert _comm_cli(["publish", path, "42"], FTK_COMM_NONCE="B").returncode == 0
     # no temporary files are left next to the id file
     assert sorted(os.listdir(tmp_path)) == ["rccl_id.bin"]
 

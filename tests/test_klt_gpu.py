@@ -350,6 +350,18 @@ def test_large_and_degenerate_patch_sizes(ftk, oracle, model, half):
         assert_parity(gpu, cpu, f"half={half} {model}/{method}")
 
 
+@pytest.mark.parametrize("half,half_cols", [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1)])
+def test_affine_patches_smaller_than_one_product_group(ftk, oracle, half, half_cols):
+    """1x1, 1x3, 3x1, 1x5, 3x3 affine patches: with fewer than four pixels the level setup's axis tables would overlap the
+    zero padding of the first product group if they shared its space — the non-fast affine variants keep their own
+    table space for such patches."""
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    uv = scenes.features(60, 320, 240, half=3)
+    for method in METHODS:
+        gpu, cpu = run_pyramid(ftk, oracle, "affine", method, ref_levels, cur_levels, uv, half=half, half_cols=half_cols)
+        assert_parity(gpu, cpu, f"half=({half},{half_cols}) affine/{method}")
+
+
 def test_unsupported_patch_is_a_clean_error(ftk):
     from feature_tracker_amd import _native
     ref_levels, cur_levels = scenes.scene(160, 120, 1)
@@ -545,6 +557,37 @@ def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle
         pts = uv[order[slots]]
         areas.append(pts[:, 0].std() * pts[:, 1].std())
     assert np.median(areas) < 0.25 * area_all, (np.median(areas), area_all)
+
+
+@pytest.mark.parametrize("n", [4603, 8192])
+def test_one_position_buffer_updated_in_place_over_many_calls(ftk, oracle, n):
+    """ref_uv == cur_uv_in == cur_uv_out (one position buffer updated in place: include/ftk.h allows the out tensors to alias the in
+    tensors) on calls large enough to carry the launch-order sort block (>= 4096 features): the block's spatial order would read
+    the reference positions in two passes while the feature workgroups overwrite them — such a call must fall back to
+    an order that does not read them, and every one of five chained calls must return the oracle's answer for ITS inputs."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "translation")
+    uv = synth.make_features(n, 320, 240, margin=30.0, border_fraction=0.0, half=5)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = D.context_on_stream(stream, 0)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = "inverse", 5, 5, n
+    zeros = np.zeros(n, np.uint8)
+    with torch.cuda.stream(stream):
+        klt = D.DeviceKlt("basic", opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_pos = torch.from_numpy(uv).to(dev)
+        d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        expect = uv
+        for call in range(5):
+            d_so = torch.empty(n, dtype=torch.uint8, device=dev)
+            klt.track(d_pos, d_pos, d_st, d_pos, d_so)
+            stream.synchronize()
+            ok, c, s, _ = oracle.klt_track_pyramid("basic", ref_levels, cur_levels, expect, expect, zeros, method="inverse", half=5, max_points=n)
+            assert np.array_equal(d_so.cpu().numpy(), s), f"call {call}"
+            assert np.array_equal(d_pos.cpu().numpy().view(np.uint32), c.view(np.uint32)), f"call {call}"
+            expect = c
 
 
 def test_host_images_reach_the_pyramid_launch_through_the_pinned_slots(ftk, oracle):
