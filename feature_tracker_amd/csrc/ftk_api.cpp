@@ -276,6 +276,27 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         const char *env = getenv("FTK_KLT_PIPELINED");
         p.pb_enabled = (small && !(env && atoi(env) == 0)) ? 1 : 0;
     }
+    // The `fast` method (the reference's default) of Basic KLT runs the one-wave kernel of klt_fast_kernels.hip at every feature
+    // count: with 1 - 2 iterations per level a feature's life is its level entries, which that kernel walks without a barrier and with
+    // the next level's windows in flight (2 000 x 13 x 13: 28.8 us on the generic two-wave kernel).  Not in the throughput mode (the
+    // generic kernel's instantiations serve it), not for patches whose per-pixel records would crowd the LDS.
+    p.fk_enabled = 0;
+    // One wave walks all P pixels of every pass: up to 15 x 15 that beats the generic kernel's 2 - 4 waves at every feature count
+    // (2 000 x 13 x 13: 22.6 vs 27.5 us; 10 000: 58.6 vs 82.9 us); larger patches only where the call is throughput-bound anyway
+    // (2 000 x 21 x 21: 77.8 vs 54.4 us on two waves).
+    if (model == FTK_MODEL_BASIC && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && !p.tree && (p.P <= 256 || (n > 2048 && p.P <= 1024))) {
+        bool small = true;
+        for (int i = 0; i < p.n_levels; ++i) {
+            small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);
+        }
+        const char *env = getenv("FTK_KLT_FAST_KERNEL");
+        ftk::KltParams one = p;
+        one.features_per_group = 1;
+        if (small && !(env && atoi(env) == 0) && ftk::klt_fast_lds_bytes(model, one) <= 40 * 1024) {
+            p.fk_enabled = 1;
+            p.waves_per_feature = 1;
+        }
+    }
     // LSSD fast, one wave per feature, no luminance scaling: the chunked sweep / chain variant (a 64-pixel ring instead of all
     // P products of all nine chains in LDS; config 4: 304 -> 242 us)
     p.terms_floats = 0;
@@ -302,7 +323,19 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.terms_floats = epad > 9 * 68 ? epad : 9 * 68;  // the ring, or the extended patch that shares its space at level entry
         p.a0_floats = 0;                                  // (klt_kernels.hip lssd_level_fast_chunked)
     }
-    if (!p.pb_enabled) {
+    if (p.fk_enabled) {
+        int group = 4;  // one-wave features that never meet, several to a workgroup (the 16-workgroups-per-CU cap)
+        if (const char *env = getenv("FTK_KLT_GROUP")) {
+            group = atoi(env);  // experiment override
+        }
+        p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
+        ftk::KltParams one = p;
+        one.features_per_group = 1;
+        const int fit = (int)((size_t)(64 * 1024) / ftk::klt_fast_lds_bytes(model, one));  // a workgroup's LDS stays below 64 KB
+        if (p.features_per_group > fit) {
+            p.features_per_group = fit < 1 ? 1 : fit;
+        }
+    } else if (!p.pb_enabled) {
         p.features_per_group = 1;  // the generic kernel's workgroup is one feature ...
         if (p.waves_per_feature == 1) {
             int group = 2;  // ... or, one-wave variants, a few features that never meet (config 4, 10 000 features: 153 / 140.5 / 141 us at 1 / 2 / 4)
@@ -517,6 +550,7 @@ int ftk_warmup(ftk_context *ctx, unsigned what) {
     if (what & FTK_WARM_KLT) {
         FTK_HIP(ctx, ftk::klt_warm(ctx->stream));
         FTK_HIP(ctx, ftk::klt_basic_warm(ctx->stream));
+        FTK_HIP(ctx, ftk::klt_fast_warm(ctx->stream));
         FTK_HIP(ctx, ftk::pyramid_warm(ctx->stream));
         // the staging blocks of the host-buffer entry points, at the size a few thousand features need ...
         // ... and what the upload of one 1080p pyramid stages (ftk_pyramid_upload gathers the levels in the pinned block)

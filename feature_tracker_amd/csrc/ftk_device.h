@@ -76,6 +76,7 @@ struct KltParams {
     int32_t pb_rwin_rows, pb_rwin_cols;  // reference window incl. the rounding row / column: 2h+5 (cols padded to 4)
     uint32_t pb_magic_rwc, pb_magic_rwq;
     int32_t pb_cap_r, pb_cap_c;          // lattice node capacity per axis: len + 2 + provable maximum of extras
+    int32_t fk_enabled;                  // the one-wave `fast` kernels (klt_fast_kernels.hip); 0 selects the generic kernel
     int32_t tree;                        // 0: sums in the reference's order (the contract); 1: throughput mode — the same per-pixel products, summed
                                          // by per-lane partials + a cross-lane butterfly (ftk_set_reduction_mode; reported, never the default)
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
@@ -264,6 +265,11 @@ hipError_t pyramid_build_levels_launch(const uint8_t *level0, int32_t rows, int3
 bool pyramid_fused_enabled();
 hipError_t extract_patch_launch(DevImage ref, float u, float v, int32_t ex_rows, int32_t ex_cols, float *d_patch, uint8_t *d_valid,
                                 uint32_t *d_count, hipStream_t stream);
+
+// One-wave kernels of the `fast` method (klt_fast_kernels.hip); klt_launch dispatches to them when p.fk_enabled.
+size_t klt_fast_lds_bytes(int model, const KltParams &p);
+hipError_t klt_fast_launch(int model, const KltParams &p, hipStream_t stream);
+hipError_t klt_fast_warm(hipStream_t stream);
 
 // One empty launch per translation unit: loads its code object (ftk_warmup).
 hipError_t klt_warm(hipStream_t stream);

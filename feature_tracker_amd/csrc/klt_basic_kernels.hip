@@ -103,54 +103,6 @@ __device__ __forceinline__ PbLds pb_carve(float4 *base, const KltParams &p, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Window prefetch: raw 8-byte loads issued early, turned into pixel pairs and stored late.
-// ---------------------------------------------------------------------------------------------
-template <int N>
-struct RawQuads {
-    uint32_t x[N], y[N];
-};
-
-template <int N>
-__device__ __forceinline__ void issue_quads(RawQuads<N> &q, const Blk &b, const DevImage &im, int r_lo, int c_lo, int wrows, int wcols,
-                                            uint32_t magic_quads) {
-    const int quads = wcols >> 2;
-    const int total = wrows * quads;
-    const int tid = opaque(b.tid);
-    const uint8_t *base = im.data + (long long)r_lo * im.cols + c_lo;  // wave-uniform: scalar base + 32-bit lane offset
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        int idx = tid + k * b.nt;
-        idx = idx < total ? idx : 0;
-        const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-        const int qq = idx - imul(r, quads);
-        const uint8_t *src = base + (size_t)(unsigned)(r * im.cols + 4 * qq);
-        __builtin_memcpy(&q.x[k], src, 4);
-        __builtin_memcpy(&q.y[k], src + 4, 4);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void store_quads(const RawQuads<N> &q, const Blk &b, uint16_t *dst, int wrows, int wcols, uint32_t magic_quads) {
-    const int quads = wcols >> 2;
-    const int total = wrows * quads;
-    const int tid = opaque(b.tid);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int idx = tid + k * b.nt;
-        if (idx < total) {
-            const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
-            const int qq = idx - imul(r, quads);
-            const uint32_t x = q.x[k], y = q.y[k];
-            const uint32_t p0 = x & 0xFFFFu;
-            const uint32_t p1 = (x >> 8) & 0xFFFFu;
-            const uint32_t p2 = x >> 16;
-            const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
-            *reinterpret_cast<uint2 *>(dst + imul(r, wcols) + 4 * qq) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Lattice nodes of one axis (executed by ONE wavefront; len <= 64).
 //   x_t = float(t - h) + centre  — the coordinate of patch row / column t, as basic_klt.cpp:127-130
 //   nodes: 0 = x_0 - 1, t + 1 = x_t, len + 1 = x_{len-1} + 1, then the extras.

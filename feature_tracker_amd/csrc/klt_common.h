@@ -1037,6 +1037,75 @@ __device__ __forceinline__ uint2 load_quad_pairs(const DevImage &im, int r_lo, i
     return make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
 }
 
+// Large-step / convergence bookkeeping shared by the three fast variants
+// (basic_klt_fast.cpp:49-60, affine_klt_fast.cpp:55-67, lssd_klt_fast.cpp:101-112).
+// Returns true when the iteration loop has to stop.
+__device__ __forceinline__ bool fast_step_logic(const KltParams &p, float squared_step, float &last_squared_step, uint32_t &large_step_cnt,
+                                                uint8_t &status) {
+    if (squared_step < last_squared_step) {
+        last_squared_step = squared_step;
+        large_step_cnt = 0;
+    } else {
+        ++large_step_cnt;
+        if (large_step_cnt >= p.max_large_step) {
+            return true;
+        }
+    }
+    if (squared_step < p.converge) {
+        status = FTK_TRACKED;
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window prefetch: raw 8-byte loads issued early, turned into pixel pairs and stored late.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct RawQuads {
+    uint32_t x[N], y[N];
+};
+
+template <int N>
+__device__ __forceinline__ void issue_quads(RawQuads<N> &q, const Blk &b, const DevImage &im, int r_lo, int c_lo, int wrows, int wcols,
+                                            uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    const int tid = opaque(b.tid);
+    const uint8_t *base = im.data + (long long)r_lo * im.cols + c_lo;  // wave-uniform: scalar base + 32-bit lane offset
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int idx = tid + k * b.nt;
+        idx = idx < total ? idx : 0;
+        const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+        const int qq = idx - imul(r, quads);
+        const uint8_t *src = base + (size_t)(unsigned)(r * im.cols + 4 * qq);
+        __builtin_memcpy(&q.x[k], src, 4);
+        __builtin_memcpy(&q.y[k], src + 4, 4);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void store_quads(const RawQuads<N> &q, const Blk &b, uint16_t *dst, int wrows, int wcols, uint32_t magic_quads) {
+    const int quads = wcols >> 2;
+    const int total = wrows * quads;
+    const int tid = opaque(b.tid);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int idx = tid + k * b.nt;
+        if (idx < total) {
+            const int r = (quads == 1) ? idx : (int)__umulhi((unsigned)idx, magic_quads);
+            const int qq = idx - imul(r, quads);
+            const uint32_t x = q.x[k], y = q.y[k];
+            const uint32_t p0 = x & 0xFFFFu;
+            const uint32_t p1 = (x >> 8) & 0xFFFFu;
+            const uint32_t p2 = x >> 16;
+            const uint32_t p3 = __builtin_amdgcn_alignbyte(y, x, 3) & 0xFFFFu;
+            *reinterpret_cast<uint2 *>(dst + imul(r, wcols) + 4 * qq) = make_uint2(p0 | (p1 << 16), p2 | (p3 << 16));
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------

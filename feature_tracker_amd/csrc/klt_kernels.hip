@@ -484,27 +484,6 @@ __device__ __forceinline__ bool ex_gradient(const KltParams &p, const float *ex,
     return false;
 }
 
-// Large-step / convergence bookkeeping shared by the three fast variants
-// (basic_klt_fast.cpp:49-60, affine_klt_fast.cpp:55-67, lssd_klt_fast.cpp:101-112).
-// Returns true when the iteration loop has to stop.
-__device__ __forceinline__ bool fast_step_logic(const KltParams &p, float squared_step, float &last_squared_step, uint32_t &large_step_cnt,
-                                                uint8_t &status) {
-    if (squared_step < last_squared_step) {
-        last_squared_step = squared_step;
-        large_step_cnt = 0;
-    } else {
-        ++large_step_cnt;
-        if (large_step_cnt >= p.max_large_step) {
-            return true;
-        }
-    }
-    if (squared_step < p.converge) {
-        status = FTK_TRACKED;
-        return true;
-    }
-    return false;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Basic KLT (translation only, 2x2)
 // ---------------------------------------------------------------------------------------------
@@ -1933,6 +1912,9 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p) {
     if (p.pb_enabled && model == FTK_MODEL_BASIC && method == FTK_METHOD_INVERSE) {
         return klt_basic_pipelined_lds_bytes(p);
     }
+    if (p.fk_enabled && method != FTK_METHOD_INVERSE && method != FTK_METHOD_DIRECT) {
+        return klt_fast_lds_bytes(model, p);
+    }
     const int k = chain_count(model);
     if (k == 0) {
         return 0;
@@ -1979,6 +1961,9 @@ hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t str
     }
     if (p.pb_enabled && model == FTK_MODEL_BASIC && method == FTK_METHOD_INVERSE) {
         return klt_basic_pipelined_launch(p, stream);
+    }
+    if (p.fk_enabled && method != FTK_METHOD_INVERSE && method != FTK_METHOD_DIRECT) {
+        return klt_fast_launch(model, p, stream);
     }
     const size_t lds = klt_lds_bytes(model, method, p);
     KltParams pg = p;

@@ -370,6 +370,17 @@ def main():
                                                    ("match_config4_nearby_raster_order", 10000, 10000, True, True)):
             print(json.dumps(matcher_case(name, n_ref, n_cur, nearby, torch, F, D, synth, oracle, reps, 4_000_000, raster)), flush=True)
         return
+    if args.only.startswith("fast"):
+        # the reference's default method on every model, at a front end's sizes and at the BASELINE sizes; "fast:basic" etc. narrows it
+        want = args.only.split(":")[1] if ":" in args.only else ""
+        for model in ("basic", "affine", "lssd"):
+            if want and model != want:
+                continue
+            for n, half, levels in ((300, 6, 4), (2000, 6, 4), (2000, 10, 4), (10000, 6, 4)):
+                c = dict(synth.CONFIGS["config2"])
+                c.update(model=model, method="fast", half=half, n=n, levels=levels)
+                print(json.dumps(klt_case(f"fast/{model}/{n}x{2 * half + 1}", c, torch, F, D, synth, oracle, reps, 1)), flush=True)
+        return
     cases = []
     for key in ("config1", "config2", "config3", "config4", "config5_shard"):
         cases.append((key, dict(synth.CONFIGS[key])))
