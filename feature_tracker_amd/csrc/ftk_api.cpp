@@ -316,7 +316,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
-    if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && !p.consider_luminance && !(chunk_env && atoi(chunk_env) == 0)) {
+    // (with consider_patch_luminance: the variant that keeps the sampled values in registers — patches up to 512 pixels, klt_kernels.hip kLumChunks)
+    if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && (!p.consider_luminance || (p.P <= 512 && !p.tree)) && !(chunk_env && atoi(chunk_env) == 0)) {
         p.lssd_chunked = 1;
         p.px_floats = 6;
         const int32_t epad = (p.E + 3) & ~3;

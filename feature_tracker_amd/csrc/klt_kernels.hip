@@ -1593,6 +1593,184 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
     }
 }
 
+// The same level with consider_patch_luminance (lssd_klt_fast.cpp:27-46, 65-78): the reference patch and its gradients are divided by
+// the reference mean once per level, the current patch by its mean in every iteration — a SECOND exact-order sum per iteration (one
+// lane: the interior of the sampled patch, row-major) in front of the nine.  Chunked like the level above: pass 1 samples chunk by
+// chunk, keeps each lane's values in REGISTERS (a lane owns the pixels lane, lane + 64, ...: at most kLumChunks of them) and chains
+// the mean through ring row 0; pass 2 divides, forms the nine products and chains them.  The quirks of the reference are kept:
+// the reference mean's numerator covers the interior of the EXTENDED patch (= the patch) and its denominator the valid count of the
+// whole extended patch; the current mean's numerator covers patch rows / columns 1 .. size - 2 only and its denominator every valid
+// pixel.  Same expressions, same order of every sum as lssd_level_fast: bit-identical.
+constexpr int kLumChunks = 8;  // 64-pixel chunks a lane can keep values for: patches up to 512 pixels (ftk_api.cpp gates on it)
+
+__device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const KltParams &p, const DevImage &ref, const DevImage &cur, float ref_u,
+                                                            float ref_v, LssdState &s, uint8_t &status, uint32_t &iters, Carve &c) {
+    c.a0 = c.terms;
+    float *ex = c.a0;
+    uint8_t *exv = c.flagsE;
+    float *ring = c.terms;  // [9][kChunkRow]
+    float4 *rec = reinterpret_cast<float4 *>(c.a1);
+    float2 *rc = reinterpret_cast<float2 *>(c.a1 + 4 * p.Ppad);
+    Win rw, cw;
+    float level_centre_u, level_centre_v;
+    se2_apply(s, ref_u, ref_v, level_centre_u, level_centre_v);
+    stage_level_windows(b, p, ref, cur, ref_u, ref_v, level_centre_u, level_centre_v, c, rw, cw);
+    bool cw_staged = true;
+    const uint32_t ref_valid_num = extract_extended_patch(b, p, ref, rw, ref_u, ref_v, c);
+    if (ref_valid_num == 0) {
+        status = FTK_OUTSIDE;
+        return;
+    }
+    // :27-35 — the reference mean: the interior of the extended patch in row-major order (== the P patch pixels), summed by lane 0
+    // from a contiguous row laid over the (not yet written) per-pixel records
+    float *row = c.a1;
+    for (int pxi = b.tid; pxi < p.Ppad; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi < p.P ? pxi : 0, prow, pcol);
+        row[pxi] = pxi < p.P ? ex[imul(prow + 1, p.ex_cols) + pcol + 1] : 0.0f;
+    }
+    blk_sync(b);
+    float ref_sum = 0.0f;
+    if (b.lane == 0) {
+        ref_sum = chain_lane(row, p.Ppad);
+    }
+    const float ref_average = uniform_lane(ref_sum, 0) / (float)ref_valid_num;
+    blk_sync(b);
+    for (int pxi = b.tid; pxi < p.P; pxi += b.nt) {
+        int prow, pcol;
+        pixel_rc(p, pxi, prow, pcol);
+        float dx, dy;
+        ex_gradient(p, ex, exv, prow, pcol, dx, dy);
+        const int ei = imul(prow, p.ex_cols) + pcol + (p.ex_cols + 1);
+        // :37-46 — dx, dy and the patch value are each divided by the mean (the gradients are differences of UNSCALED values)
+        rec[pxi] = make_float4(dx / ref_average, dy / ref_average, ex[ei] / ref_average, __int_as_float(exv[ei] != 0 ? -1 : 0));
+        rc[pxi] = make_float2((float)(prow - p.half_rows) + ref_v, (float)(pcol - p.half_cols) + ref_u);
+    }
+    blk_sync(b);
+
+    status = FTK_LARGE_RESIDUAL;
+    float last_squared_step = INFINITY;
+    uint32_t large_step_cnt = 0;
+    const int n_chunks = (p.P + kChunkPixels - 1) / kChunkPixels;
+    for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
+        ++iters;
+        float centre_u, centre_v;
+        se2_apply(s, ref_u, ref_v, centre_u, centre_v);
+        ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
+        const int min_row = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_v)), -p.patch_rows);
+        const int min_col = wadd(__builtin_amdgcn_readfirstlane(f2i(centre_u)), -p.patch_cols);
+        const int max_row = wadd(min_row, p.patch_rows * 2);
+        const int max_col = wadd(min_col, p.patch_cols * 2);
+        const bool partly_outside = (min_row < 0 || max_row > cur.rows - 2 || min_col < 0 || max_col > cur.cols - 2);
+        // ---- pass 1: ExtractPatchInCurrentImage (:145-195) + the mean's numerator (:65-71) ----
+        float val[kLumChunks];
+        uint32_t ok_mask = 0;  // bit k: this lane's pixel of chunk k was sampled inside the image
+        uint32_t cur_valid_num = 0;
+        float mean_acc = 0.0f;
+#pragma unroll
+        for (int chunk = 0; chunk < kLumChunks; ++chunk) {
+            val[chunk] = 0.0f;
+            if (chunk < n_chunks) {
+                const int pxi = chunk * kChunkPixels + b.lane;
+                const bool in = pxi < p.P;
+                const int pp = in ? pxi : 0;
+                const float2 rci = rc[pp];
+                float row_j, col_j;
+                se2_apply(s, rci.y, rci.x, col_j, row_j);
+                float value = 0.0f;
+                bool ok_cur;
+                if (partly_outside) {
+                    ok_cur = sample(cur, cw, row_j, col_j, value);
+                    if (!ok_cur) {
+                        value = 0.0f;
+                    }
+                } else {
+                    const bool roomy = (unsigned)__float_as_int(row_j) <= (unsigned)__float_as_int((float)(cur.rows - 2)) &&
+                                       (unsigned)__float_as_int(col_j) <= (unsigned)__float_as_int((float)(cur.cols - 2));
+                    if (wave_ballot(!roomy) == 0ull) {
+                        value = bilinear_inside(cur, cw, row_j, col_j);
+                    } else {
+                        value = bilinear(cur, cw, row_j, col_j);
+                    }
+                    ok_cur = true;
+                }
+                ok_cur = ok_cur && in;
+                int prow, pcol;
+                pixel_rc(p, pp, prow, pcol);
+                const bool interior = in && prow >= 1 && prow < p.patch_rows - 1 && pcol >= 1 && pcol < p.patch_cols - 1;
+                val[chunk] = value;
+                ok_mask |= ok_cur ? (1u << chunk) : 0u;
+                cur_valid_num += (uint32_t)__popcll(wave_ballot(ok_cur));
+                ring[b.lane] = interior ? value : 0.0f;
+                blk_sync(b);
+                if (b.lane == 0) {
+                    mean_acc = chain_chunk(mean_acc, ring);
+                }
+                blk_sync(b);
+            }
+        }
+        if (cur_valid_num == 0) {
+            break;  // :60-63
+        }
+        const float cur_average = uniform_lane(mean_acc, 0) / (float)cur_valid_num;
+        // ---- pass 2: the scaled patch (:72-78) and ComputeHessianAndBias (:197-229) ----
+        bool seen_valid = false;
+        float acc = 0.0f;
+#pragma unroll
+        for (int chunk = 0; chunk < kLumChunks; ++chunk) {
+            if (chunk < n_chunks) {
+                const int pxi = chunk * kChunkPixels + b.lane;
+                const int pp = pxi < p.P ? pxi : 0;
+                const float2 rci = rc[pp];
+                const float4 px4 = rec[pp];
+                const float row_i = rci.x, col_i = rci.y;
+                const bool ok = __float_as_int(px4.w) != 0 && ((ok_mask >> chunk) & 1u) != 0u;
+                const float scaled = val[chunk] / cur_average;
+                const float s0 = s.r00 * (-row_i) + s.r01 * col_i;
+                const float s1 = s.r10 * (-row_i) + s.r11 * col_i;
+                // an unused pixel contributes exact zeros to every sum: its factors are zeroed (lssd_level_fast_chunked)
+                const float dx = ok ? px4.x : 0.0f, dy = ok ? px4.y : 0.0f;
+                const float j0 = ok ? px4.x * s0 + px4.y * s1 : 0.0f;
+                const float residual = ok ? scaled - px4.z : 0.0f;
+                ring[0 * kChunkRow + b.lane] = j0 * j0;
+                ring[1 * kChunkRow + b.lane] = j0 * dx;
+                ring[2 * kChunkRow + b.lane] = j0 * dy;
+                ring[3 * kChunkRow + b.lane] = dx * dx;
+                ring[4 * kChunkRow + b.lane] = dx * dy;
+                ring[5 * kChunkRow + b.lane] = dy * dy;
+                ring[6 * kChunkRow + b.lane] = -(j0 * residual);
+                ring[7 * kChunkRow + b.lane] = -(dx * residual);
+                ring[8 * kChunkRow + b.lane] = -(dy * residual);
+                seen_valid = seen_valid || ok;
+                blk_sync(b);
+                if (b.lane < 9) {
+                    acc = chain_chunk(acc, ring + b.lane * kChunkRow);
+                }
+                blk_sync(b);
+            }
+        }
+        if (wave_ballot(seen_valid) == 0ull) {
+            break;  // :80-83
+        }
+        const int acc_bits = __float_as_int(acc);
+        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
+        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
+        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5));
+        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7)),
+                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8))};
+        float v[3];
+        ldlt3_solve<true>(h00, h01, h02, h11, h12, h22, bb, v, b.lane);
+        if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
+            status = FTK_NUMERIC_ERROR;
+            break;
+        }
+        se2_update<true>(s, v, b.lane);
+        if (fast_step_logic(p, vec3_squared_norm(v), last_squared_step, large_step_cnt, status)) {
+            break;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-feature driver: TrackMultipleLevel / TrackSingleLevel of the three trackers
 // (basic_klt.cpp:7-86, affine_klt.cpp:6-91, lssd_klt.cpp:7-94).
@@ -1637,7 +1815,9 @@ constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest firs
 // instantiations contain none of its code: the chain helpers and the chunked LSSD level sum by per-lane partials + a butterfly
 // instead of in the reference's order.  The non-fast affine variants ignore it (their 24 sums of 169 terms already run as 24
 // parallel chains; a butterfly over so few pixels is not faster) and stay exact.  Run-time geometry only (H == 0).
-template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false>
+// LUM: the chunked LSSD-fast level with consider_patch_luminance (its own instantiations, so that the plain chunked level keeps its
+// register count: the luminance form holds a lane's sampled values across its two passes).
+template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false, bool LUM = false>
 __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument: a local copy whose arrays are indexed
     // with a run-time level would live in scratch memory
@@ -1789,7 +1969,9 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
             }
         } else {
             if (METHOD == FTK_METHOD_FAST) {
-                if (SOLO && p.lssd_chunked) {
+                if constexpr (LUM) {
+                    lssd_level_fast_chunked_lum(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
+                } else if (SOLO && p.lssd_chunked) {
                     lssd_level_fast_chunked(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
                 } else {
                     lssd_level_fast(b, p, ref, cur, ref_u, ref_v, ls, status, iters, c);
@@ -1876,6 +2058,12 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
             if (check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols && check.Ppad == p.Ppad && check.rwin_cols == p.rwin_cols) {
                 kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 6> : klt_track_kernel<MODEL, METHOD, false, 6>;
             }
+        }
+    }
+    if constexpr (MODEL == FTK_MODEL_LSSD && METHOD == FTK_METHOD_FAST) {
+        if (p.waves_per_feature == 1 && p.lssd_chunked && p.consider_luminance && !p.tree) {
+            const bool h6 = kernel == klt_track_kernel<MODEL, METHOD, true, 6>;
+            kernel = h6 ? klt_track_kernel<MODEL, METHOD, true, 6, false, true> : klt_track_kernel<MODEL, METHOD, true, 0, false, true>;
         }
     }
     const unsigned sort_block = p.sort_iters ? 1u : 0u;  // one more workgroup: the sort of a later call's launch order
