@@ -284,7 +284,12 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // One wave walks all P pixels of every pass: up to 15 x 15 that beats the generic kernel's 2 - 4 waves at every feature count
     // (2 000 x 13 x 13: 22.6 vs 27.5 us; 10 000: 58.6 vs 82.9 us); larger patches only where the call is throughput-bound anyway
     // (2 000 x 21 x 21: 77.8 vs 54.4 us on two waves).
-    if (model == FTK_MODEL_BASIC && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && !p.tree && (p.P <= 256 || (n > 2048 && p.P <= 1024))) {
+    // The affine tracker's fast method runs on the same skeleton (the first iteration of a level sweeps and chains 64-pixel chunks
+    // through a ring, the later ones six whole rows) from 512 features on: 13 x 13, same box, one wave / generic kernel: 1 000
+    // features 34.7 / 36.9 us, 2 000: 77.0 / 83.6, 3 000: 66.0 / 108.3, 5 000: 80.5 / 128.9 — and 100: 83.8 / 75.0, 300: 56.9 / 53.4:
+    // a small call IS its slowest feature (31 iterations here), and that one runs 10 % faster on the generic kernel's three waves.
+    const bool fk_model = model == FTK_MODEL_BASIC || (model == FTK_MODEL_AFFINE && n > 512);
+    if (fk_model && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && !p.tree && (p.P <= 256 || (n > 2048 && p.P <= 1024))) {
         bool small = true;
         for (int i = 0; i < p.n_levels; ++i) {
             small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);

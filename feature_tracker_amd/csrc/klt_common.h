@@ -739,6 +739,45 @@ __device__ __forceinline__ void ldlt6_solve(const Ldlt6 &f, const float *b_lds, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Affine KLT (6x6).  Chain indices of the 18 distinct Hessian product sequences + 6 bias ones.
+// H(1,2) = H(0,3), H(1,4) = H(0,5) are the same products; H(3,4) is yy*dxdy as in the reference
+// (affine_klt.cpp:245, sic), i.e. the same sequence as H(2,3).
+// ---------------------------------------------------------------------------------------------
+enum {
+    A_XX_DXDX, A_XX_DXDY, A_XY_DXDX, A_XY_DXDY, A_X_DXDX, A_X_DXDY, A_XX_DYDY, A_XY_DYDY, A_X_DYDY, A_YY_DXDX, A_YY_DXDY, A_Y_DXDX, A_Y_DXDY,
+    A_YY_DYDY, A_Y_DYDY, A_DXDX, A_DXDY, A_DYDY, A_B0, A_B1, A_B2, A_B3, A_B4, A_B5, A_COUNT
+};
+
+// Where chain lane s < 18 stores its sum in the dense row-major 6 x 6 Hessian (H(1,2) = H(0,3), H(1,4) = H(0,5), H(3,4) = H(2,3): the
+// aliases of affine_klt.cpp:264-270 and the (sic) of :245): up to four entries e = 6 i + j per sum, one byte each (sums with fewer
+// entries repeat one).  Row i of chain indices: 0 1 2 3 4 5 | 1 6 3 7 5 8 | 2 3 9 10 11 12 | 3 7 10 13 10 14 | 4 5 11 10 15 16 | 5 8 12 14 16 17.
+__device__ __forceinline__ uint32_t affine_dense_slots(int sum) {
+    constexpr uint32_t kSlots[18] = {
+        0x00000000u | 0u * 0x01010101u,                           //  0: H00
+        1u | 6u << 8 | 1u << 16 | 6u << 24,                       //  1: H01 H10
+        2u | 12u << 8 | 2u << 16 | 12u << 24,                     //  2: H02 H20
+        3u | 18u << 8 | 8u << 16 | 13u << 24,                     //  3: H03 H30 H12 H21
+        4u | 24u << 8 | 4u << 16 | 24u << 24,                     //  4: H04 H40
+        5u | 30u << 8 | 10u << 16 | 25u << 24,                    //  5: H05 H50 H14 H41
+        7u * 0x01010101u,                                         //  6: H11
+        9u | 19u << 8 | 9u << 16 | 19u << 24,                     //  7: H13 H31
+        11u | 31u << 8 | 11u << 16 | 31u << 24,                   //  8: H15 H51
+        14u * 0x01010101u,                                        //  9: H22
+        15u | 20u << 8 | 22u << 16 | 27u << 24,                   // 10: H23 H32 H34 H43
+        16u | 26u << 8 | 16u << 16 | 26u << 24,                   // 11: H24 H42
+        17u | 32u << 8 | 17u << 16 | 32u << 24,                   // 12: H25 H52
+        21u * 0x01010101u,                                        // 13: H33
+        23u | 33u << 8 | 23u << 16 | 33u << 24,                   // 14: H35 H53
+        28u * 0x01010101u,                                        // 15: H44
+        29u | 34u << 8 | 29u << 16 | 34u << 24,                   // 16: H45 H54
+        35u * 0x01010101u,                                        // 17: H55
+    };
+    return kSlots[sum < 18 ? sum : 17];
+}
+// chain lanes that hold the diagonal H(j, j), j = 0..5
+constexpr int kAffineDiagLane[6] = {A_XX_DXDX, A_XX_DYDY, A_YY_DXDX, A_YY_DYDY, A_DXDX, A_DYDY};
+
 // Phase B: lane k < K of wave 0 adds terms[k][0..Ppad) strictly left to right and publishes the sum.
 // The adds form one dependent chain (that IS the reference's order); the LDS reads are software
 // pipelined one round (8 x ds_read_b128 = 32 terms) ahead in two ping-pong register sets, pinned

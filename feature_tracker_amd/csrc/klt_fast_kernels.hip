@@ -16,6 +16,13 @@
 //     products, in one pass of the same dependent adds (the sums are formed in the reference's row-major order either way);
 //   * the per-pixel record {dx, dy, reference value, usable} is one 16-byte LDS read per pixel and iteration.
 //
+// The affine tracker's fast method (affine_klt_fast.cpp:7-188) runs on the same skeleton: the level entry is the same extended patch;
+// an iteration samples the current image at the WARPED patch positions (per-pixel bilinear weights, LDS window with a global-memory
+// path for taps that left it), forms six bias products per pixel, and the 18 Hessian products (anchored at the level-entry position,
+// :95-96) ride on the first iteration.  Its 24 sums do not fit a feature's LDS share as whole rows (24 x P floats), so sweep and
+// chain alternate over 64-pixel CHUNKS through a one-slot ring [24][64 + 4] — the same products in the same order on the same
+// lanes; the 6 x 6 LDLT is factored once per level on lanes 0 - 5 (ldlt6_factor_diag) and every iteration runs the substitutions.
+//
 // Arithmetic contract as in klt_kernels.hip: IEEE fp32, no contraction, correctly rounded division, every sum strictly in
 // row-major pixel order on one lane.  Results are bit-identical to the generic kernel and to the oracle (tests/test_klt_gpu.py).
 #define FTK_CHAIN_ROUND 4
@@ -36,28 +43,44 @@ __host__ __device__ inline int fk_pad4(int x) { return (x + 3) & ~3; }
 // fall on five different groups of four banks
 __host__ __device__ inline int fk_term_pitch(const KltParams &p) { return (p.Ppad & 7) == 4 ? p.Ppad : p.Ppad + 4; }
 
+constexpr int kAfRows = 24;     // rows of the affine ring: 0 - 5 the bias products (every iteration), 6 + A_* the 18 Hessian products (first iteration)
+constexpr int kAfSumFloats = 56;  // [0, 36) the dense 6 x 6 Hessian the factorisation reads, [40, 46) the bias sums, [48, 54) the solution
+
 struct FkLds {
-    float4 *rec;        // [Ppad] {dx, dy, extended patch at the pixel, usable (int bits: -1 / 0)}
-    float *terms;       // [kFkTerms][pitch]
+    float4 *rec;        // [Ppad] {dx, dy, extended patch at the pixel, flags (int bits; Basic: -1 / 0 = usable; affine: bit 0 usable, bit 1 has a gradient)}
+    float *terms;       // Basic: [kFkTerms][pitch]; affine: the ring [kAfRows][kChunkRow]
+    float *sums;        // affine only: kAfSumFloats
     float *ex;          // [Epad] extended reference patch (level entry only); an element outside the image holds kFkInvalid
     uint16_t *ref_win;  // rwin_rows x rwin_cols pixel pairs
     uint16_t *cur_win;  // cwin_rows x cwin_cols pixel pairs
 };
 
-__host__ __device__ inline size_t fk_lds_bytes(const KltParams &p) {
+__host__ __device__ inline size_t fk_terms_floats(int model, const KltParams &p) {
+    // + what the chain's prefetch may read past the last row
+    if (model == FTK_MODEL_AFFINE) {
+        // the ring of the first iteration, or the six whole bias rows of the later ones (larger from 17 x 17 on), in the same space
+        const size_t ring = (size_t)kAfRows * kChunkRow, rows = 6 * (size_t)fk_term_pitch(p);
+        return (ring > rows ? ring : rows) + 16 * FTK_CHAIN_ROUND + kAfSumFloats;
+    }
+    return (size_t)kFkTerms * fk_term_pitch(p) + 16 * FTK_CHAIN_ROUND;
+}
+
+__host__ __device__ inline size_t fk_lds_bytes(int model, const KltParams &p) {
     size_t bytes = 16 * (size_t)p.Ppad;
-    bytes += 4 * (size_t)kFkTerms * fk_term_pitch(p) + 4 * 16 * FTK_CHAIN_ROUND;  // + what the chain's prefetch may read past the last row
+    bytes += 4 * fk_terms_floats(model, p);
     bytes += 4 * (size_t)(p.ex_rows * 4 * ((p.ex_cols + 3) >> 2));  // the extended patch, rows of whole quads
     bytes += 2 * (size_t)fk_pad4(p.rwin_rows * p.rwin_cols);
     bytes += 2 * (size_t)fk_pad4(p.cwin_rows * p.cwin_cols);
     return (bytes + 15) & ~(size_t)15;
 }
 
+template <int MODEL>
 __device__ __forceinline__ FkLds fk_carve(float4 *base, const KltParams &p) {
     FkLds c;
     c.rec = base;
     c.terms = reinterpret_cast<float *>(c.rec + p.Ppad);
-    c.ex = c.terms + kFkTerms * fk_term_pitch(p) + 16 * FTK_CHAIN_ROUND;
+    c.sums = c.terms + fk_terms_floats(FTK_MODEL_AFFINE, p) - kAfSumFloats;  // (behind the rows' prefetch slack; affine only)
+    c.ex = c.terms + fk_terms_floats(MODEL, p);
     c.ref_win = reinterpret_cast<uint16_t *>(c.ex + p.ex_rows * 4 * ((p.ex_cols + 3) >> 2));
     c.cur_win = c.ref_win + fk_pad4(p.rwin_rows * p.rwin_cols);
     return c;
@@ -205,9 +228,10 @@ __device__ __forceinline__ void fk_touch_kernarg() {
     asm volatile("" ::"s"(sink));
 }
 
+// MODEL: FTK_MODEL_BASIC or FTK_MODEL_AFFINE.
 // HR / HC: the half patch sizes as compile-time constants (the geometry folds into immediates), or 0 / 0 for "as passed".
-template <int HR, int HC>
-__global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_fast_kernel(const KltParams p_arg) {
+template <int MODEL, int HR, int HC>
+__global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_fast_kernel(const KltParams p_arg) {
 #ifdef FTK_STAMPS
     const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -265,7 +289,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         }
         return;
     }
-    const FkLds c = fk_carve(lds_raw + (size_t)group_slot * (p.group_lds_stride >> 4), p);
+    const FkLds c = fk_carve<MODEL>(lds_raw + (size_t)group_slot * (p.group_lds_stride >> 4), p);
     const int pitch = fk_term_pitch(p);
     const int exp = fk_ex_pitch(p);
 
@@ -276,6 +300,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     float ref_v = p.single_level ? full_ref_v : full_ref_v / scale;
     float cur_u = p.single_level ? in_u : in_u / scale;
     float cur_v = p.single_level ? in_v : in_v / scale;
+    // affine_klt.cpp:21,70: the warp starts from the identity on the pyramid path, from the prediction on the single-level one;
+    // it is carried unchanged from level to level
+    float a00 = p.single_level ? p.prior[0] : 1.0f, a01 = p.single_level ? p.prior[1] : 0.0f;
+    float a10 = p.single_level ? p.prior[2] : 0.0f, a11 = p.single_level ? p.prior[3] : 1.0f;
 
     const int rrows = p.rwin_rows, rcols = p.rwin_cols;
     const bool cur_fits = p.cwin_rows * (p.cwin_cols >> 2) <= kFkCurQuads * kWave;
@@ -308,15 +336,20 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             RawQuads<kFkCurQuads> qc;
             issue_quads(qc, b, cur, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwq);
             // the zero padding of the term rows (pixels P .. pitch - 1 are never written again) while the loads fly
-            for (int idx = lane; idx < kFkTerms * (pitch - p.P); idx += kWave) {
-                const int k = idx / (pitch - p.P);
-                c.terms[k * pitch + p.P + (idx - k * (pitch - p.P))] = 0.0f;
+            // (the affine ring has none: every sweep writes all 64 columns of the rows it chains)
+            if constexpr (MODEL == FTK_MODEL_BASIC) {
+                for (int idx = lane; idx < kFkTerms * (pitch - p.P); idx += kWave) {
+                    const int k = idx / (pitch - p.P);
+                    c.terms[k * pitch + p.P + (idx - k * (pitch - p.P))] = 0.0f;
+                }
             }
             store_quads(qc, b, c.cur_win, cw.rows, cw.cols, p.magic_cwq);
         } else {
-            for (int idx = lane; idx < kFkTerms * (pitch - p.P); idx += kWave) {
-                const int k = idx / (pitch - p.P);
-                c.terms[k * pitch + p.P + (idx - k * (pitch - p.P))] = 0.0f;
+            if constexpr (MODEL == FTK_MODEL_BASIC) {
+                for (int idx = lane; idx < kFkTerms * (pitch - p.P); idx += kWave) {
+                    const int k = idx / (pitch - p.P);
+                    c.terms[k * pitch + p.P + (idx - k * (pitch - p.P))] = 0.0f;
+                }
             }
             stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
         }
@@ -398,135 +431,364 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
             level_runs = false;
         }
         if (level_runs) {
-            // ---- PrecomputeJacobianAndHessian (basic_klt_fast.cpp:64-99): dx = dy = 0 where a 4-neighbour is missing ----
+            if constexpr (MODEL == FTK_MODEL_BASIC) {
+                // ---- PrecomputeJacobianAndHessian (basic_klt_fast.cpp:64-99): dx = dy = 0 where a 4-neighbour is missing ----
 #pragma unroll 4
-            for (int pass = 0; pass < n_pass; ++pass) {
-                const int pxi = pass * kWave + lane;
-                if (pxi < p.P) {
-                    int prow, pcol;
-                    pixel_rc(p, pxi, prow, pcol);
-                    const int ei = imul(prow + 1, exp) + pcol + 1;
-                    // five independent reads, no branch: the sign bits ARE the validity flags
-                    const float e_l = c.ex[ei - 1], e_r = c.ex[ei + 1], e_t = c.ex[ei - exp], e_b = c.ex[ei + exp], e_c = c.ex[ei];
-                    float dx = e_r - e_l, dy = e_b - e_t;
-                    int usable = -1;
-                    if (!all_ref_valid) {  // wave-uniform
-                        const bool grad = (__float_as_int(e_l) | __float_as_int(e_r) | __float_as_int(e_t) | __float_as_int(e_b)) >= 0;
-                        dx = grad ? dx : 0.0f;
-                        dy = grad ? dy : 0.0f;
-                        usable = __float_as_int(e_c) >= 0 ? -1 : 0;
-                    }
-                    c.rec[pxi] = make_float4(dx, dy, e_c, __int_as_float(usable));
-                    c.terms[2 * pitch + pxi] = dx * dx;
-                    c.terms[3 * pitch + pxi] = dx * dy;
-                    c.terms[4 * pitch + pxi] = dy * dy;
-                }
-            }
-            fk_fence();
-            FTK_STAMP_END(b, 2);
-            status = FTK_LARGE_RESIDUAL;  // basic_klt_fast.cpp:29
-            float last_squared_step = INFINITY;
-            uint32_t large_step_cnt = 0;
-            Ldlt2 fac = {0.0f, 0.0f, 0.0f, false};
-            for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
-                ++iters;
-                FTK_STAMP_BEGIN(b);
-                if (!win_covers(cw, cur_u, cur_v)) {
-                    // the patch has left the window (or the integer test has to decide): restage around the present position
-                    int need_r, need_c;
-                    footprint_origin(p, cur_u, cur_v, need_r, need_c);
-                    const long long nr = need_r, nc = need_c;
-                    const bool covered = nr >= (long long)cw.r_lo && nr + (2 * p.half_rows + 4) <= (long long)cw.r_lo + cw.rows &&
-                                         nc >= (long long)cw.c_lo && nc + (2 * p.half_cols + 4) <= (long long)cw.c_lo + cw.cols + 1;
-                    if (!covered) {
-                        cw.r_lo = wadd(need_r, -p.cwin_margin);
-                        cw.c_lo = wadd(need_c, -p.cwin_margin);
-                        win_set_cover(p, cw);
-                        stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
-                        fk_fence();
-                    }
-                }
-                // ---- ComputeBias (basic_klt_fast.cpp:101-195): integer lattice floor(cur) - patch / 2, one weight set ----
-                const float int_row = floorf(cur_v), int_col = floorf(cur_u);
-                const float dec_row = cur_v - int_row, dec_col = cur_u - int_col;
-                const float w_tl = (1.0f - dec_row) * (1.0f - dec_col);
-                const float w_tr = (1.0f - dec_row) * dec_col;
-                const float w_bl = dec_row * (1.0f - dec_col);
-                const float w_br = dec_row * dec_col;
-                const int min_row = __builtin_amdgcn_readfirstlane(wadd(f2i(int_row), -(p.patch_rows / 2)));
-                const int min_col = __builtin_amdgcn_readfirstlane(wadd(f2i(int_col), -(p.patch_cols / 2)));
-                const int rel_r = (int)((unsigned)min_row - (unsigned)cw.r_lo), rel_c = (int)((unsigned)min_col - (unsigned)cw.c_lo);
-                // the whole lattice (+ 1 neighbours) inside the image: no per-pixel bounds test (wave-uniform)
-                const bool all_inside = min_row >= 0 && (long long)min_row + p.patch_rows - 1 <= (long long)cur.rows - 2 && min_col >= 0 &&
-                                        (long long)min_col + p.patch_cols - 1 <= (long long)cur.cols - 2;
-                uint32_t n_valid = 0;
-                if (all_inside && all_ref_valid) {
-                    // the usual case: every pixel is used — no selects, no counts (the window covers the lattice: win_covers above)
-                    const int rel = imul(rel_r, cw.cols) + rel_c;
-#pragma unroll 4
-                    for (int pass = 0; pass < n_pass; ++pass) {
-                        const int pxi = pass * kWave + lane;
-                        if (pxi < p.P) {
-                            int prow, pcol;
-                            pixel_rc(p, pxi, prow, pcol);
-                            const float4 rec = c.rec[pxi];
-                            const float i_cur = win_bilinear(c.cur_win, cw.cols, rel + imul(prow, cw.cols) + pcol, w_tl, w_tr, w_bl, w_br);
-                            const float dt = i_cur - rec.z;
-                            c.terms[pxi] = -(rec.x * dt);
-                            c.terms[pitch + pxi] = -(rec.y * dt);
+                for (int pass = 0; pass < n_pass; ++pass) {
+                    const int pxi = pass * kWave + lane;
+                    if (pxi < p.P) {
+                        int prow, pcol;
+                        pixel_rc(p, pxi, prow, pcol);
+                        const int ei = imul(prow + 1, exp) + pcol + 1;
+                        // five independent reads, no branch: the sign bits ARE the validity flags
+                        const float e_l = c.ex[ei - 1], e_r = c.ex[ei + 1], e_t = c.ex[ei - exp], e_b = c.ex[ei + exp], e_c = c.ex[ei];
+                        float dx = e_r - e_l, dy = e_b - e_t;
+                        int usable = -1;
+                        if (!all_ref_valid) {  // wave-uniform
+                            const bool grad = (__float_as_int(e_l) | __float_as_int(e_r) | __float_as_int(e_t) | __float_as_int(e_b)) >= 0;
+                            dx = grad ? dx : 0.0f;
+                            dy = grad ? dy : 0.0f;
+                            usable = __float_as_int(e_c) >= 0 ? -1 : 0;
                         }
-                    }
-                    n_valid = (uint32_t)p.P;
-                } else {
-#pragma unroll 2
-                    for (int pass = 0; pass < n_pass; ++pass) {
-                        const int pxi = pass * kWave + lane;
-                        bool ok = false;
-                        if (pxi < p.P) {
-                            int prow, pcol;
-                            pixel_rc(p, pxi, prow, pcol);
-                            const float4 rec = c.rec[pxi];
-                            const int lr = rel_r + prow, lc = rel_c + pcol;
-                            const bool in_win = (unsigned)lr < (unsigned)(cw.rows - 1) && (unsigned)lc < (unsigned)cw.cols;  // always, for a pixel inside the image
-                            const int row = wadd(min_row, prow), col = wadd(min_col, pcol);
-                            const bool in_img = !(row < 0 || row > cur.rows - 2 || col < 0 || col > cur.cols - 2);
-                            ok = in_img && in_win && __float_as_int(rec.w) != 0;
-                            const float i_cur = win_bilinear(c.cur_win, cw.cols, in_win ? imul(lr, cw.cols) + lc : 0, w_tl, w_tr, w_bl, w_br);
-                            const float dt = i_cur - rec.z;
-                            c.terms[pxi] = ok ? -(rec.x * dt) : 0.0f;
-                            c.terms[pitch + pxi] = ok ? -(rec.y * dt) : 0.0f;
-                        }
-                        n_valid += (uint32_t)__popcll(wave_ballot(ok));
+                        c.rec[pxi] = make_float4(dx, dy, e_c, __int_as_float(usable));
+                        c.terms[2 * pitch + pxi] = dx * dx;
+                        c.terms[3 * pitch + pxi] = dx * dy;
+                        c.terms[4 * pitch + pxi] = dy * dy;
                     }
                 }
                 fk_fence();
-                FTK_STAMP_END(b, 3);
-                if (n_valid == 0) {
-                    break;  // basic_klt_fast.cpp:40-42
+                FTK_STAMP_END(b, 2);
+                status = FTK_LARGE_RESIDUAL;  // basic_klt_fast.cpp:29
+                float last_squared_step = INFINITY;
+                uint32_t large_step_cnt = 0;
+                Ldlt2 fac = {0.0f, 0.0f, 0.0f, false};
+                for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
+                    ++iters;
+                    FTK_STAMP_BEGIN(b);
+                    if (!win_covers(cw, cur_u, cur_v)) {
+                        // the patch has left the window (or the integer test has to decide): restage around the present position
+                        int need_r, need_c;
+                        footprint_origin(p, cur_u, cur_v, need_r, need_c);
+                        const long long nr = need_r, nc = need_c;
+                        const bool covered = nr >= (long long)cw.r_lo && nr + (2 * p.half_rows + 4) <= (long long)cw.r_lo + cw.rows &&
+                                             nc >= (long long)cw.c_lo && nc + (2 * p.half_cols + 4) <= (long long)cw.c_lo + cw.cols + 1;
+                        if (!covered) {
+                            cw.r_lo = wadd(need_r, -p.cwin_margin);
+                            cw.c_lo = wadd(need_c, -p.cwin_margin);
+                            win_set_cover(p, cw);
+                            stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
+                            fk_fence();
+                        }
+                    }
+                    // ---- ComputeBias (basic_klt_fast.cpp:101-195): integer lattice floor(cur) - patch / 2, one weight set ----
+                    const float int_row = floorf(cur_v), int_col = floorf(cur_u);
+                    const float dec_row = cur_v - int_row, dec_col = cur_u - int_col;
+                    const float w_tl = (1.0f - dec_row) * (1.0f - dec_col);
+                    const float w_tr = (1.0f - dec_row) * dec_col;
+                    const float w_bl = dec_row * (1.0f - dec_col);
+                    const float w_br = dec_row * dec_col;
+                    const int min_row = __builtin_amdgcn_readfirstlane(wadd(f2i(int_row), -(p.patch_rows / 2)));
+                    const int min_col = __builtin_amdgcn_readfirstlane(wadd(f2i(int_col), -(p.patch_cols / 2)));
+                    const int rel_r = (int)((unsigned)min_row - (unsigned)cw.r_lo), rel_c = (int)((unsigned)min_col - (unsigned)cw.c_lo);
+                    // the whole lattice (+ 1 neighbours) inside the image: no per-pixel bounds test (wave-uniform)
+                    const bool all_inside = min_row >= 0 && (long long)min_row + p.patch_rows - 1 <= (long long)cur.rows - 2 && min_col >= 0 &&
+                                            (long long)min_col + p.patch_cols - 1 <= (long long)cur.cols - 2;
+                    uint32_t n_valid = 0;
+                    if (all_inside && all_ref_valid) {
+                        // the usual case: every pixel is used — no selects, no counts (the window covers the lattice: win_covers above)
+                        const int rel = imul(rel_r, cw.cols) + rel_c;
+#pragma unroll 4
+                        for (int pass = 0; pass < n_pass; ++pass) {
+                            const int pxi = pass * kWave + lane;
+                            if (pxi < p.P) {
+                                int prow, pcol;
+                                pixel_rc(p, pxi, prow, pcol);
+                                const float4 rec = c.rec[pxi];
+                                const float i_cur = win_bilinear(c.cur_win, cw.cols, rel + imul(prow, cw.cols) + pcol, w_tl, w_tr, w_bl, w_br);
+                                const float dt = i_cur - rec.z;
+                                c.terms[pxi] = -(rec.x * dt);
+                                c.terms[pitch + pxi] = -(rec.y * dt);
+                            }
+                        }
+                        n_valid = (uint32_t)p.P;
+                    } else {
+#pragma unroll 2
+                        for (int pass = 0; pass < n_pass; ++pass) {
+                            const int pxi = pass * kWave + lane;
+                            bool ok = false;
+                            if (pxi < p.P) {
+                                int prow, pcol;
+                                pixel_rc(p, pxi, prow, pcol);
+                                const float4 rec = c.rec[pxi];
+                                const int lr = rel_r + prow, lc = rel_c + pcol;
+                                const bool in_win = (unsigned)lr < (unsigned)(cw.rows - 1) && (unsigned)lc < (unsigned)cw.cols;  // always, for a pixel inside the image
+                                const int row = wadd(min_row, prow), col = wadd(min_col, pcol);
+                                const bool in_img = !(row < 0 || row > cur.rows - 2 || col < 0 || col > cur.cols - 2);
+                                ok = in_img && in_win && __float_as_int(rec.w) != 0;
+                                const float i_cur = win_bilinear(c.cur_win, cw.cols, in_win ? imul(lr, cw.cols) + lc : 0, w_tl, w_tr, w_bl, w_br);
+                                const float dt = i_cur - rec.z;
+                                c.terms[pxi] = ok ? -(rec.x * dt) : 0.0f;
+                                c.terms[pitch + pxi] = ok ? -(rec.y * dt) : 0.0f;
+                            }
+                            n_valid += (uint32_t)__popcll(wave_ballot(ok));
+                        }
+                    }
+                    fk_fence();
+                    FTK_STAMP_END(b, 3);
+                    if (n_valid == 0) {
+                        break;  // basic_klt_fast.cpp:40-42
+                    }
+                    // the exact-order sums: lanes 0 / 1 the bias, and in the level's first iteration lanes 2 - 4 the Hessian
+                    const int chains = iter == 0 ? kFkTerms : 2;
+                    float acc = 0.0f;
+                    if (lane < chains) {
+                        acc = chain_lane(c.terms + lane * pitch, p.Ppad);
+                    }
+                    const int acc_bits = __float_as_int(acc);
+                    FTK_STAMP_END(b, 5);
+                    if (iter == 0) {
+                        fac = ldlt2_factor(__int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3)),
+                                           __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)));
+                    }
+                    float v0, v1;
+                    ldlt2_apply(fac, __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1)), v0, v1, lane);  // basic_klt_fast.cpp:44
+                    if (isnan(v0) || isnan(v1)) {
+                        status = FTK_NUMERIC_ERROR;
+                        break;
+                    }
+                    cur_u += v0;
+                    cur_v += v1;
+                    FTK_STAMP_END(b, 6);
+                    if (fast_step_logic(p, v0 * v0 + v1 * v1, last_squared_step, large_step_cnt, status)) {
+                        break;
+                    }
                 }
-                // the exact-order sums: lanes 0 / 1 the bias, and in the level's first iteration lanes 2 - 4 the Hessian
-                const int chains = iter == 0 ? kFkTerms : 2;
-                float acc = 0.0f;
-                if (lane < chains) {
-                    acc = chain_lane(c.terms + lane * pitch, p.Ppad);
+            } else {
+                // ---- PrecomputeJacobianAndHessian, the per-pixel part (affine_klt_fast.cpp:71-94): dx = dy = 0 where a 4-neighbour is missing ----
+#pragma unroll 4
+                for (int pass = 0; pass < n_pass; ++pass) {
+                    const int pxi = pass * kWave + lane;
+                    if (pxi < p.P) {
+                        int prow, pcol;
+                        pixel_rc(p, pxi, prow, pcol);
+                        const int ei = imul(prow + 1, exp) + pcol + 1;
+                        const float e_l = c.ex[ei - 1], e_r = c.ex[ei + 1], e_t = c.ex[ei - exp], e_b = c.ex[ei + exp], e_c = c.ex[ei];
+                        float dx = e_r - e_l, dy = e_b - e_t;
+                        int flags = 3;
+                        if (!all_ref_valid) {  // wave-uniform
+                            const bool grad = (__float_as_int(e_l) | __float_as_int(e_r) | __float_as_int(e_t) | __float_as_int(e_b)) >= 0;
+                            dx = grad ? dx : 0.0f;
+                            dy = grad ? dy : 0.0f;
+                            flags = (__float_as_int(e_c) >= 0 ? 1 : 0) | (grad ? 2 : 0);
+                        }
+                        c.rec[pxi] = make_float4(dx, dy, e_c, __int_as_float(flags));
+                    }
                 }
-                const int acc_bits = __float_as_int(acc);
-                FTK_STAMP_END(b, 5);
-                if (iter == 0) {
-                    fac = ldlt2_factor(__int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3)),
-                                       __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)));
+                fk_fence();
+                FTK_STAMP_END(b, 2);
+                status = FTK_LARGE_RESIDUAL;  // affine_klt_fast.cpp:29
+                float last_squared_step = INFINITY;
+                uint32_t large_step_cnt = 0;
+                Ldlt6 fac;
+                fac.perm = 0;
+                fac.d_mine = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    fac.l[i] = 0.0f;
                 }
-                float v0, v1;
-                ldlt2_apply(fac, __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1)), v0, v1, lane);  // basic_klt_fast.cpp:44
-                if (isnan(v0) || isnan(v1)) {
-                    status = FTK_NUMERIC_ERROR;
-                    break;
-                }
-                cur_u += v0;
-                cur_v += v1;
-                FTK_STAMP_END(b, 6);
-                if (fast_step_logic(p, v0 * v0 + v1 * v1, last_squared_step, large_step_cnt, status)) {
-                    break;
+                float *const ring_col = c.terms + lane;             // this lane's column of the ring (first iteration's sweeps)
+                const float *const ring_row = c.terms + imul(lane < kAfRows ? lane : 0, kChunkRow);  // ... and its row (chain lanes)
+                // One patch pixel of ComputeBias (affine_klt_fast.cpp:140-188): the current image at the warped position, and the
+                // factors of the six bias products — zeroed for an unused pixel, so that it contributes exact zeros (five selects
+                // instead of one per product; the products are then +0 or -0, and x + (+-0) == x for every value a sum that started
+                // at +0 can hold).  Returns whether the pixel is used.
+                auto bias_factors = [&](int pxi, bool in_patch, int &prow, int &pcol, float4 &rec, float &dt, float &bx, float &by, float &bdx,
+                                        float &bdy) -> bool {
+                    pixel_rc(p, in_patch ? pxi : 0, prow, pcol);
+                    rec = c.rec[in_patch ? pxi : 0];
+                    const float dcol = (float)(pcol - p.half_cols);
+                    const float drow = (float)(prow - p.half_rows);
+                    const float warped_x = a00 * dcol + a01 * drow;
+                    const float warped_y = a10 * dcol + a11 * drow;
+                    const float row_c = warped_y + cur_v;
+                    const float col_c = warped_x + cur_u;
+                    const Axis ar = make_axis(row_c, cur.rows - 1), ac = make_axis(col_c, cur.cols - 1);
+                    bool hit = true;
+                    float i_cur = tap(cw, ar, ac, hit);
+                    const bool valid = ar.valid && ac.valid;
+                    if (valid && !hit) {
+                        sample(cur, cw, row_c, col_c, i_cur);  // a warped tap outside the window: global memory, same arithmetic
+                    }
+#ifdef FTK_STAMPS_MISSES
+                    b.stamp_acc[2] += 100ull * (unsigned long long)__popcll(wave_ballot(in_patch && valid && !hit));  // diagnostic: taps that left the window
+                    b.stamp_acc[0] += 100ull * (unsigned long long)__popcll(wave_ballot(in_patch && !valid));        // ... and taps outside the image
+#endif
+                    const bool ok = in_patch && valid && (__float_as_int(rec.w) & 1) != 0;
+                    dt = ok ? i_cur - rec.z : 0.0f;
+                    bx = ok ? col_c : 0.0f;
+                    by = ok ? row_c : 0.0f;
+                    bdx = ok ? rec.x : 0.0f;
+                    bdy = ok ? rec.y : 0.0f;
+                    return ok;
+                };
+                for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
+                    ++iters;
+                    FTK_STAMP_BEGIN(b);
+                    if (!win_covers(cw, cur_u, cur_v)) {
+                        // the (unwarped) patch has left the window: restage around the present position; warped taps outside the window
+                        // are sampled from global memory with the same arithmetic
+                        int need_r, need_c;
+                        footprint_origin(p, cur_u, cur_v, need_r, need_c);
+                        const long long nr = need_r, nc = need_c;
+                        const bool covered = nr >= (long long)cw.r_lo && nr + (2 * p.half_rows + 4) <= (long long)cw.r_lo + cw.rows &&
+                                             nc >= (long long)cw.c_lo && nc + (2 * p.half_cols + 4) <= (long long)cw.c_lo + cw.cols + 1;
+                        if (!covered) {
+                            cw.r_lo = wadd(need_r, -p.cwin_margin);
+                            cw.c_lo = wadd(need_c, -p.cwin_margin);
+                            win_set_cover(p, cw);
+                            stage_any(opaque_blk(b), cur, c.cur_win, cw.r_lo, cw.c_lo, cw.rows, cw.cols, p.magic_cwc, p.magic_cwq);
+                            fk_fence();
+                        }
+                    }
+                    const bool first = iter == 0;
+                    float acc = 0.0f;
+                    uint32_t n_valid = 0;
+                    if (first) {
+                        // ---- the level's first iteration: the six bias products AND the Hessian's 18 (affine_klt_fast.cpp:95-129), 64 pixels
+                        // at a time: sweep into the ring, then the exact-order sums of those 64 terms continue on 24 chain lanes ----
+                        for (int base = 0; base < p.P; base += kChunkPixels) {
+                            const int pxi = base + lane;
+                            const bool in_patch = pxi < p.P;
+                            int prow, pcol;
+                            float4 rec;
+                            float dt, bx, by, bdx, bdy;
+                            const bool ok = bias_factors(pxi, in_patch, prow, pcol, rec, dt, bx, by, bdx, bdy);
+                            ring_col[0 * kChunkRow] = -(dt * bx * bdx);
+                            ring_col[1 * kChunkRow] = -(dt * bx * bdy);
+                            ring_col[2 * kChunkRow] = -(dt * by * bdx);
+                            ring_col[3 * kChunkRow] = -(dt * by * bdy);
+                            ring_col[4 * kChunkRow] = -(dt * bdx);
+                            ring_col[5 * kChunkRow] = -(dt * bdy);
+                            n_valid += (uint32_t)__popcll(wave_ballot(ok));
+                            // x, y: the patch offset + the position at level entry — cur_uv has not moved yet (affine_klt_fast.cpp:95-96)
+                            const bool grad = in_patch && (__float_as_int(rec.w) & 2) != 0;
+                            const float x = grad ? (float)(pcol - p.half_cols) + cur_u : 0.0f;
+                            const float y = grad ? (float)(prow - p.half_rows) + cur_v : 0.0f;
+                            const float dx = grad ? rec.x : 0.0f, dy = grad ? rec.y : 0.0f;
+                            const float xx = x * x, yy = y * y, xy = x * y;
+                            const float dxdx = dx * dx, dydy = dy * dy, dxdy = dx * dy;
+                            float *const h = ring_col + 6 * kChunkRow;
+                            h[A_XX_DXDX * kChunkRow] = xx * dxdx;
+                            h[A_XX_DXDY * kChunkRow] = xx * dxdy;
+                            h[A_XY_DXDX * kChunkRow] = xy * dxdx;
+                            h[A_XY_DXDY * kChunkRow] = xy * dxdy;
+                            h[A_X_DXDX * kChunkRow] = x * dxdx;
+                            h[A_X_DXDY * kChunkRow] = x * dxdy;
+                            h[A_XX_DYDY * kChunkRow] = xx * dydy;
+                            h[A_XY_DYDY * kChunkRow] = xy * dydy;
+                            h[A_X_DYDY * kChunkRow] = x * dydy;
+                            h[A_YY_DXDX * kChunkRow] = yy * dxdx;
+                            h[A_YY_DXDY * kChunkRow] = yy * dxdy;
+                            h[A_Y_DXDX * kChunkRow] = y * dxdx;
+                            h[A_Y_DXDY * kChunkRow] = y * dxdy;
+                            h[A_YY_DYDY * kChunkRow] = yy * dydy;
+                            h[A_Y_DYDY * kChunkRow] = y * dydy;
+                            h[A_DXDX * kChunkRow] = dxdx;
+                            h[A_DXDY * kChunkRow] = dxdy;
+                            h[A_DYDY * kChunkRow] = dydy;
+                            fk_fence();
+                            if (lane < kAfRows) {
+                                const int left = p.P - base;  // a short last chunk is chained to a multiple of four (lanes past the patch wrote zeros)
+                                acc = left >= kChunkPixels ? chain_chunk(acc, ring_row) : chain_lane(ring_row, (left + 3) & ~3, acc);
+                            }
+                            fk_fence();  // the next sweep's stores stay behind these reads
+                        }
+                    } else {
+                        // ---- every later iteration: six whole rows [6][pitch] over the ring's space — all passes of the sweep first (their
+                        // LDS round trips overlap), then ONE uninterrupted chain per sum ----
+#pragma unroll 4
+                        for (int pass = 0; pass < n_pass; ++pass) {
+                            const int pxi = pass * kWave + lane;
+                            int prow, pcol;
+                            float4 rec;
+                            float dt, bx, by, bdx, bdy;
+                            const bool ok = bias_factors(pxi, pxi < p.P, prow, pcol, rec, dt, bx, by, bdx, bdy);
+                            if (pxi < p.Ppad) {  // the padding columns P .. Ppad - 1 are rewritten too: the ring's sweeps run over them
+                                c.terms[0 * pitch + pxi] = -(dt * bx * bdx);
+                                c.terms[1 * pitch + pxi] = -(dt * bx * bdy);
+                                c.terms[2 * pitch + pxi] = -(dt * by * bdx);
+                                c.terms[3 * pitch + pxi] = -(dt * by * bdy);
+                                c.terms[4 * pitch + pxi] = -(dt * bdx);
+                                c.terms[5 * pitch + pxi] = -(dt * bdy);
+                            }
+                            n_valid += (uint32_t)__popcll(wave_ballot(ok));  // (every lane counts every pass: the total stays wave-uniform)
+                        }
+                        fk_fence();
+                        FTK_STAMP_END(b, 3);
+                        if (lane < 6) {
+                            acc = chain_lane(c.terms + imul(lane, pitch), p.Ppad);
+                        }
+                        fk_fence();
+                    }
+                    FTK_STAMP_END(b, 5);
+                    if (n_valid == 0) {
+                        break;  // affine_klt_fast.cpp:38-40
+                    }
+                    if (first) {
+                        // The Hessian is fixed for the level: it is FACTORISED once (rows on lanes 0 - 5) and every iteration only runs
+                        // the two substitutions — the factorisation is a pure function of H.  Lanes 6 + s publish sum s as the dense
+                        // 6 x 6 (every alias of affine_klt_fast.cpp:130-132 written by the lane that owns the sum); the diagonal the
+                        // pivot search needs comes from the accumulators themselves.
+                        float *const dense = c.sums;
+                        if (lane >= 6 && lane < kAfRows) {
+                            const uint32_t slots = affine_dense_slots(lane - 6);
+                            dense[slots & 0xffu] = acc;
+                            dense[(slots >> 8) & 0xffu] = acc;
+                            dense[(slots >> 16) & 0xffu] = acc;
+                            dense[slots >> 24] = acc;
+                        }
+                        float ad_all[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            ad_all[j] = fabsf(bcast_lane(acc, 6 + kAffineDiagLane[j]));
+                        }
+                        float my_ad = ad_all[0];
+#pragma unroll
+                        for (int j = 1; j < 6; ++j) {
+                            my_ad = (lane == j) ? ad_all[j] : my_ad;
+                        }
+                        fk_fence();
+                        fac = ldlt6_factor_diag(my_ad, ad_all, Ldlt6Dense{dense}, lane);
+                    }
+                    // (the substitutions with L broadcast into wave-uniform registers — ~130 straight-line instructions instead of ~290
+                    // with a cross-lane broadcast per term — were built and measured: 0.08 us per iteration SLOWER; docs/LAB_NOTES.md)
+                    if (lane < 6) {
+                        c.sums[40 + lane] = acc;
+                    }
+                    fk_fence();
+                    ldlt6_solve(fac, c.sums + 40, c.sums + 48, lane);  // affine_klt_fast.cpp:42
+                    fk_fence();
+                    float z[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        z[j] = c.sums[48 + j];
+                    }
+                    if (isnan(z[0]) || isnan(z[1]) || isnan(z[2]) || isnan(z[3]) || isnan(z[4]) || isnan(z[5])) {
+                        status = FTK_NUMERIC_ERROR;
+                        break;
+                    }
+                    const float v0 = (z[0] * cur_u + z[2] * cur_v) + z[4];  // affine_klt_fast.cpp:48
+                    const float v1 = (z[1] * cur_u + z[3] * cur_v) + z[5];
+                    cur_u += v0;
+                    cur_v += v1;
+                    a00 += z[0];  // col(0) += z.head<2>(), col(1) += z.segment<2>(2) (:50-53)
+                    a10 += z[1];
+                    a01 += z[2];
+                    a11 += z[3];
+                    FTK_STAMP_END(b, 6);
+                    if (fast_step_logic(p, v0 * v0 + v1 * v1, last_squared_step, large_step_cnt, status)) {
+                        break;
+                    }
                 }
             }
         }
@@ -595,9 +857,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 #endif
 }
 
-template <int HR, int HC>
-hipError_t fk_launch_basic(const KltParams &p, size_t lds, hipStream_t stream) {
-    void (*kernel)(const KltParams) = klt_basic_fast_kernel<HR, HC>;
+template <int MODEL, int HR, int HC>
+hipError_t fk_launch(const KltParams &p, size_t lds, hipStream_t stream) {
+    void (*kernel)(const KltParams) = klt_fast_kernel<MODEL, HR, HC>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -613,22 +875,22 @@ hipError_t fk_launch_basic(const KltParams &p, size_t lds, hipStream_t stream) {
 }  // namespace
 
 size_t klt_fast_lds_bytes(int model, const KltParams &p) {
-    if (model != FTK_MODEL_BASIC) {
+    if (model != FTK_MODEL_BASIC && model != FTK_MODEL_AFFINE) {
         return 0;
     }
-    const size_t one = fk_lds_bytes(p);
+    const size_t one = fk_lds_bytes(model, p);
     return one * (size_t)(p.features_per_group > 1 ? p.features_per_group : 1);
 }
 
 hipError_t klt_fast_launch(int model, const KltParams &p_in, hipStream_t stream) {
-    if (model != FTK_MODEL_BASIC) {
+    if (model != FTK_MODEL_BASIC && model != FTK_MODEL_AFFINE) {
         return hipErrorInvalidValue;
     }
     KltParams p = p_in;
     if (p.features_per_group < 1) {
         p.features_per_group = 1;
     }
-    p.group_lds_stride = (int32_t)fk_lds_bytes(p);  // a multiple of 16
+    p.group_lds_stride = (int32_t)fk_lds_bytes(model, p);  // a multiple of 16
     size_t lds = klt_fast_lds_bytes(model, p);
     if (p.sort_iters && lds < (size_t)kOrderLdsBytes) {
         lds = kOrderLdsBytes;
@@ -638,15 +900,19 @@ hipError_t klt_fast_launch(int model, const KltParams &p_in, hipStream_t stream)
         KltParams check = p;
         klt_fill_geometry(check);  // what the specialised kernels recompute: it must be what the caller passed
         if (check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols && check.rwin_cols == p.rwin_cols && check.Ppad == p.Ppad) {
-            switch (p.half_rows) {
-                case 5: return fk_launch_basic<5, 5>(p, lds, stream);
-                case 6: return fk_launch_basic<6, 6>(p, lds, stream);
-                case 10: return fk_launch_basic<10, 10>(p, lds, stream);
-                default: break;
+            if (model == FTK_MODEL_BASIC) {
+                switch (p.half_rows) {
+                    case 5: return fk_launch<FTK_MODEL_BASIC, 5, 5>(p, lds, stream);
+                    case 6: return fk_launch<FTK_MODEL_BASIC, 6, 6>(p, lds, stream);
+                    case 10: return fk_launch<FTK_MODEL_BASIC, 10, 10>(p, lds, stream);
+                    default: break;
+                }
+            } else if (p.half_rows == 6) {
+                return fk_launch<FTK_MODEL_AFFINE, 6, 6>(p, lds, stream);
             }
         }
     }
-    return fk_launch_basic<0, 0>(p, lds, stream);
+    return model == FTK_MODEL_BASIC ? fk_launch<FTK_MODEL_BASIC, 0, 0>(p, lds, stream) : fk_launch<FTK_MODEL_AFFINE, 0, 0>(p, lds, stream);
 }
 
 __global__ void klt_fast_warm_kernel() {}

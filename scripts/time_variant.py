@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--size", default="640x480")
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--fixed-iterations", action="store_true", help="never converge, never stop on large steps: kMaxIteration iterations on every level (what ONE iteration costs)")
+    ap.add_argument("--max-iteration", type=int, default=15)
     args = ap.parse_args()
     import torch
     import feature_tracker_amd as F
@@ -40,6 +42,9 @@ def main():
             uv = synth.make_features(n, w, h, half=half)
             opt = F.OpticalFlowOptions()
             opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, half, half, n
+            opt.kMaxIteration = args.max_iteration
+            if args.fixed_iterations:
+                opt.kMaxConvergeStep, opt.kMaxToleranceLargeStep = 0.0, 1 << 30
             klt = D.DeviceKlt(model, opt, rp, cp, ctx, consider_luminance=lum)
             d_ref = torch.from_numpy(uv).to(dev)
             d_in, d_st = d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -59,7 +64,7 @@ def main():
                 stream.synchronize()
                 best.append((time.perf_counter() - t0) / args.steps * 1e6)
             out = {"spec": spec, "us_per_step": round(min(best), 2), "us_runs": [round(x, 2) for x in best], "mean_iters": float(d_it.float().mean().item())}
-            if not args.no_oracle:
+            if not args.no_oracle and not args.fixed_iterations:
                 t0 = time.perf_counter()
                 ok, cuv, cst, cit = oracle_lib.klt_track_pyramid(model, rl, cl, uv, method=method, half=half, max_points=n, consider_luminance=lum)
                 out["cpu_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
