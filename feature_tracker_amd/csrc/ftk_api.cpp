@@ -199,8 +199,10 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     if (ref->device != ctx->device || cur->device != ctx->device) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt: pyramid lives on another device");
     }
-    if (opt->half_rows < 0 || opt->half_cols < 0 || opt->half_rows > 63 || opt->half_cols > 63) {
-        return fail(ctx, FTK_E_UNSUPPORTED, "klt: half patch size (%d, %d) outside [0, 63]", opt->half_rows, opt->half_cols);
+    // The reference takes any int32 half size (optical_flow.h:24-25).  Here: up to 1023 (a 2047 x 2047 patch; pixel indices stay
+    // below 2^23 for the 24-bit multiplier); patches beyond a workgroup's LDS run the large-patch form below.
+    if (opt->half_rows < 0 || opt->half_cols < 0 || opt->half_rows > 1023 || opt->half_cols > 1023) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "klt: half patch size (%d, %d) outside [0, 1023]", opt->half_rows, opt->half_cols);
     }
     ftk::KltParams &p = *out;
     memset(&p, 0, sizeof(p));
@@ -355,9 +357,46 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     p.pb_cap_r = p.patch_rows + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
     p.pb_cap_c = p.patch_cols + 2 + (FTK_PB_EXTRAS_TIMING_ONLY);
 #endif
-    const size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
-    if (lds == 0 || lds > 160 * 1024) {
-        return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu B of LDS (limit 163840)", p.patch_rows, p.patch_cols, lds);
+    size_t lds = ftk::klt_lds_bytes(model, opt->method, p);
+    if (lds == 0) {
+        return fail(ctx, FTK_E_UNSUPPORTED, "klt: unknown variant (model %d, method %d)", model, opt->method);
+    }
+    // The large-patch form: a patch whose per-pixel arrays exceed a workgroup's 160 KB of LDS (from 41 x 41 for Basic KLT, 37 x 37
+    // for the non-fast affine variants) runs the generic multi-wave kernel with those arrays in a per-workgroup slice of device
+    // memory (ftk_device.h KltParams::spill) — same code, same sums.  Exact mode only.  FTK_KLT_SPILL=1 forces the form for any
+    // patch, 2 also drops the LDS image windows (what happens by itself from about 280 x 280): the tests walk every variant through both.
+    const char *spill_env = getenv("FTK_KLT_SPILL");
+    const int spill_force = spill_env ? atoi(spill_env) : 0;
+    if (lds > 160 * 1024 || spill_force > 0) {
+        p.spill = 1;
+        p.tree = 0;
+        p.pb_enabled = p.fk_enabled = p.lssd_chunked = 0;
+        p.features_per_group = 1;
+        int w = (p.P + 63) / 64;
+        p.waves_per_feature = w < 2 ? 2 : (w > 4 ? 4 : w);
+        ftk::KltParams geometry = p;
+        ftk::klt_fill_geometry(geometry);
+        p.a0_floats = geometry.a0_floats;
+        p.px_floats = 3;
+        p.terms_floats = 0;
+        if (model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
+            p.px_floats = 4;
+            p.terms_floats = ((p.Ppad / 4 + ftk::kAffineTermsRoundGroups - 1) / ftk::kAffineTermsRoundGroups) * ftk::kAffineTermsRoundGroups * ftk::kAffineTermsGroupFloats;
+        }
+        lds = ftk::klt_lds_bytes(model, opt->method, p);
+        if (lds > 150 * 1024 || spill_force > 1) {
+            // not even the windows fit: every tap takes the samplers' global-memory path (same arithmetic); a disabled window has one
+            // row and no column, which every covered-by-the-window test refuses
+            p.rwin_rows = p.cwin_rows = 1;
+            p.rwin_cols = p.cwin_cols = 0;
+            p.magic_rwc = p.magic_cwc = p.magic_rwq = p.magic_cwq = 0;
+            lds = ftk::klt_lds_bytes(model, opt->method, p);
+        }
+        const size_t floats = ftk::klt_spill_floats(model, p);
+        if (floats == 0 || floats > 0xFFFFFFFFull) {
+            return fail(ctx, FTK_E_UNSUPPORTED, "klt: patch %dx%d needs %zu floats of device memory per feature", p.patch_rows, p.patch_cols, floats);
+        }
+        p.spill_stride_floats = (uint32_t)floats;
     }
     return FTK_OK;
 }
@@ -491,6 +530,9 @@ void ftk_context_destroy(ftk_context *ctx) {
             (void)hipFree(ctx->sched_iters[k]);
             (void)hipFree(ctx->sched_order[k]);
         }
+    }
+    if (ctx->klt_spill) {
+        (void)hipFree(ctx->klt_spill);
     }
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
@@ -989,7 +1031,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     if (rc != FTK_OK) {
         return rc;
     }
-    p.tree = ctx->reduction == FTK_REDUCTION_TREE ? 1 : 0;
+    p.tree = (ctx->reduction == FTK_REDUCTION_TREE && !p.spill) ? 1 : 0;
     p.ref_uv = d_ref_uv;
     p.cur_uv_in = d_cur_uv_in;
     p.cur_uv_out = d_cur_uv_out;
@@ -997,6 +1039,41 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     p.status_out = d_status_out;
     p.iters = d_iters;
     FTK_HIP(ctx, hipSetDevice(ctx->device));
+    if (p.spill) {
+        // Large patches: a slice of device memory per launch slot.  All features at once while that stays within a budget (4 GB;
+        // FTK_KLT_SPILL_BUDGET_MB), otherwise in batches of consecutive features — a feature's result does not depend on the others.
+        const size_t per = sizeof(float) * (size_t)p.spill_stride_floats;
+        size_t budget = (size_t)4096 << 20;
+        if (const char *env = getenv("FTK_KLT_SPILL_BUDGET_MB")) {
+            budget = (size_t)(atoll(env) > 0 ? atoll(env) : 1) << 20;
+        }
+        size_t batch = budget / per;
+        batch = batch < 1 ? 1 : (batch > (size_t)n ? (size_t)n : batch);
+        const int rc_buf = ftk_ensure_device_buffer(ctx, &ctx->klt_spill, &ctx->klt_spill_bytes, batch * per);
+        if (rc_buf != FTK_OK) {
+            return rc_buf;
+        }
+        p.spill_base = static_cast<float *>(ctx->klt_spill);
+        ctx->sched_calls = 0;  // no launch order for these calls; a later ordinary call starts its history over
+        ctx->sched_n = 0;
+        for (size_t b0 = 0; b0 < (size_t)n; b0 += batch) {
+            const size_t nb = (size_t)n - b0 < batch ? (size_t)n - b0 : batch;
+            ftk::KltParams q = p;
+            q.n = (int32_t)nb;
+            q.ref_uv = p.ref_uv + 2 * b0;
+            q.cur_uv_in = p.cur_uv_in + 2 * b0;
+            q.cur_uv_out = p.cur_uv_out + 2 * b0;
+            q.status_in = p.status_in + b0;
+            q.status_out = p.status_out + b0;
+            q.iters = p.iters ? p.iters + b0 : nullptr;
+            q.n_track = (size_t)p.n_track > b0 ? (uint32_t)((size_t)p.n_track - b0 < nb ? (size_t)p.n_track - b0 : nb) : 0u;  // kMaxTrackPointsNumber is a cap on the whole list
+            const hipError_t e = ftk::klt_launch(model, opt->method, q, ctx->stream);
+            if (e != hipSuccess) {
+                return fail(ctx, e == hipErrorOutOfMemory ? FTK_E_OUT_OF_MEMORY : FTK_E_HIP, "klt launch (large patch) failed: %s", hipGetErrorString(e));
+            }
+        }
+        return FTK_OK;
+    }
     {
         // Launch order.  A call's time is bulk + tail: features run a data-dependent number of Gauss-Newton iterations
         // (config 3: mean 6.7, one feature 52), a launch in list order starts the long ones wherever they happen to sit,

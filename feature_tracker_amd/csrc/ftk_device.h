@@ -77,6 +77,13 @@ struct KltParams {
     uint32_t pb_magic_rwc, pb_magic_rwq;
     int32_t pb_cap_r, pb_cap_c;          // lattice node capacity per axis: len + 2 + provable maximum of extras
     int32_t fk_enabled;                  // the one-wave `fast` kernels (klt_fast_kernels.hip); 0 selects the generic kernel
+    // Patches whose per-pixel arrays exceed a workgroup's 160 KB of LDS (the reference has no patch-size ceiling: optical_flow.h:24-25
+    // takes any int32 half size): the generic kernel with its product rows, extended patch, per-pixel records and flags in a
+    // per-workgroup slice of device memory instead (L2-resident at these sizes); sums, counts and — where they fit — the image
+    // windows stay in LDS.  Same code, same arithmetic; only the address space of those arrays differs (klt_kernels.hip SPILL).
+    int32_t spill;
+    float *spill_base;                   // spill_stride_floats floats per workgroup (launch slot)
+    uint32_t spill_stride_floats;
     int32_t tree;                        // 0: sums in the reference's order (the contract); 1: throughput mode — the same per-pixel products, summed
                                          // by per-lane partials + a cross-lane butterfly (ftk_set_reduction_mode; reported, never the default)
     unsigned long long *stamps; // diagnostic build (-DFTK_STAMPS) only: 8 cycle totals per feature; else null
@@ -133,6 +140,8 @@ __host__ __device__ constexpr void klt_fill_geometry(KltParams &p) {
 
 // LDS bytes a (model, method) variant needs for the given geometry; 0 if the variant is unknown.
 size_t klt_lds_bytes(int model, int method, const KltParams &p);
+// Floats of device memory one workgroup of the large-patch (p.spill) form needs; 0 if the variant is unknown.
+size_t klt_spill_floats(int model, const KltParams &p);
 // Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
 // Lane-parallel 6x6 LDLT (klt_common.h) on n systems, one wave each: the test hook behind ftk_ldlt6_solve.

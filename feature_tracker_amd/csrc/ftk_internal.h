@@ -53,6 +53,9 @@ struct ftk_context {
     uint32_t sched_calls = 0;    // consecutive calls with that feature count so far
     void *match_pad = nullptr;
     size_t match_pad_bytes = 0;
+    // per-workgroup slices of the trackers' large-patch form (ftk_device.h KltParams::spill)
+    void *klt_spill = nullptr;
+    size_t klt_spill_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -90,6 +90,40 @@ __device__ __forceinline__ Carve carve_lds(float *base, int K, const KltParams &
     return c;
 }
 
+// The large-patch form (KltParams::spill): the arrays whose size grows with the patch live in this workgroup's slice of device
+// memory (`spill`), the fixed-size ones and the image windows in LDS.  Same fields, same order of use; the kernels never ask which.
+constexpr int kSpillSlackFloats = 64;  // what the chain's prefetch may read past the last product row
+
+__host__ __device__ inline size_t spill_floats(int K, const KltParams &p) {
+    const size_t epad = (size_t)pad4(p.E);
+    const size_t floats = (size_t)(p.terms_floats > 0 ? p.terms_floats : K * p.Ppad) + (size_t)p.a0_floats + (size_t)carve_px_floats(p) * (size_t)p.Ppad;
+    return floats + (epad + (size_t)p.Ppad + 3) / 4 + kSpillSlackFloats;
+}
+
+__host__ __device__ inline size_t spill_lds_bytes(const KltParams &p) {
+    // a disabled window (rows 1, cols 0: klt_api's choice when the windows do not fit either) still owns eight shorts: the
+    // branch-free taps read element 0 before they discard the value
+    const size_t shorts = (size_t)pad4(p.rwin_rows * p.rwin_cols) + (size_t)pad4(p.cwin_rows * p.cwin_cols) + 16;
+    return sizeof(float) * (72 + 24) + sizeof(uint16_t) * shorts;
+}
+
+__device__ __forceinline__ Carve carve_spill(float *lds, float *spill, int K, const KltParams &p) {
+    Carve c;
+    const int epad = pad4(p.E);
+    c.terms = spill;
+    c.a0 = c.terms + (p.terms_floats > 0 ? p.terms_floats : K * p.Ppad);
+    c.a1 = c.a0 + p.a0_floats;
+    c.a2 = c.a1 + p.Ppad;
+    c.a3 = c.a2 + p.Ppad;
+    c.flagsE = reinterpret_cast<uint8_t *>(c.a1 + carve_px_floats(p) * p.Ppad);
+    c.flagsP = c.flagsE + epad;
+    c.sums = lds;
+    c.wave_cnt = reinterpret_cast<uint32_t *>(c.sums + 72);
+    c.ref_win = reinterpret_cast<uint16_t *>(c.wave_cnt + 24);
+    c.cur_win = c.ref_win + pad4(p.rwin_rows * p.rwin_cols) + 8;
+    return c;
+}
+
 // Workgroup-wide sum of the per-wave valid-pixel counts.  The leading barrier also publishes the
 // terms written in phase A; the trailing one lets the slots be reused.
 __device__ __forceinline__ uint32_t block_total(const Blk &b, uint32_t wave_sum, uint32_t *slots) {
@@ -1782,7 +1816,8 @@ constexpr int kLongFeatureSlots = FTK_LONG_SLOTS;  // launch slots (longest firs
 // parallel chains; a butterfly over so few pixels is not faster) and stay exact.  Run-time geometry only (H == 0).
 // LUM: the chunked LSSD-fast level with consider_patch_luminance (its own instantiations, so that the plain chunked level keeps its
 // register count: the luminance form holds a lane's sampled values across its two passes).
-template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false, bool LUM = false>
+// SPILL: the large-patch form (KltParams::spill; multi-wave, run-time geometry, exact sums only): carve_spill instead of carve_lds.
+template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false, bool LUM = false, bool SPILL = false>
 __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument: a local copy whose arrays are indexed
     // with a run-time level would live in scratch memory
@@ -1868,7 +1903,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
     if (SOLO && p.features_per_group > 1) {
         lds_mine += (size_t)(threadIdx.x >> 6) * (p.group_lds_stride >> 2);
     }
-    Carve c = carve_lds(lds_mine, K, p);
+    Carve c = SPILL ? carve_spill(lds_mine, p.spill_base + (size_t)block * p.spill_stride_floats, K, p) : carve_lds(lds_mine, K, p);
     if (MODEL == FTK_MODEL_AFFINE && METHOD != FTK_METHOD_FAST) {
         if (p.a0_floats == 0) {
             c.a0 = c.terms;  // the level setup's axis tables share the head of the product groups (a0_floats == 0: ftk_api.cpp)
@@ -2008,7 +2043,12 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
 template <int MODEL, int METHOD>
 hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stream) {
     void (*kernel)(const KltParams) = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0> : klt_track_kernel<MODEL, METHOD, false, 0>;
-    if (p.tree) {  // throughput mode (reported, never the contract): its own instantiations, run-time geometry
+    if (p.spill) {
+        if (p.waves_per_feature < 2 || !p.spill_base) {
+            return hipErrorInvalidValue;
+        }
+        kernel = klt_track_kernel<MODEL, METHOD, false, 0, false, false, true>;
+    } else if (p.tree) {  // throughput mode (reported, never the contract): its own instantiations, run-time geometry
         kernel = p.waves_per_feature == 1 ? klt_track_kernel<MODEL, METHOD, true, 0, true> : klt_track_kernel<MODEL, METHOD, false, 0, true>;
     }
     static const bool specialise = !(getenv("FTK_KLT_SPECIALISE") && atoi(getenv("FTK_KLT_SPECIALISE")) == 0);  // experiment switch
@@ -2017,7 +2057,7 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
     // kernel went from 81 to 128 VGPRs and 9...18 % SLOWER)
     constexpr bool gains = true;
     if constexpr (gains) {
-        if (!p.tree && specialise && p.half_rows == 6 && p.half_cols == 6) {
+        if (!p.tree && !p.spill && specialise && p.half_rows == 6 && p.half_cols == 6) {
             KltParams check = p;
             klt_fill_geometry(check);  // what the specialised kernel recomputes: it must be what the caller passed
             if (check.cwin_rows == p.cwin_rows && check.cwin_cols == p.cwin_cols && check.Ppad == p.Ppad && check.rwin_cols == p.rwin_cols) {
@@ -2026,7 +2066,7 @@ hipError_t launch_variant(const KltParams &p, size_t lds_bytes, hipStream_t stre
         }
     }
     if constexpr (MODEL == FTK_MODEL_LSSD && METHOD == FTK_METHOD_FAST) {
-        if (p.waves_per_feature == 1 && p.lssd_chunked && p.consider_luminance && !p.tree) {
+        if (p.waves_per_feature == 1 && p.lssd_chunked && p.consider_luminance && !p.tree && !p.spill) {
             const bool h6 = kernel == klt_track_kernel<MODEL, METHOD, true, 6>;
             kernel = h6 ? klt_track_kernel<MODEL, METHOD, true, 6, false, true> : klt_track_kernel<MODEL, METHOD, true, 0, false, true>;
         }
@@ -2072,8 +2112,16 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p) {
     if (k == 0) {
         return 0;
     }
+    if (p.spill) {
+        return (spill_lds_bytes(p) + 15) & ~(size_t)15;
+    }
     const size_t one = (carve_bytes(k, p) + 15) & ~(size_t)15;
     return (p.waves_per_feature == 1 && p.features_per_group > 1) ? one * (size_t)p.features_per_group : one;
+}
+
+size_t klt_spill_floats(int model, const KltParams &p) {
+    const int k = chain_count(model);
+    return k == 0 ? 0 : (spill_floats(k, p) + 3) & ~(size_t)3;
 }
 
 namespace {

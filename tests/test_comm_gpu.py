@@ -137,22 +137,24 @@ def test_a_failed_local_launch_poisons_its_shard_instead_of_leaving_the_collecti
         d_out, d_st = torch.zeros_like(d_ref), torch.zeros(n, dtype=torch.uint8, device=dev)
         klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)  # sizes the exchange buffers
         stream.synchronize()
-        klt.opt.half_rows = 64  # outside [0, 63]: fill_klt_params refuses it
-        with pytest.raises(_native.FtkError) as e:
+        try:  # (a communicator left open by a failed assertion keeps the interpreter from exiting)
+            klt.opt.half_rows = 1024  # outside [0, 1023]: fill_klt_params refuses it
+            with pytest.raises(_native.FtkError) as e:
+                klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)
+            assert e.value.code == -4 and "half patch" in str(e.value)
+            stream.synchronize()
+            assert (d_st.cpu().numpy() == 0xFF).all() and (d_out.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
+            # host-buffer form
+            cur, st = uv.copy(), np.zeros(n, np.uint8)
+            rc = _native.lib().ftk_klt_track_sharded(ctx.handle, comm.handle, klt.model, C.byref(klt.opt), klt.ref_pyr.handle, klt.cur_pyr.handle,
+                                                     uv.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), n, None, 0, 0, None)
+            assert rc != 0
+            klt.opt.half_rows = 5  # and the communicator is still usable afterwards
             klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)
-        assert e.value.code == -4 and "half patch" in str(e.value)
-        stream.synchronize()
-        assert (d_st.cpu().numpy() == 0xFF).all() and (d_out.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all()
-        # host-buffer form
-        cur, st = uv.copy(), np.zeros(n, np.uint8)
-        rc = _native.lib().ftk_klt_track_sharded(ctx.handle, comm.handle, klt.model, C.byref(klt.opt), klt.ref_pyr.handle, klt.cur_pyr.handle,
-                                                 uv.ctypes.data_as(C.c_void_p), cur.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), n, None, 0, 0, None)
-        assert rc != 0
-        klt.opt.half_rows = 5  # and the communicator is still usable afterwards
-        klt.track_sharded(comm, d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_st)
-        stream.synchronize()
-        assert (d_st.cpu().numpy() <= 4).all()
-        comm.close()
+            stream.synchronize()
+            assert (d_st.cpu().numpy() <= 4).all()
+        finally:
+            comm.close()
 
 
 def test_comm_argument_errors(ftk):

@@ -362,10 +362,40 @@ def test_affine_patches_smaller_than_one_product_group(ftk, oracle, half, half_c
         assert_parity(gpu, cpu, f"half=({half},{half_cols}) affine/{method}")
 
 
-def test_unsupported_patch_is_a_clean_error(ftk):
+@pytest.mark.parametrize("model,method,half", [("affine", "inverse", 30), ("affine", "fast", 30), ("affine", "direct", 19), ("basic", "inverse", 40),
+                                               ("basic", "fast", 70), ("lssd", "inverse", 24), ("lssd", "fast", 33)])
+def test_patches_beyond_a_workgroups_lds_run_the_large_patch_form(ftk, oracle, model, method, half):
+    """The reference has no patch-size ceiling (optical_flow.h:24-25: any int32 half size).  Patches whose per-pixel arrays exceed
+    160 KB of LDS — 24 sums x 61 x 61 products for affine inverse at half 30, which round 3 refused with FTK_E_UNSUPPORTED — run
+    the generic kernel with those arrays in device memory; the results are the oracle's, bit for bit.  Half 70 is also beyond the
+    old limit of 63 on the half size itself."""
+    ref_levels, cur_levels = scenes.scene(640, 480, 2)
+    uv = scenes.features(24, 640, 480, half=min(half, 60), border_fraction=0.1)
+    gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=half)
+    assert_parity(gpu, cpu, f"large patch half={half} {model}/{method}")
+
+
+@pytest.mark.parametrize("windows", [1, 2])
+@pytest.mark.parametrize("model", MODELS)
+def test_large_patch_form_forced_on_ordinary_patches(ftk, oracle, model, windows, monkeypatch):
+    """FTK_KLT_SPILL=1 sends every variant through the large-patch form at an ordinary size (13 x 13, rectangular 5 x 9), =2 also
+    without the LDS image windows (every tap from global memory — what patches from about 280 x 280 get); the feature list is
+    tracked in three batches (a 1 MB budget of device memory), with a kMaxTrackPointsNumber that cuts the second batch."""
+    monkeypatch.setenv("FTK_KLT_SPILL", str(windows))
+    monkeypatch.setenv("FTK_KLT_SPILL_BUDGET_MB", "1")
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "hard", "similarity")
+    uv = scenes.features(150, 320, 240, half=6, seed=5, border_fraction=0.05)
+    for method in METHODS:
+        for half, half_cols, cap in ((6, None, 100000), (2, 4, 70)):
+            gpu, cpu = run_pyramid(ftk, oracle, model, method, ref_levels, cur_levels, uv, half=half, half_cols=half_cols, max_points=cap,
+                                   luminance=(model == "lssd" and method == "fast"))
+            assert_parity(gpu, cpu, f"forced large-patch form ({windows}) {model}/{method} half=({half},{half_cols})")
+
+
+def test_half_patch_size_beyond_1023_is_a_clean_error(ftk):
     from feature_tracker_amd import _native
     ref_levels, cur_levels = scenes.scene(160, 120, 1)
-    klt = make_tracker(ftk, "affine", "inverse", 30)  # 24 chains x 61^2 terms do not fit 160 KB of LDS
+    klt = make_tracker(ftk, "basic", "inverse", 1024)
     with pytest.raises(_native.FtkError) as e:
         klt.TrackFeatures(ref_levels[0], cur_levels[0], np.float32([[80, 60]]))
     assert e.value.code == -4
