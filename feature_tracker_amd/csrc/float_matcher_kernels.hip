@@ -38,6 +38,7 @@
 // score (so a maximum names its own element): a perturbation of at most 31 ulp < 2e-6 of the cosine, i.e.
 // 1e-6 on the distance — eps stays below 5.6e-4 and 2 * eps below kMargin with > 25 % to spare.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "ftk_device.h"
 
@@ -53,6 +54,11 @@ constexpr int kPitch = kChunkK + 8;  // halfs; +16 B keeps the 128-bit fragment 
 constexpr float kMargin = 1.5e-3f;
 constexpr float kNormLo = 9.094947017729282e-13f;  // 2^-40
 constexpr float kNormHi = 1.099511627776e12f;      // 2^40
+// Candidates per row up to which a call runs as ONE exact launch (cosine_match_small_kernel: a wave walks its row's candidates
+// alone, so its time grows with n_cur); measured, scripts/cosine_small_ab.py
+constexpr int kCosineSmallCurNearby = 2048;  // 300 x 300 x 256 NearbyMatch 48.7 -> 10.7 us, 1 000 x 1 000 47.4 -> 21.3, 2 000 x 2 000 54.6 -> 40.3 (3 000 candidates: even)
+constexpr int kCosineSmallCurForce = 384;    // ForceMatch computes every pair exactly: 100 x 100 x 256 35.4 -> 14.8 us, 300 x 300 40.3 -> 32.1, 600 x 600 41.6 -> 59.2 (not taken)
+constexpr int kCosineSmallRefMax = 4096;
 
 __device__ __forceinline__ uint32_t order_key(float f) {
     const uint32_t b = __float_as_uint(f);
@@ -1374,7 +1380,155 @@ __global__ void __launch_bounds__(256) cosine_recheck_kernel(const CosineParams 
     }
 }
 
+// ---- small calls: the whole match in ONE launch, exact arithmetic only --------------------------
+// The sizes the reference's own programs match (<= 300 features a side: test_descriptor_matcher_superpoint.cpp:52-58) are bound by
+// the pipeline's launches (clear + prep + contraction + recheck: 42 us for 300 x 300 x 256 NearbyMatch, of which the pairs inside
+// the windows are a few thousand exact distances).  Here a wave owns a reference row, kept in registers — lane c of every octet
+// holds x[8 k + c], the elements its lane of Eigen's two packet accumulators multiplies — and its eight octets walk the
+// candidates j = octet, octet + 8, ...: window test, then x . y and y . y by the octet in Eigen's order (eigen_dot_octet's
+// operations on registers), the distance as the scalar code writes it, a running minimum per octet (strict '<': lowest j on
+// ties), merged over the octets at the end.  No workspace, no fp16 copies, no candidate lists; dims 64 / 128 / 256.
+template <int kSteps>
+__device__ __forceinline__ float small_octet_sum(float acc, int q, int base) {
+    // (acc of packet accumulator 0 + accumulator 1), then the SSE2 predux (p0 + p2) + (p1 + p3): Core/Redux.h
+    const float p = acc + __shfl(acc, base + 4 + q);  // meaningful in the octet's lanes 0 - 3
+    const float p0 = __shfl(p, base + 0), p1 = __shfl(p, base + 1), p2 = __shfl(p, base + 2), p3 = __shfl(p, base + 3);
+    return (p0 + p2) + (p1 + p3);
+}
+
+template <int kSteps, bool kNearby>
+__global__ void __launch_bounds__(256) cosine_match_small_kernel(const CosineParams p) {
+    const int lane = (int)threadIdx.x & 63, c = lane & 7, q = c & 3, octet = lane >> 3, base = lane & ~7;
+    const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
+    if (row >= p.n_ref) {
+        return;
+    }
+    constexpr int kDim = 8 * kSteps;
+    float x[kSteps];
+    {
+        const float *xr = p.ref + (size_t)row * kDim + c;
+#pragma unroll
+        for (int k = 0; k < kSteps; ++k) {
+            x[k] = xr[8 * k];
+        }
+    }
+    float acc = x[0] * x[0];
+#pragma unroll
+    for (int k = 1; k < kSteps; ++k) {
+        acc = acc + x[k] * x[k];
+    }
+    const float na = sqrtf(small_octet_sum<kSteps>(acc, q, base));  // ref.norm()
+    float pu = 0.0f, pv = 0.0f;
+    if (kNearby) {
+        pu = p.pred_uv[2 * (size_t)row];
+        pv = p.pred_uv[2 * (size_t)row + 1];
+    }
+    float best_d = __uint_as_float(0x7F800000u);
+    int best_j = -1;
+    int zero_j = INT_MAX;  // NearbyMatch: lowest in-window j whose distance is exactly 0 — where the reference's scan stops (:119)
+    // minimum over the candidates j <= j_limit of this lane's octet
+    auto scan = [&](int j_limit) {
+        best_d = __uint_as_float(0x7F800000u);
+        best_j = -1;
+        const int j_last = j_limit < p.n_cur - 1 ? j_limit : p.n_cur - 1;
+        for (int j0 = 0; j0 <= j_last; j0 += 64) {
+            // 64 candidates at a time through the window test (one per lane); the survivors — a few per row under a real window —
+            // are dealt to the octets eight at a time in ascending j, so that an octet meets its candidates in ascending order
+            const int jt = j0 + lane;
+            bool inside = jt <= j_last;
+            if (kNearby && inside) {
+                const float2 cu = reinterpret_cast<const float2 *>(p.cur_uv)[jt];
+                inside = !(fabsf(pu - cu.x) > p.max_col || fabsf(pv - cu.y) > p.max_row);  // descriptor_matcher.h:108-111
+            }
+            unsigned long long mask = __ballot(inside);
+            while (mask != 0ull) {  // wave-uniform
+                int mine = -1;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const int bit = mask != 0ull ? (int)__builtin_ctzll(mask) : -1;
+                    mine = octet == o ? bit : mine;
+                    mask &= mask - 1ull;
+                }
+                const bool live = mine >= 0;
+                const int j = j0 + (live ? mine : 0);
+                const float *yr = p.cur + (size_t)j * kDim + c;
+                float y[kSteps];
+#pragma unroll
+                for (int k = 0; k < kSteps; ++k) {
+                    y[k] = yr[8 * k];  // every load of the row in flight before the first product
+                }
+                float dot = x[0] * y[0], nn = y[0] * y[0];
+#pragma unroll
+                for (int k = 1; k < kSteps; ++k) {
+                    dot = dot + x[k] * y[k];
+                    nn = nn + y[k] * y[k];
+                }
+                const float nb = sqrtf(small_octet_sum<kSteps>(nn, q, base));  // cur.norm()
+                const float d = 0.5f - small_octet_sum<kSteps>(dot, q, base) / na / nb * 0.5f;
+                if (live && d < best_d) {  // j ascends within an octet: a tie keeps the earlier candidate
+                    best_d = d;
+                    best_j = j;
+                }
+                if (kNearby && live && d == 0.0f && j < zero_j) {
+                    zero_j = j;
+                }
+            }
+        }
+    };
+    // the minimum over the wave's eight octets: smallest distance, lowest j among equals (NaN distances never enter)
+    auto merge = [&]() {
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+            const float od = __shfl_xor(best_d, off);
+            const int oj = __shfl_xor(best_j, off);
+            if (oj >= 0 && (best_j < 0 || od < best_d || (od == best_d && oj < best_j))) {
+                best_d = od;
+                best_j = oj;
+            }
+        }
+    };
+    scan(INT_MAX);
+    merge();
+    if (kNearby) {
+        // the reference stops a row's scan at the first in-window candidate at distance exactly 0; only a NEGATIVE distance (a cosine
+        // rounded above 1) behind that stop could differ: then the minimum is taken again over j <= stop (cosine_recheck_kernel)
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+            zero_j = min(zero_j, __shfl_xor(zero_j, off));
+        }
+        if (best_j >= 0 && best_d < 0.0f && best_j > zero_j) {  // wave-uniform after the merges
+            scan(zero_j);
+            merge();
+        }
+    }
+    // strict '<' against a running minimum that starts at the threshold (descriptor_matcher.h:68-75, :114-117)
+    if (lane == 0 && best_j >= 0 && best_d < p.max_distance) {
+        p.index_pairs[row] = best_j;
+    }
+}
+
+template <int kSteps>
+hipError_t cosine_launch_small(const CosineParams &p, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.n_ref + 3) / 4));
+    if (p.pred_uv) {
+        hipLaunchKernelGGL((cosine_match_small_kernel<kSteps, true>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((cosine_match_small_kernel<kSteps, false>), grid, dim3(256), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace
+
+bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby) {
+    const char *env = getenv("FTK_COSINE_SMALL");  // experiment switch, read per call
+    if (env && atoi(env) == 0) {
+        return false;
+    }
+    const char *any = getenv("FTK_COSINE_SMALL_ANY");  // experiment: no size limit (scripts/cosine_small_ab.py)
+    const bool fits = (any && atoi(any) != 0) || (n_ref <= kCosineSmallRefMax && n_cur <= (nearby ? kCosineSmallCurNearby : kCosineSmallCurForce));
+    return (dim == 64 || dim == 128 || dim == 256) && fits;
+}
 
 size_t cosine_rs_lds_bytes(int dim_pad) {
     return sizeof(_Float16) * ((size_t)kTile * (dim_pad + 8) + (size_t)2 * kCurTile * kPitch) + sizeof(float4) * 2 * kCurTile +
@@ -1389,6 +1543,13 @@ size_t cosine_rr_lds_bytes(int dim_pad) {
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     if (p.n_ref <= 0 || p.n_cur <= 0) {
         return hipSuccess;
+    }
+    if (cosine_small_form(p.n_ref, p.n_cur, p.dim, p.pred_uv != nullptr)) {
+        switch (p.dim) {
+            case 64: return cosine_launch_small<8>(p, stream);
+            case 128: return cosine_launch_small<16>(p, stream);
+            default: return cosine_launch_small<32>(p, stream);
+        }
     }
     hipError_t e = hipMemsetAsync(p.clear_begin, 0, p.clear_bytes, stream);  // key 0 = "no candidate yet", counts 0
     if (e != hipSuccess) {

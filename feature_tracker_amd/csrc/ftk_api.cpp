@@ -2136,6 +2136,13 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
         splits = atoi(env);  // experiment override
     }
     splits = std::max(1, std::min(splits, tiles_total));
+    if (p.ref_stationary == 2 && !getenv("FTK_COSINE_SPLITS")) {
+        // At least TWO tiles per split: a walk's first step has no running maximum to cut against yet, so it lists its whole share
+        // of every row; with one-tile splits that is all there is, the rows' lists overflow (kCosineCandCap) and the recheck falls
+        // back to the exact scan of every pair — 2 000 x 2 000 x 256: 32 splits 17.6 + 3 591 us (contraction + recheck), 16 splits
+        // 20.2 + 11.8 us; 1 000 x 1 000 x 128: 16 splits 11.4 + 1 099 us, 8 splits 14.1 + 7.6 us (scripts/trace_cosine_shape.sh).
+        splits = std::max(1, std::min(splits, tiles_total / 2));
+    }
     p.splits = splits;
     p.tiles_per_split = (tiles_total + splits - 1) / splits;
     // workspace carve-up (every region 256-byte aligned)

@@ -177,6 +177,8 @@ struct MatchParams {
                             // ({u min, u max, v min, v max}; hamming_box_kernel fills them, the scan leaves early on them)
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
+// Whether match_launch runs a call of this shape as ONE launch without the keys workspace or the NearbyMatch boxes (small calls).
+bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits);
 
 // Float-descriptor (cosine distance) matcher: float_matcher_kernels.hip.
 constexpr int kCosineCandCap = 64;       // candidates kept per ref row before the row falls back to the exact scan
@@ -210,6 +212,8 @@ struct CosineParams {
 size_t cosine_rs_lds_bytes(int dim_pad);
 size_t cosine_rr_lds_bytes(int dim_pad);
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
+// Whether cosine_match_launch runs a call of this shape as one exact launch without the workspace (small calls).
+bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby);
 
 // DirectMethod (direct_kernels.hip): one workgroup per pose problem; all problems of a launch share
 // the pyramid depth and the options.

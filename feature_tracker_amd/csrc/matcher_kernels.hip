@@ -16,6 +16,8 @@
 // v_bcnt_u32_b32 (popcount-accumulate) — no MFMA, the data are bits.
 #include "ftk_device.h"
 
+#include <stdlib.h>
+
 namespace ftk {
 namespace {
 
@@ -897,6 +899,95 @@ __global__ void __launch_bounds__(64) hamming_match_mfma_kernel(const MatchParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small calls — the sizes the reference's own programs match (<= 300 features: test_descriptor_matcher_brief.cpp:59-65) — are
+// bound by their LAUNCHES, not by their pairs: boxes + scan + epilogue are three dependent launches of 4 us for 90 000 pairs.
+// Here the whole call is ONE launch with no workspace: a wave owns a reference row, its lanes share the candidates (lane l takes
+// j = l, l + 64, ...: coalesced 16-byte loads), each keeps the minimum of the packed key (distance << 20 | j) — smallest distance,
+// then lowest j: the reference's strict '<' scan (descriptor_matcher.h:68-75) — the wave reduces the 64 keys and lane 0 writes
+// index_pairs[row] if a match exists (untouched otherwise, :60-62).  NearbyMatch applies the window per pair (:108-111).
+// ---------------------------------------------------------------------------------------------------------------------------
+// Where the one-launch form wins (scripts/match_small_ab.py, event-bracketed calls, launches / one launch): 300 x 300 x 256 bits
+// 10.4 / 6.3 us, 1000 x 1000 10.2 / 7.0, 2000 x 2000 11.7 / 9.7, 3000 x 300 11.0 / 6.9, 300 x 3000 10.0 / 8.9 — and where it does not:
+// 2000 x 2000 x 512 15.9 / 20.4, 300 x 3000 x 512 10.6 / 15.2, 64 x 60 000 10.3 / 73 (a wave walks its row's candidates alone).
+constexpr long long kSmallMatchWork = 32ll << 20;  // n_ref * n_cur * n_words up to which the one-launch form is used ...
+constexpr int kSmallMatchRowWork = 24576;          // ... while a row's walk stays below n_cur * n_words = this
+constexpr int kSmallNoIndex = 0xFFFFF;
+
+template <int NW, bool kNearby>
+__global__ void __launch_bounds__(kBlock) hamming_match_small_kernel(const MatchParams p) {
+    const int lane = (int)threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kBlock / 64) + ((int)threadIdx.x >> 6));
+    if (row >= p.n_ref) {
+        return;
+    }
+    uint32_t ref[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        ref[w] = p.ref_words[(long long)row * NW + w];  // wave-uniform: scalar loads
+    }
+    float pred_u = 0.0f, pred_v = 0.0f;
+    if (kNearby) {
+        pred_u = p.pred_uv[2 * (long long)row];
+        pred_v = p.pred_uv[2 * (long long)row + 1];
+    }
+    // d < limit0 is the conservative integer form of `distance < kMaxValidDescriptorDistance` (the exact test closes the scan)
+    const int limit0 = (p.max_distance >= 0.0f && p.max_distance < 1000.0f) ? (int)p.max_distance + 1 : (p.max_distance < 0.0f ? 0 : 1023);
+    uint32_t best = ((uint32_t)limit0 << 20) | (uint32_t)kSmallNoIndex;
+#pragma unroll 2
+    for (int j = lane; j < p.n_cur; j += 64) {
+        uint32_t cur[NW];
+        if constexpr (NW % 4 == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.cur_words + (long long)j * NW);
+#pragma unroll
+            for (int q = 0; q < NW / 4; ++q) {
+                const uint4 four = src[q];
+                cur[4 * q] = four.x;
+                cur[4 * q + 1] = four.y;
+                cur[4 * q + 2] = four.z;
+                cur[4 * q + 3] = four.w;
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                cur[w] = p.cur_words[(long long)j * NW + w];
+            }
+        }
+        bool in_window = true;
+        if (kNearby) {
+            const float2 c = reinterpret_cast<const float2 *>(p.cur_uv)[j];
+            in_window = !(fabsf(pred_u - c.x) > p.max_col || fabsf(pred_v - c.y) > p.max_row);
+        }
+        uint32_t d = __popc(ref[0] ^ cur[0]);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            d += __popc(ref[w] ^ cur[w]);
+        }
+        const uint32_t key = (d << 20) | (uint32_t)j;
+        best = in_window ? min(best, key) : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        best = min(best, (uint32_t)__shfl_xor((int)best, off));
+    }
+    const int j_best = (int)(best & (uint32_t)kSmallNoIndex);
+    // `distance < min_distance && distance < threshold` with min_distance starting at the threshold
+    if (lane == 0 && j_best != kSmallNoIndex && (float)(best >> 20) < p.max_distance) {
+        p.index_pairs[row] = j_best;
+    }
+}
+
+template <int NW>
+hipError_t launch_small(const MatchParams &p, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.n_ref + kBlock / 64 - 1) / (kBlock / 64)));
+    if (p.pred_uv) {
+        hipLaunchKernelGGL((hamming_match_small_kernel<NW, true>), grid, dim3(kBlock), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((hamming_match_small_kernel<NW, false>), grid, dim3(kBlock), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(kBlock) match_epilogue_kernel(unsigned long long *keys, int32_t *index_pairs, int n_ref) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n_ref) {
@@ -951,11 +1042,28 @@ hipError_t launch_nw(const MatchParams &p, hipStream_t stream) {
 
 }  // namespace
 
+bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits) {
+    const char *env = getenv("FTK_MATCH_SMALL");  // experiment switch, read per call (scripts/match_small_ab.py flips it)
+    const bool allowed = !(env && atoi(env) == 0);
+    const bool width = n_words == 1 || n_words == 2 || n_words == 4 || n_words == 8 || n_words == 16;
+    return allowed && width && n_bits > 0 && n_cur < kSmallNoIndex && (long long)n_cur * n_words <= kSmallMatchRowWork &&
+           (long long)n_ref * n_cur * n_words <= kSmallMatchWork;
+}
+
 hipError_t match_launch(const MatchParams &p, hipStream_t stream) {
     if (p.n_ref <= 0 || p.n_cur <= 0) {
         return hipSuccess;
     }
     hipError_t e = hipSuccess;
+    if (match_small_form(p.n_ref, p.n_cur, p.n_words, p.n_bits)) {
+        switch (p.n_words) {
+            case 1: return launch_small<1>(p, stream);
+            case 2: return launch_small<2>(p, stream);
+            case 4: return launch_small<4>(p, stream);
+            case 8: return launch_small<8>(p, stream);
+            default: return launch_small<16>(p, stream);
+        }
+    }
     if (!p.keys_clean) {
         e = hipMemsetAsync(p.keys, 0xFF, sizeof(unsigned long long) * (size_t)p.n_ref, stream);
         if (e != hipSuccess) {

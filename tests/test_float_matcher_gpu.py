@@ -12,6 +12,14 @@ from feature_tracker_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["default", "launches"], autouse=True)
+def matcher_form(request, monkeypatch):
+    """Every test runs twice: with the default dispatch — the one-launch exact form (cosine_match_small_kernel: calls of few candidates) and the clear + prep + contraction + recheck pipeline by size — and with the one-launch form
+    switched off (FTK_COSINE_SMALL=0, read per call), so that small inputs also reach the kernels that serve the large ones."""
+    if request.param == "launches":
+        monkeypatch.setenv("FTK_COSINE_SMALL", "0")
+
+
 def matcher(ftk, max_dist, col=40, row=40):
     m = ftk.CosineMatcher()
     m.options().kMaxValidDescriptorDistance = max_dist

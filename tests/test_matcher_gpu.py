@@ -7,6 +7,14 @@ from feature_tracker_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["default", "launches"], autouse=True)
+def matcher_form(request, monkeypatch):
+    """Every test runs twice: with the default dispatch — the one-launch form (hamming_match_small_kernel: small calls) and the boxes + scan + epilogue launches by size — and with the one-launch form
+    switched off (FTK_MATCH_SMALL=0, read per call), so that small inputs also reach the kernels that serve the large ones."""
+    if request.param == "launches":
+        monkeypatch.setenv("FTK_MATCH_SMALL", "0")
+
+
 def matcher(ftk, max_dist, col=40, row=40):
     m = ftk.BriefMatcher()
     m.options().kMaxValidDescriptorDistance = max_dist
