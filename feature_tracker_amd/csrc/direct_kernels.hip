@@ -24,13 +24,23 @@
 // and is kept in LDS for the producers; the Jacobian of the pixel w.r.t. the pose (:145-148) depends
 // on the reference-frame point only and is recomputed per lane (12 products).
 // fp32 throughout, no contraction; quaternion arithmetic as defined in oracle/oracle_direct_method.c.
-#define FTK_CHAIN_ROUND 4
+#ifndef FTK_DM_CHAIN_ROUND
+#define FTK_DM_CHAIN_ROUND 4
+#endif
+#define FTK_CHAIN_ROUND FTK_DM_CHAIN_ROUND
 #include "klt_common.h"
 
 namespace ftk {
 namespace {
 
-constexpr int kDmWaves = 8;
+// Experiment switches (scripts/build_variant.sh): ten waves (nine producers) and chain rounds of eight reads were measured — 3.56 /
+// 3.49 / 3.55 ms against 3.49 for the 300-point problem — as was a raised priority for the chain wave (3.47): the launch is bound by
+// what ONE compute unit can issue per iteration (793 chunks x ~390 producer instructions + 50 700 x 1.4 chain instructions), not by
+// the split of that work over its waves (docs/LAB_NOTES.md).
+#ifndef FTK_DM_WAVES
+#define FTK_DM_WAVES 8
+#endif
+constexpr int kDmWaves = FTK_DM_WAVES;
 constexpr int kDmProducers = kDmWaves - 1;
 constexpr int kDmChunk = 64;
 constexpr int kDmRow = kDmChunk + 4;  // row pitch in floats: keeps the consumer's b128 reads on distinct banks
@@ -83,14 +93,37 @@ __device__ __forceinline__ void q_rotate(const Quat &q, float vx, float vy, floa
     oz = (vz + q.w * uz) + cz;
 }
 
-// GrayImage::GetPixelValue straight from global memory (no LDS window: every tap of a problem is
-// touched once per iteration, and the images stay in L2).
-__device__ __forceinline__ bool tap_global(const DevImage &im, float row, float col, float &value) {
-    Win none;
-    none.data = nullptr;
-    none.r_lo = none.c_lo = 0;
-    none.rows = none.cols = 0;
-    return sample(im, none, row, col, value);
+// GrayImage::GetPixelValue straight from global memory (no LDS window: every tap of a problem is touched once per iteration,
+// and the images stay in L2), in two halves so that the SIX taps of a term have all their 24 byte loads in flight before the
+// first value is formed: the producers were bound by six dependent round trips per term (sample() returns early on an invalid
+// coordinate, and the compiler keeps the taps behind one another).  An invalid tap reads pixel (0, 0) and is not used.  Same
+// validity rule, fractions, weight products and sum order as sample() (klt_common.h).
+struct DmTap {
+    bool valid;
+    float w_tl, w_tr, w_bl, w_br;
+    uint8_t p00, p01, p10, p11;
+};
+
+__device__ __forceinline__ void dm_tap_issue(DmTap &t, const DevImage &im, float row, float col) {
+    t.valid = row >= 0.0f && col >= 0.0f && row <= (float)(im.rows - 1) && col <= (float)(im.cols - 1);
+    const float r = t.valid ? row : 0.0f, c = t.valid ? col : 0.0f;
+    const int r0 = (int)r, c0 = (int)c;
+    const float sub_row = __builtin_amdgcn_fractf(r), sub_col = __builtin_amdgcn_fractf(c);
+    const float inv_sub_row = 1.0f - sub_row, inv_sub_col = 1.0f - sub_col;
+    t.w_tl = inv_sub_row * inv_sub_col;
+    t.w_tr = inv_sub_row * sub_col;
+    t.w_bl = sub_row * inv_sub_col;
+    t.w_br = sub_row * sub_col;
+    const int r1 = (r0 + 1 < im.rows) ? r0 + 1 : r0, c1 = (c0 + 1 < im.cols) ? c0 + 1 : c0;
+    const unsigned top = __umul24((unsigned)r0, (unsigned)im.cols), bottom = __umul24((unsigned)r1, (unsigned)im.cols);
+    t.p00 = im.data[top + (unsigned)c0];
+    t.p01 = im.data[top + (unsigned)c1];
+    t.p10 = im.data[bottom + (unsigned)c0];
+    t.p11 = im.data[bottom + (unsigned)c1];
+}
+
+__device__ __forceinline__ float dm_tap_value(const DmTap &t) {
+    return t.w_tl * (float)t.p00 + t.w_tr * (float)t.p01 + t.w_bl * (float)t.p10 + t.w_br * (float)t.p11;
 }
 
 __device__ __forceinline__ float dm_chain_chunk(float acc, const float *row) {
@@ -120,8 +153,10 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
     const bool consumer = wave == 0;
     float *const ring = reinterpret_cast<float *>(dm_lds);                   // [2][kDmProducers][kDmTerms][kDmRow]
     float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;         // [96]: 27 sums | H 6x6 at 32 | dx at 68
-    // [n_track][4]: cur u, cur v, usable, - ; in LDS, or in device memory for problems too large for it (written and read
-    // by this workgroup only, with a workgroup barrier in between)
+    // [n_track][4] float4: {cur u, cur v, usable, scaled ref u} (every iteration) | {scaled ref v, j00, j02, j03} | {j04, j05, j11, j12} |
+    // {j13, j14, j15, -} (once per level: the reference position at this level and the non-trivial entries of jacobian_pixel_xi,
+    // :145-148, which depend on the reference-frame point and the level's intrinsics only); in LDS, or in device memory for
+    // problems too large for it (written and read by this workgroup only, with a workgroup barrier in between)
     float4 *const feat = pr.feat != nullptr ? pr.feat : reinterpret_cast<float4 *>(sums + 96);
     const int n = pr.n;
     const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
@@ -129,6 +164,25 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
     const long long total_terms = (long long)n_track * P;
     const int n_chunks = (int)((total_terms + kDmChunk - 1) / kDmChunk);
     const int n_rounds = (n_chunks + kDmProducers - 1) / kDmProducers;
+    // Walking the (feature, pixel) stream without a division per term: a wave's first chunk gives its lane's (feature, pixel) once,
+    // every further chunk is a constant number of terms on (all waves sample: kDmWaves chunks; the producers: kDmProducers) =
+    // step_i features and step_pix pixels, with one carry.
+    const int step_all_i = (kDmWaves * kDmChunk) / P, step_all_pix = (kDmWaves * kDmChunk) % P;
+    const int step_prod_i = (kDmProducers * kDmChunk) / P, step_prod_pix = (kDmProducers * kDmChunk) % P;
+    const float inv_patch_cols = 1.0f / (float)pp.patch_cols;
+    auto term_start = [&](int first_chunk, int &i, int &pix) {
+        const long long g = (long long)first_chunk * kDmChunk + lane;
+        i = (int)(g / P);
+        pix = (int)(g - (long long)i * P);
+    };
+    auto term_advance = [&](int &i, int &pix, int step_i, int step_pix) {
+        i += step_i;
+        pix += step_pix;
+        if (pix >= P) {
+            pix -= P;
+            ++i;
+        }
+    };
 
     // pose in registers, identical in every thread
     Quat q = {pr.pose[1], pr.pose[2], pr.pose[3], pr.pose[0]};
@@ -143,6 +197,20 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
             // scaled_K / scaled_ref_points_: value / scale, then doubled once per finer level (exact), :47-52,64-69
             const float up = (float)(1 << (pp.n_levels - 1 - level));
             const float fx = (pr.K[0] / scale) * up, fy = (pr.K[1] / scale) * up, cx = (pr.K[2] / scale) * up, cy = (pr.K[3] / scale) * up;
+            // ---- per level: the part of a term that does not change with the pose ----
+            for (int i = tid; i < n_track; i += kDmWaves * kWave) {
+                const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+                const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
+                const float zi = 1.0f / prz;
+                const float z2i = zi * zi;
+                // jacobian_pixel_xi, :145-148 — operator precedence as written (j01 = j10 = 0)
+                const float j00 = fx * zi, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i, j05 = -fx * pry * zi;
+                const float j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i, j15 = fy * prx * zi;
+                feat[4 * i].w = scaled_ru;
+                feat[4 * i + 1] = make_float4(scaled_rv, j00, j02, j03);
+                feat[4 * i + 2] = make_float4(j04, j05, j11, j12);
+                feat[4 * i + 3] = make_float4(j13, j14, j15, 0.0f);
+            }
             bool stop = false;
             for (uint32_t iter = 0; iter < pp.max_iteration && !stop; ++iter) {
                 ++iterations;
@@ -164,45 +232,51 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                             pr.cur_uv[2 * i + 1] = cv;
                         }
                     }
-                    feat[i] = make_float4(cu, cv, usable ? 1.0f : 0.0f, 0.0f);
+                    feat[4 * i].x = cu;
+                    feat[4 * i].y = cv;
+                    feat[4 * i].z = usable ? 1.0f : 0.0f;
                 }
                 __syncthreads();
 
                 // the 1 x 6 Jacobian row and the residual of term `lane` of a 64-term chunk of the (feature, pixel) stream (:144-168)
-                auto chunk_terms = [&](int chunk, float (&jac)[6], float &residual) {
-                    const long long g = (long long)chunk * kDmChunk + lane;
+                // (i, pix): the feature and the patch pixel of this lane's term of `chunk` — kept by the caller, which walks its chunks
+                // with a constant stride (term_advance below: no division per term; a 64-bit one cost more than the six taps)
+                auto chunk_terms = [&](int chunk, int i, int pix, float (&jac)[6], float &residual) {
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         jac[r] = 0.0f;
                     }
                     residual = 0.0f;
-                    if (chunk < n_chunks && g < total_terms) {
-                        const int i = (int)(g / P);
-                        const int pix = (int)(g - (long long)i * P);
-                        const int prow = pix / pp.patch_cols, pcol = pix - prow * pp.patch_cols;
-                        const float4 f = feat[i];
+                    if (chunk < n_chunks && i < n_track) {
+                        int prow = (int)((float)pix * inv_patch_cols);  // pix < 2^22: off by at most one, put right by the remainder
+                        int pcol = pix - prow * pp.patch_cols;
+                        if (pcol < 0) {
+                            --prow;
+                            pcol += pp.patch_cols;
+                        } else if (pcol >= pp.patch_cols) {
+                            ++prow;
+                            pcol -= pp.patch_cols;
+                        }
+                        const float4 f = feat[4 * i];
                         if (f.z != 0.0f) {
+                            const float4 f1 = feat[4 * i + 1], f2 = feat[4 * i + 2], f3 = feat[4 * i + 3];
                             const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
-                            const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
-                            const float row_i = drow + scaled_rv, col_i = dcol + scaled_ru;
+                            const float row_i = drow + f1.x, col_i = dcol + f.w;
                             const float row_j = drow + f.y, col_j = dcol + f.x;
-                            float t0, t1, t2, t3, t4, t5;
                             // all six must be valid (:160-162); evaluation order does not matter for the result
-                            bool ok = tap_global(cur, row_j, col_j - 1.0f, t0);
-                            ok = tap_global(cur, row_j, col_j + 1.0f, t1) && ok;
-                            ok = tap_global(cur, row_j - 1.0f, col_j, t2) && ok;
-                            ok = tap_global(cur, row_j + 1.0f, col_j, t3) && ok;
-                            ok = tap_global(ref, row_i, col_i, t4) && ok;
-                            ok = tap_global(cur, row_j, col_j, t5) && ok;
+                            DmTap a0, a1, a2, a3, a4, a5;
+                            dm_tap_issue(a0, cur, row_j, col_j - 1.0f);
+                            dm_tap_issue(a1, cur, row_j, col_j + 1.0f);
+                            dm_tap_issue(a2, cur, row_j - 1.0f, col_j);
+                            dm_tap_issue(a3, cur, row_j + 1.0f, col_j);
+                            dm_tap_issue(a4, ref, row_i, col_i);
+                            dm_tap_issue(a5, cur, row_j, col_j);
+                            const bool ok = a0.valid && a1.valid && a2.valid && a3.valid && a4.valid && a5.valid;
+                            const float t0 = dm_tap_value(a0), t1 = dm_tap_value(a1), t2 = dm_tap_value(a2), t3 = dm_tap_value(a3), t4 = dm_tap_value(a4),
+                                        t5 = dm_tap_value(a5);
                             if (ok) {
-                                const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
-                                const float zi = 1.0f / prz;
-                                const float z2i = zi * zi;
-                                // jacobian_pixel_xi, :145-148 — operator precedence as written
-                                const float j00 = fx * zi, j01 = 0.0f, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i,
-                                            j05 = -fx * pry * zi;
-                                const float j10 = 0.0f, j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i,
-                                            j15 = fy * prx * zi;
+                                const float j00 = f1.y, j01 = 0.0f, j02 = f1.z, j03 = f1.w, j04 = f2.x, j05 = f2.y;
+                                const float j10 = 0.0f, j11 = f2.z, j12 = f2.w, j13 = f3.x, j14 = f3.y, j15 = f3.z;
                                 const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
                                 residual = t5 - t4;
                                 jac[0] = gx * j00 + gy * j10;
@@ -223,9 +297,12 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                     for (int k = 0; k < kDmTerms; ++k) {
                         part[k] = 0.0f;
                     }
+                    int ti, tpix;
+                    term_start(wave, ti, tpix);
                     for (int chunk = wave; chunk < n_chunks; chunk += kDmWaves) {
                         float jac[6], residual;
-                        chunk_terms(chunk, jac, residual);
+                        chunk_terms(chunk, ti, tpix, jac, residual);
+                        term_advance(ti, tpix, step_all_i, step_all_pix);
                         int k = 0;
 #pragma unroll
                         for (int r = 0; r < 6; ++r) {
@@ -262,12 +339,17 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                         }
                     }
                 } else {
+                int ti = 0, tpix = 0;
+                if (!consumer) {
+                    term_start(wave - 1, ti, tpix);
+                }
                 for (int round = 0; round < n_rounds; ++round) {
                     if (!consumer) {
                         const int chunk = round * kDmProducers + (wave - 1);
                         float *slot = ring + (((round & 1) * kDmProducers + (wave - 1)) * kDmTerms) * kDmRow;
                         float jac[6], residual;
-                        chunk_terms(chunk, jac, residual);
+                        chunk_terms(chunk, ti, tpix, jac, residual);
+                        term_advance(ti, tpix, step_prod_i, step_prod_pix);
                         // an unused pixel contributes exact zeros (x + (+-0) == x, and the sums start at +0)
                         int k = 0;
 #pragma unroll
@@ -365,7 +447,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
 }  // namespace
 
 size_t direct_lds_bytes(uint32_t max_features) {
-    return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 96 + 4 * (size_t)max_features);
+    return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 96 + 16 * (size_t)max_features);
 }
 
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream) {

@@ -1958,12 +1958,12 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         max_features = std::max(max_features, tracked);
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
-    // The per-feature projections of an iteration live in LDS while they fit beside the product ring (16 B per tracked
-    // feature, up to kDirectLdsFeatures); larger problems keep that table in a context-owned device buffer instead —
+    // The per-feature table (an iteration's projections, a level's reference positions and Jacobians) lives in LDS while it fits
+    // beside the product ring (64 B per tracked feature, up to kDirectLdsFeatures); larger problems keep that table in a context-owned device buffer instead —
     // same kernel, same arithmetic, same order of the sums.
     const bool feat_in_global = max_features > ftk::kDirectLdsFeatures;
     if (feat_in_global) {
-        const size_t per = align_up(sizeof(float) * 4 * (size_t)max_features, 256);
+        const size_t per = align_up(sizeof(float) * 16 * (size_t)max_features, 256);
         const int rc = ensure_device_buffer(ctx, &ctx->direct_feat, &ctx->direct_feat_bytes, per * (size_t)n_problems);
         if (rc != FTK_OK) {
             return rc;

@@ -231,7 +231,11 @@ struct DirectProblem {
     int32_t status_valid;   // 0: reset every status to kTracked first (direct_method_tracker.cpp:73-75)
     float4 *feat;           // null: the per-feature projection table lives in LDS; else n_track entries of device memory (large problems)
 };
-constexpr uint32_t kDirectLdsFeatures = 3072;  // tracked features whose projection table still fits in LDS beside the ring
+#if defined(FTK_DM_WAVES) && FTK_DM_WAVES > 8
+constexpr uint32_t kDirectLdsFeatures = 384;  // (experiment builds with more producer waves: a larger ring)
+#else
+constexpr uint32_t kDirectLdsFeatures = 768;  // tracked features whose per-feature table (64 B each) still fits in LDS beside the ring
+#endif
 struct DirectParams {
     const DirectProblem *problems;  // device memory, one per workgroup
     int32_t tree;                   // throughput mode (ftk_set_reduction_mode): butterfly sums instead of the scalar loop's order

@@ -928,8 +928,8 @@ __device__ __forceinline__ int chain_tie(float acc) {
     return zero;
 }
 
+#if FTK_CHAIN_ROUND == 4  // written for 4 batches of 16 terms (a 64-pixel chunk); translation units with another round do not use it
 __device__ __forceinline__ float chain_chunk(float acc, const float *row) {
-    static_assert(kChainRound == 4, "chain_chunk is written for 4 batches of 16 terms (a 64-pixel chunk)");
     const float4 *t = reinterpret_cast<const float4 *>(row);
     float4 qa[kChainRound], qb[kChainRound];
     chain_load(qa, t);
@@ -942,6 +942,7 @@ __device__ __forceinline__ float chain_chunk(float acc, const float *row) {
     acc = chain_consume_all(acc, qb);
     return acc;
 }
+#endif
 
 
 constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked sweep / chain loops = one wave round
