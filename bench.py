@@ -878,6 +878,8 @@ def main():
             configs_leg["config4_matcher"] = matcher_config_leg(k_cfg, ctx, dev, stream)
             configs_leg["config4_tracker_luminance"] = tracker_config_leg("config4_luminance", dict(synth.CONFIGS["config4"], luminance=True), k_cfg, ctx, dev, stream, src_hash)
             configs_leg["basic_fast_2000_13x13"] = tracker_config_leg("basic_fast", dict(synth.CONFIGS["config2"], half=6, method="fast"), k_cfg, ctx, dev, stream, src_hash)
+            # the reference's default method (kFast) of the other two trackers, at sizes their one-wave kernels serve
+            configs_leg["affine_fast_5000_13x13"] = tracker_config_leg("affine_fast", dict(synth.CONFIGS["config3"], width=640, height=480, levels=4, method="fast"), k_cfg, ctx, dev, stream, src_hash)
             configs_leg["seconds_spent"] = time.perf_counter() - t_cfg
         if world == 1 and args.features == 0 and not args.no_host_call_leg:
             host_call = host_call_leg(cfg, ref_levels, cur_levels, uv, first_uv, first_st)

@@ -249,6 +249,16 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     if (n > 2048 && p.P <= 256 && !(model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT))) {
         waves = 1;
     }
+    // The non-fast LSSD variants sweep the patch twice per iteration (twelve taps a pixel) and Basic direct five current taps: they
+    // keep several waves per feature for longer (13 x 13, one / two / three waves: LSSD inverse 2 000 features 226 / 200 / 180 us,
+    // 3 000: 210 / 183 / 202, 5 000: 225 / 200 / 173, 10 000: 235 / 240 / 285; Basic direct 3 000: 41.6 / 34.9 / 47.8, 10 000: 89 / 111 / 133).
+    if (p.P > 64 && p.P <= 256 && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
+        if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_INVERSE) {
+            waves = n <= 2048 ? (p.P > 128 ? 3 : 2) : (n <= 6144 ? 2 : 1);
+        } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT) {
+            waves = n <= 1024 ? waves : (n <= 4096 ? 2 : 1);
+        }
+    }
     if (const char *env = getenv("FTK_KLT_WAVES")) {
         waves = atoi(env);  // experiment override
     }

@@ -60,6 +60,8 @@ def klt_round():
     n = int(rs.choice([1, 7, 64, 300, 1000, 2500]))
     # half of the draws on the patch sizes that have compile-time instantiations (5, 6, 10: klt_fill_geometry), half anywhere in [1, 10]
     half, half_c = (int(rs.choice([5, 6, 10])) if rs.rand() < 0.5 else int(rs.randint(1, 11))), None
+    if rs.rand() < 0.06:  # now and then a patch beyond a workgroup's LDS: the large-patch form (few features: the oracle walks every pixel)
+        half, n = int(rs.choice([19, 24, 33, 45])), int(rs.choice([1, 7, 24]))
     if rs.rand() < 0.2:
         half_c = int(rs.randint(1, 11))
     uv = synth.make_features(n, w, h, seed=int(rs.randint(1 << 30)), margin=min(40.0, w / 8.0), border_fraction=float(rs.choice([0.0, 0.05, 0.3])), half=half)
