@@ -25,7 +25,7 @@
 // on the reference-frame point only and is recomputed per lane (12 products).
 // fp32 throughout, no contraction; quaternion arithmetic as defined in oracle/oracle_direct_method.c.
 #ifndef FTK_DM_CHAIN_ROUND
-#define FTK_DM_CHAIN_ROUND 4
+#define FTK_DM_CHAIN_ROUND 8  // 32 terms per prefetch round (four: +2 % on the spread kernel, whose consumer does nothing but chain; the one-workgroup kernel does not care)
 #endif
 #define FTK_CHAIN_ROUND FTK_DM_CHAIN_ROUND
 #include "klt_common.h"
@@ -33,10 +33,11 @@
 namespace ftk {
 namespace {
 
-// Experiment switches (scripts/build_variant.sh): ten waves (nine producers) and chain rounds of eight reads were measured — 3.56 /
-// 3.49 / 3.55 ms against 3.49 for the 300-point problem — as was a raised priority for the chain wave (3.47): the launch is bound by
-// what ONE compute unit can issue per iteration (793 chunks x ~390 producer instructions + 50 700 x 1.4 chain instructions), not by
-// the split of that work over its waves (docs/LAB_NOTES.md).
+// Experiment switches (scripts/build_variant.sh).  In the ONE-workgroup kernel ten waves (nine producers), chain rounds of eight reads and
+// a raised priority for the chain wave change nothing (3.56 / 3.49 / 3.47 ms against 3.49 for the 300-point problem): that kernel is
+// bound by what one compute unit can issue per iteration (793 chunks x ~390 producer instructions + 50 700 x 1.4 chain instructions),
+// not by the split of that work over its waves — which is why a single problem is SPREAD over the chip (direct_track_spread_kernel
+// below: 2.53 ms); there the consumer only chains, and both switches pay (docs/LAB_NOTES.md).
 #ifndef FTK_DM_WAVES
 #define FTK_DM_WAVES 8
 #endif
@@ -142,6 +143,139 @@ __device__ __forceinline__ float dm_chain_chunk(float acc, const float *row) {
     return acc;
 }
 
+// ---- pieces shared by the one-workgroup kernel and the spread kernel (same arithmetic by construction) ----
+
+// Per level: the part of feature i's terms that does not change with the pose -> feat[4 i].w, feat[4 i + 1 .. 3]
+__device__ __forceinline__ void dm_level_row(float4 *feat, const DirectProblem &pr, int i, float scale, float up, float fx, float fy) {
+    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+    const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
+    const float zi = 1.0f / prz;
+    const float z2i = zi * zi;
+    // jacobian_pixel_xi, :145-148 — operator precedence as written (j01 = j10 = 0)
+    const float j00 = fx * zi, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i, j05 = -fx * pry * zi;
+    const float j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i, j15 = fy * prx * zi;
+    feat[4 * i].w = scaled_ru;
+    feat[4 * i + 1] = make_float4(scaled_rv, j00, j02, j03);
+    feat[4 * i + 2] = make_float4(j04, j05, j11, j12);
+    feat[4 * i + 3] = make_float4(j13, j14, j15, 0.0f);
+}
+
+// Projection of feature i with the current pose (:128-142) -> feat[4 i].xyz; write_uv: also cur_pixel_uv (:141-142)
+__device__ __forceinline__ void dm_project(float4 *feat, const DirectProblem &pr, int i, const Quat &q_inv, float px, float py, float pz, float fx, float fy,
+                                           float cx, float cy, bool write_uv) {
+    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
+    float cu = 0.0f, cv = 0.0f;
+    bool usable = !(prz < kZeroFloat);
+    if (usable) {
+        float cxp, cyp, czp;
+        q_rotate(q_inv, prx - px, pry - py, prz - pz, cxp, cyp, czp);
+        usable = !(czp < kZeroFloat);
+        if (usable) {
+            const float nx = cxp / czp, ny = cyp / czp;
+            cu = fx * nx + cx;
+            cv = fy * ny + cy;
+            if (write_uv) {
+                pr.cur_uv[2 * i] = cu;
+                pr.cur_uv[2 * i + 1] = cv;
+            }
+        }
+    }
+    feat[4 * i].x = cu;
+    feat[4 * i].y = cv;
+    feat[4 * i].z = usable ? 1.0f : 0.0f;
+}
+
+// The 1 x 6 Jacobian row and the residual of one term of the (feature, pixel) stream (:144-168); in_range: the term exists
+__device__ __forceinline__ void dm_term(const float4 *feat, const DirectParams &pp, const DevImage &ref, const DevImage &cur, bool in_range, int i, int pix,
+                                        float inv_patch_cols, float (&jac)[6], float &residual) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        jac[r] = 0.0f;
+    }
+    residual = 0.0f;
+    if (in_range) {
+        int prow = (int)((float)pix * inv_patch_cols);  // pix < 2^22: off by at most one, put right by the remainder
+        int pcol = pix - prow * pp.patch_cols;
+        if (pcol < 0) {
+            --prow;
+            pcol += pp.patch_cols;
+        } else if (pcol >= pp.patch_cols) {
+            ++prow;
+            pcol -= pp.patch_cols;
+        }
+        const float4 f = feat[4 * i];
+        if (f.z != 0.0f) {
+            const float4 f1 = feat[4 * i + 1], f2 = feat[4 * i + 2], f3 = feat[4 * i + 3];
+            const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
+            const float row_i = drow + f1.x, col_i = dcol + f.w;
+            const float row_j = drow + f.y, col_j = dcol + f.x;
+            // all six must be valid (:160-162); evaluation order does not matter for the result
+            DmTap a0, a1, a2, a3, a4, a5;
+            dm_tap_issue(a0, cur, row_j, col_j - 1.0f);
+            dm_tap_issue(a1, cur, row_j, col_j + 1.0f);
+            dm_tap_issue(a2, cur, row_j - 1.0f, col_j);
+            dm_tap_issue(a3, cur, row_j + 1.0f, col_j);
+            dm_tap_issue(a4, ref, row_i, col_i);
+            dm_tap_issue(a5, cur, row_j, col_j);
+            const bool ok = a0.valid && a1.valid && a2.valid && a3.valid && a4.valid && a5.valid;
+            const float t0 = dm_tap_value(a0), t1 = dm_tap_value(a1), t2 = dm_tap_value(a2), t3 = dm_tap_value(a3), t4 = dm_tap_value(a4),
+                        t5 = dm_tap_value(a5);
+            if (ok) {
+                const float j00 = f1.y, j01 = 0.0f, j02 = f1.z, j03 = f1.w, j04 = f2.x, j05 = f2.y;
+                const float j10 = 0.0f, j11 = f2.z, j12 = f2.w, j13 = f3.x, j14 = f3.y, j15 = f3.z;
+                const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
+                residual = t5 - t4;
+                jac[0] = gx * j00 + gy * j10;
+                jac[1] = gx * j01 + gy * j11;
+                jac[2] = gx * j02 + gy * j12;
+                jac[3] = gx * j03 + gy * j13;
+                jac[4] = gx * j04 + gy * j14;
+                jac[5] = gx * j05 + gy * j15;
+            }
+        }
+    }
+}
+
+// wave 0: the 27 sums (lane k < 27 holds sum k) -> full symmetric H in LDS -> lane-parallel LDLT (klt_common.h) -> dx at sums[68..74)
+__device__ __forceinline__ void dm_solve(float *sums, float acc, int lane) {
+    if (lane < kDmTerms) {
+        sums[lane] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
+    if (lane < 36) {
+        const int r0 = lane / 6, c0 = lane - 6 * r0;
+        const int r = r0 < c0 ? r0 : c0, cc = r0 < c0 ? c0 : r0;
+        sums[32 + lane] = sums[r * (13 - r) / 2 + (cc - r)];  // upper triangle, row-major
+    }
+    __builtin_amdgcn_wave_barrier();
+    const Ldlt6 fac = ldlt6_factor(sums + 32, lane);
+    ldlt6_solve(fac, sums + 21, sums + 68, lane);
+}
+
+// The pose update (:170-181), redundantly in every thread; returns whether the level's iterations stop
+__device__ __forceinline__ bool dm_update_pose(const float *sums, float converge, Quat &q, float &px, float &py, float &pz) {
+    float dx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        dx[k] = sums[68 + k];
+    }
+    bool has_nan = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        has_nan = has_nan || isnan(dx[k]);
+    }
+    if (has_nan) {
+        return true;  // :173
+    }
+    px += dx[0];
+    py += dx[1];
+    pz += dx[2];
+    Quat dq = {dx[3] * 0.5f, dx[4] * 0.5f, dx[5] * 0.5f, 1.0f};
+    q = q_normalized(q_mul(q_normalized(dq), q));
+    const float sq = (((dx[0] * dx[0] + dx[2] * dx[2]) + (dx[1] * dx[1] + dx[3] * dx[3])) + dx[4] * dx[4]) + dx[5] * dx[5];
+    return sq < converge;  // :181
+}
+
 // TREE: the throughput mode (ftk_set_reduction_mode) — all eight waves sample, every lane keeps 27 partial sums, a butterfly and a
 // fixed-order sum over the waves replace the ring and wave 0's exact-order chains (50 700 dependent adds per iteration at the
 // reference's 300 points x 13 x 13).  Same products, another summation order: NOT bit-identical to the scalar loop; reported only.
@@ -199,17 +333,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
             const float fx = (pr.K[0] / scale) * up, fy = (pr.K[1] / scale) * up, cx = (pr.K[2] / scale) * up, cy = (pr.K[3] / scale) * up;
             // ---- per level: the part of a term that does not change with the pose ----
             for (int i = tid; i < n_track; i += kDmWaves * kWave) {
-                const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
-                const float scaled_ru = (pr.ref_uv[2 * i] / scale) * up, scaled_rv = (pr.ref_uv[2 * i + 1] / scale) * up;
-                const float zi = 1.0f / prz;
-                const float z2i = zi * zi;
-                // jacobian_pixel_xi, :145-148 — operator precedence as written (j01 = j10 = 0)
-                const float j00 = fx * zi, j02 = -fx * prx * z2i, j03 = -fx * prx * pry * z2i, j04 = fx + fx * prx * prx * z2i, j05 = -fx * pry * zi;
-                const float j11 = fy * zi, j12 = -fy * pry * z2i, j13 = -fy - fy * pry * pry * z2i, j14 = fy * prx * pry * z2i, j15 = fy * prx * zi;
-                feat[4 * i].w = scaled_ru;
-                feat[4 * i + 1] = make_float4(scaled_rv, j00, j02, j03);
-                feat[4 * i + 2] = make_float4(j04, j05, j11, j12);
-                feat[4 * i + 3] = make_float4(j13, j14, j15, 0.0f);
+                dm_level_row(feat, pr, i, scale, up, fx, fy);
             }
             bool stop = false;
             for (uint32_t iter = 0; iter < pp.max_iteration && !stop; ++iter) {
@@ -217,24 +341,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                 // ---- projection of every feature with the current pose (:128-142) ----
                 const Quat q_inv = q_inverse(q);
                 for (int i = tid; i < n_track; i += kDmWaves * kWave) {
-                    const float prx = pr.p_ref[3 * i], pry = pr.p_ref[3 * i + 1], prz = pr.p_ref[3 * i + 2];
-                    float cu = 0.0f, cv = 0.0f;
-                    bool usable = !(prz < kZeroFloat);
-                    if (usable) {
-                        float cxp, cyp, czp;
-                        q_rotate(q_inv, prx - px, pry - py, prz - pz, cxp, cyp, czp);
-                        usable = !(czp < kZeroFloat);
-                        if (usable) {
-                            const float nx = cxp / czp, ny = cyp / czp;
-                            cu = fx * nx + cx;
-                            cv = fy * ny + cy;
-                            pr.cur_uv[2 * i] = cu;
-                            pr.cur_uv[2 * i + 1] = cv;
-                        }
-                    }
-                    feat[4 * i].x = cu;
-                    feat[4 * i].y = cv;
-                    feat[4 * i].z = usable ? 1.0f : 0.0f;
+                    dm_project(feat, pr, i, q_inv, px, py, pz, fx, fy, cx, cy, true);
                 }
                 __syncthreads();
 
@@ -242,52 +349,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                 // (i, pix): the feature and the patch pixel of this lane's term of `chunk` — kept by the caller, which walks its chunks
                 // with a constant stride (term_advance below: no division per term; a 64-bit one cost more than the six taps)
                 auto chunk_terms = [&](int chunk, int i, int pix, float (&jac)[6], float &residual) {
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        jac[r] = 0.0f;
-                    }
-                    residual = 0.0f;
-                    if (chunk < n_chunks && i < n_track) {
-                        int prow = (int)((float)pix * inv_patch_cols);  // pix < 2^22: off by at most one, put right by the remainder
-                        int pcol = pix - prow * pp.patch_cols;
-                        if (pcol < 0) {
-                            --prow;
-                            pcol += pp.patch_cols;
-                        } else if (pcol >= pp.patch_cols) {
-                            ++prow;
-                            pcol -= pp.patch_cols;
-                        }
-                        const float4 f = feat[4 * i];
-                        if (f.z != 0.0f) {
-                            const float4 f1 = feat[4 * i + 1], f2 = feat[4 * i + 2], f3 = feat[4 * i + 3];
-                            const float drow = (float)(prow - pp.half_rows), dcol = (float)(pcol - pp.half_cols);
-                            const float row_i = drow + f1.x, col_i = dcol + f.w;
-                            const float row_j = drow + f.y, col_j = dcol + f.x;
-                            // all six must be valid (:160-162); evaluation order does not matter for the result
-                            DmTap a0, a1, a2, a3, a4, a5;
-                            dm_tap_issue(a0, cur, row_j, col_j - 1.0f);
-                            dm_tap_issue(a1, cur, row_j, col_j + 1.0f);
-                            dm_tap_issue(a2, cur, row_j - 1.0f, col_j);
-                            dm_tap_issue(a3, cur, row_j + 1.0f, col_j);
-                            dm_tap_issue(a4, ref, row_i, col_i);
-                            dm_tap_issue(a5, cur, row_j, col_j);
-                            const bool ok = a0.valid && a1.valid && a2.valid && a3.valid && a4.valid && a5.valid;
-                            const float t0 = dm_tap_value(a0), t1 = dm_tap_value(a1), t2 = dm_tap_value(a2), t3 = dm_tap_value(a3), t4 = dm_tap_value(a4),
-                                        t5 = dm_tap_value(a5);
-                            if (ok) {
-                                const float j00 = f1.y, j01 = 0.0f, j02 = f1.z, j03 = f1.w, j04 = f2.x, j05 = f2.y;
-                                const float j10 = 0.0f, j11 = f2.z, j12 = f2.w, j13 = f3.x, j14 = f3.y, j15 = f3.z;
-                                const float gx = (t1 - t0) * 0.5f, gy = (t3 - t2) * 0.5f;
-                                residual = t5 - t4;
-                                jac[0] = gx * j00 + gy * j10;
-                                jac[1] = gx * j01 + gy * j11;
-                                jac[2] = gx * j02 + gy * j12;
-                                jac[3] = gx * j03 + gy * j13;
-                                jac[4] = gx * j04 + gy * j14;
-                                jac[5] = gx * j05 + gy * j15;
-                            }
-                        }
-                    }
+                    dm_term(feat, pp, ref, cur, chunk < n_chunks && i < n_track, i, pix, inv_patch_cols, jac, residual);
                 };
                 // ---- the (feature, pixel) stream in rounds of kDmProducers chunks ----
                 float acc = 0.0f;
@@ -376,46 +438,11 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
                 }
                 }
                 if (consumer) {
-                    // wave 0: sums -> full symmetric H in LDS -> lane-parallel LDLT (klt_common.h) -> dx in LDS
-                    if (lane < kDmTerms) {
-                        sums[lane] = acc;
-                    }
-                    __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
-                    if (lane < 36) {
-                        const int r0 = lane / 6, c0 = lane - 6 * r0;
-                        const int r = r0 < c0 ? r0 : c0, cc = r0 < c0 ? c0 : r0;
-                        sums[32 + lane] = sums[r * (13 - r) / 2 + (cc - r)];  // upper triangle, row-major
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const Ldlt6 fac = ldlt6_factor(sums + 32, lane);
-                    ldlt6_solve(fac, sums + 21, sums + 68, lane);
+                    dm_solve(sums, acc, lane);
                 }
                 __syncthreads();
-
                 // ---- update, redundantly in every thread (:170-181) ----
-                float dx[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    dx[k] = sums[68 + k];
-                }
-                bool has_nan = false;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    has_nan = has_nan || isnan(dx[k]);
-                }
-                if (has_nan) {
-                    stop = true;  // :173
-                } else {
-                    px += dx[0];
-                    py += dx[1];
-                    pz += dx[2];
-                    Quat dq = {dx[3] * 0.5f, dx[4] * 0.5f, dx[5] * 0.5f, 1.0f};
-                    q = q_normalized(q_mul(q_normalized(dq), q));
-                    const float sq = (((dx[0] * dx[0] + dx[2] * dx[2]) + (dx[1] * dx[1] + dx[3] * dx[3])) + dx[4] * dx[4]) + dx[5] * dx[5];
-                    if (sq < pp.converge) {
-                        stop = true;  // :181
-                    }
-                }
+                stop = dm_update_pose(sums, pp.converge, q, px, py, pz);
                 __syncthreads();  // everyone has read `sums` and `feat` before the next iteration rewrites them
             }
         }
@@ -444,10 +471,289 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ONE pose problem spread over the chip (exact sums).  The one-workgroup kernel above is bound by what a single compute unit can
+// issue per iteration — 793 chunks x ~390 producer instructions beside the 50 700-term chains (profiles/r4_pmc_direct.txt) — while
+// 255 compute units idle.  Here workgroup 0 is the CONSUMER and keeps only the sequential part: seven loader waves copy finished
+// chunks of products from device memory into the LDS ring, wave 0 adds them in stream order, solves and moves the pose.  Workgroups
+// 1 .. NP are PRODUCERS: per iteration each takes the pose the consumer published, projects the features, and its waves form the
+// 27 products of chunks w, w + 8 NP, ... (w = the wave's number over all producers: the first chunks of the stream come first).
+//
+// Hand-offs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every handed-off byte is stored
+// AND loaded with agent-scope relaxed atomics (sc1: L2, never a stale L1 line); a storing wave waits for its stores (vmcnt(0))
+// before one lane stores the flag; the wave that polled a flag is the wave that loads what it guards.
+//   * consumer -> producers: pose[7] + level, then iter_tag = g + 1 (g counts iterations over all levels; 0xFFFFFFFF = leave);
+//   * producer wave -> consumer loader wave: the chunk's 27 x 64 products, then chunk_flag[c] = g + 1.
+// A chunk slot is rewritten only after the consumer has published the NEXT pose, i.e. after it has consumed the whole stream.
+// Every wait is BOUNDED (kSpreadMaxPolls): a wait that runs out poisons the pose with NaN and releases everybody — a bug or a
+// launch that cannot become co-resident ends in a wrong answer the caller sees, never in a hung device.
+// Results are those of the one-workgroup kernel bit for bit: same terms (dm_term), same order of the sums, same solve.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSpreadStop = 0xFFFFFFFFu;
+constexpr uint32_t kSpreadMaxPolls = 1u << 22;   // x (one L2 round trip + s_sleep) ~ seconds
+constexpr int kSpreadHeaderWords = 64;           // iter_tag, error, level, -, pose[7] ...
+
+__device__ __forceinline__ uint32_t spread_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spread_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void spread_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Polls *flag until it equals `want` (or `also`); false when the wait ran out.  Whole wave, uniform address.
+__device__ __forceinline__ bool spread_wait(const uint32_t *flag, uint32_t want, uint32_t also, uint32_t &seen) {
+    for (uint32_t polls = 0; polls < kSpreadMaxPolls; ++polls) {
+        seen = spread_load(flag);
+        if (seen == want || seen == also) {
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(const DirectParams pp) {
+    extern __shared__ float4 dm_lds[];
+    const DirectProblem pr = pp.problems[0];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    const int n = pr.n;
+    const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
+    const int P = pp.patch_rows * pp.patch_cols;
+    const long long total_terms = (long long)n_track * P;
+    const int n_chunks = (int)((total_terms + kDmChunk - 1) / kDmChunk);
+    uint32_t *const header = pp.spread_ws;
+    uint32_t *const chunk_flag = header + kSpreadHeaderWords;
+    uint32_t *const products = chunk_flag + ((n_chunks + 63) & ~63);  // [n_chunks][kDmTerms][kDmChunk] floats (as bits)
+    const float scale = (float)(1 << (pp.n_levels - 1));
+
+    if (blockIdx.x == 0) {
+        // ================= the consumer =================
+        const bool chain_wave = wave == 0;
+        if (chain_wave) {
+            __builtin_amdgcn_s_setprio(3);  // the chain IS the launch: it goes ahead of the loader wave on its SIMD (2.67 -> 2.59 ms; with rounds of eight 2.53)
+        }
+        float *const ring = reinterpret_cast<float *>(dm_lds);            // [2][kDmProducers][kDmTerms][kDmRow]
+        float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;  // [96]
+        const int n_rounds = (n_chunks + kDmProducers - 1) / kDmProducers;
+        Quat q = {pr.pose[1], pr.pose[2], pr.pose[3], pr.pose[0]};
+        float px = pr.pose[4], py = pr.pose[5], pz = pr.pose[6];
+        uint32_t iterations = 0, g = 0;
+        bool failed = false;
+        if (tid == 0) {
+            reinterpret_cast<uint32_t *>(sums)[80] = 0u;  // "a loader's wait ran out"
+        }
+        __syncthreads();
+        for (int level = pp.n_levels - 1; level > -1 && !failed; --level) {
+            bool stop = false;
+            for (uint32_t iter = 0; iter < pp.max_iteration && !stop && !failed; ++iter) {
+                ++iterations;
+                // ---- publish the pose of iteration g ----
+                if (tid == 0) {
+                    spread_store(header + 2, (uint32_t)level);
+                    spread_store(header + 4, __float_as_uint(q.x));
+                    spread_store(header + 5, __float_as_uint(q.y));
+                    spread_store(header + 6, __float_as_uint(q.z));
+                    spread_store(header + 7, __float_as_uint(q.w));
+                    spread_store(header + 8, __float_as_uint(px));
+                    spread_store(header + 9, __float_as_uint(py));
+                    spread_store(header + 10, __float_as_uint(pz));
+                    spread_stores_done();
+                    spread_store(header, g + 1u);
+                }
+                // ---- the stream: loaders bring chunk round r + 1 into the ring while wave 0 adds round r ----
+                float acc = 0.0f;
+                bool wait_failed = false;
+                for (int round = 0; round < n_rounds; ++round) {
+                    if (!chain_wave) {
+                        const int chunk = round * kDmProducers + (wave - 1);
+                        if (chunk < n_chunks) {
+                            uint32_t seen;
+                            if (!spread_wait(chunk_flag + chunk, g + 1u, g + 1u, seen)) {
+                                wait_failed = true;
+                            }
+                            const uint32_t *src = products + (size_t)chunk * (kDmTerms * kDmChunk) + lane;
+                            float *slot = ring + (((round & 1) * kDmProducers + (wave - 1)) * kDmTerms) * kDmRow + lane;
+                            uint32_t v[kDmTerms];
+#pragma unroll
+                            for (int k = 0; k < kDmTerms; ++k) {
+                                v[k] = spread_load(src + k * kDmChunk);
+                            }
+#pragma unroll
+                            for (int k = 0; k < kDmTerms; ++k) {
+                                slot[k * kDmRow] = __uint_as_float(v[k]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (chain_wave && lane < kDmTerms) {
+                        for (int w = 0; w < kDmProducers; ++w) {
+                            if (round * kDmProducers + w < n_chunks) {
+                                acc = dm_chain_chunk(acc, ring + ((((round & 1) * kDmProducers + w) * kDmTerms) + lane) * kDmRow);
+                            }
+                        }
+                    }
+                }
+                if (chain_wave) {
+                    dm_solve(sums, acc, lane);
+                }
+                // a loader whose wait ran out: every thread learns it (the barrier below is the one the solve needs anyway)
+                if (wait_failed && lane == 0) {
+                    reinterpret_cast<uint32_t *>(sums)[80] = 1u;
+                }
+                __syncthreads();
+                stop = dm_update_pose(sums, pp.converge, q, px, py, pz);
+                failed = reinterpret_cast<const uint32_t *>(sums)[80] != 0u;
+                __syncthreads();  // everyone has read `sums` before the next iteration rewrites them
+                ++g;
+            }
+        }
+        if (tid == 0) {
+            if (failed) {
+                spread_store(header + 1, 1u);
+                q.x = q.y = q.z = q.w = px = py = pz = __uint_as_float(0x7FC00000u);
+            }
+            spread_store(header, kSpreadStop);  // the producers leave
+            pr.pose[0] = q.w;
+            pr.pose[1] = q.x;
+            pr.pose[2] = q.y;
+            pr.pose[3] = q.z;
+            pr.pose[4] = px;
+            pr.pose[5] = py;
+            pr.pose[6] = pz;
+            if (pr.iterations) {
+                *pr.iterations = iterations;
+            }
+        }
+        return;
+    }
+
+    // ================= a producer =================
+    const int np = (int)gridDim.x - 1;
+    const int producer = (int)blockIdx.x - 1;
+    float *const shared = reinterpret_cast<float *>(dm_lds);  // [16]: the pose and level this iteration runs with, then the feature table
+    uint32_t *const shared_u = reinterpret_cast<uint32_t *>(dm_lds);
+    float4 *const feat = dm_lds + 4;
+    const float inv_patch_cols = 1.0f / (float)pp.patch_cols;
+    const int stride_chunks = np * kDmWaves;
+    const int step_i = (int)(((long long)stride_chunks * kDmChunk) / P), step_pix = (int)(((long long)stride_chunks * kDmChunk) % P);
+    int cur_level = -1;
+    float fx = 0.0f, fy = 0.0f, cx = 0.0f, cy = 0.0f;
+    DevImage ref = pr.ref[0], cur = pr.cur[0];
+    uint32_t last_tag = 0;
+    for (;;) {
+        // ---- the next published pose (one wave polls; the others get it through LDS behind the barrier).  Tags only grow; a producer
+        // whose waves own no chunk of a small stream may miss one — the consumer does not wait for it — and simply takes the next.
+        if (wave == 0) {
+            uint32_t seen = last_tag;
+            bool ok = false;
+            for (uint32_t polls = 0; polls < kSpreadMaxPolls; ++polls) {
+                seen = spread_load(header);
+                if (seen != last_tag) {
+                    ok = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const uint32_t mine = lane < 11 ? spread_load(header + lane) : 0u;  // the wave that polled loads what the tag guards
+            if (lane >= 2 && lane < 11) {
+                shared_u[lane] = mine;
+            }
+            if (lane == 0) {
+                shared_u[0] = ok ? seen : kSpreadStop;
+            }
+        }
+        __syncthreads();
+        const uint32_t tag = shared_u[0];
+        if (tag == kSpreadStop) {
+            break;
+        }
+        last_tag = tag;
+        const int level = (int)shared_u[2];
+        Quat q = {shared[4], shared[5], shared[6], shared[7]};
+        const float px = shared[8], py = shared[9], pz = shared[10];
+        if (level != cur_level) {
+            cur_level = level;
+            ref = pp.problems[0].ref[level];
+            cur = pp.problems[0].cur[level];
+            const float up = (float)(1 << (pp.n_levels - 1 - level));
+            fx = (pr.K[0] / scale) * up;
+            fy = (pr.K[1] / scale) * up;
+            cx = (pr.K[2] / scale) * up;
+            cy = (pr.K[3] / scale) * up;
+            for (int i = tid; i < n_track; i += kDmWaves * kWave) {
+                dm_level_row(feat, pr, i, scale, up, fx, fy);
+            }
+        }
+        const Quat q_inv = q_inverse(q);
+        for (int i = tid; i < n_track; i += kDmWaves * kWave) {
+            dm_project(feat, pr, i, q_inv, px, py, pz, fx, fy, cx, cy, producer == 0);
+        }
+        __syncthreads();
+        // ---- this wave's chunks of the stream ----
+        int chunk = producer * kDmWaves + wave;
+        int ti, tpix;
+        {
+            const long long t = (long long)chunk * kDmChunk + lane;
+            ti = (int)(t / P);
+            tpix = (int)(t - (long long)ti * P);
+        }
+        for (; chunk < n_chunks; chunk += stride_chunks) {
+            float jac[6], residual;
+            dm_term(feat, pp, ref, cur, ti < n_track, ti, tpix, inv_patch_cols, jac, residual);
+            uint32_t *dst = products + (size_t)chunk * (kDmTerms * kDmChunk) + lane;
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = r; c < 6; ++c) {
+                    spread_store(dst + k * kDmChunk, __float_as_uint(jac[r] * jac[c]));
+                    ++k;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                spread_store(dst + (21 + r) * kDmChunk, __float_as_uint(residual * jac[r]));
+            }
+            spread_stores_done();
+            if (lane == 0) {
+                spread_store(chunk_flag + chunk, tag);
+            }
+            ti += step_i;
+            tpix += step_pix;
+            if (tpix >= P) {
+                tpix -= P;
+                ++ti;
+            }
+        }
+        __syncthreads();  // every wave is done with the feature table before the next iteration's projection rewrites it
+    }
+    // ---- status write-back (:72-83), by the producer that wrote cur_pixel_uv ----
+    if (producer == 0) {
+        const DevImage bottom = pr.ref[0];
+        for (int i = tid; i < n; i += kDmWaves * kWave) {
+            uint8_t st = pr.status_valid ? pr.status[i] : (uint8_t)FTK_TRACKED;
+            const float u = pr.cur_uv[2 * i], v = pr.cur_uv[2 * i + 1];
+            if (u < 0.0f || u > (float)(bottom.cols - 1) || v < 0.0f || v > (float)(bottom.rows - 1)) {
+                st = FTK_OUTSIDE;
+            }
+            pr.status[i] = st;
+        }
+    }
+}
+
 }  // namespace
 
 size_t direct_lds_bytes(uint32_t max_features) {
     return sizeof(float) * ((size_t)2 * kDmProducers * kDmTerms * kDmRow + 96 + 16 * (size_t)max_features);
+}
+
+size_t direct_spread_ws_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols) {
+    const long long total_terms = (long long)n_track * patch_rows * patch_cols;
+    const long long n_chunks = (total_terms + kDmChunk - 1) / kDmChunk;
+    return sizeof(uint32_t) * (size_t)(kSpreadHeaderWords + ((n_chunks + 63) & ~63ll) + n_chunks * (long long)(kDmTerms * kDmChunk));
+}
+
+size_t direct_spread_clear_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols) {
+    const long long total_terms = (long long)n_track * patch_rows * patch_cols;
+    const long long n_chunks = (total_terms + kDmChunk - 1) / kDmChunk;
+    return sizeof(uint32_t) * (size_t)(kSpreadHeaderWords + ((n_chunks + 63) & ~63ll));  // header + chunk flags: zero before every launch
 }
 
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream) {
@@ -456,13 +762,19 @@ hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t m
     }
     const size_t lds = direct_lds_bytes(max_features);
     void (*kernel)(const DirectParams) = p.tree ? direct_track_kernel<true> : direct_track_kernel<false>;
+    if (p.spread > 0) {
+        if (n_problems != 1 || p.tree || !p.spread_ws) {
+            return hipErrorInvalidValue;
+        }
+        kernel = direct_track_spread_kernel;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             return e;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)n_problems), dim3(kDmWaves * kWave), lds, stream, p);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(p.spread > 0 ? 1 + p.spread : n_problems)), dim3(kDmWaves * kWave), lds, stream, p);
     return hipGetLastError();
 }
 

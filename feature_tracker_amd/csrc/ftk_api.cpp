@@ -544,6 +544,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->klt_spill) {
         (void)hipFree(ctx->klt_spill);
     }
+    if (ctx->direct_spread) {
+        (void)hipFree(ctx->direct_spread);
+    }
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
     }
@@ -2009,6 +2012,32 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     p.patch_cols = 2 * opt->half_cols + 1;
     p.converge = opt->max_converge_step;
     p.method = opt->method;
+    // ONE problem with enough terms: spread over the chip (direct_track_spread_kernel) — the one-workgroup kernel is bound by what a
+    // single compute unit can issue per iteration.  Exact sums only; FTK_DIRECT_SPREAD=0 keeps the one-workgroup kernel, =n sets the
+    // number of producer workgroups (default 32).
+    p.spread = 0;
+    p.spread_ws = nullptr;
+    {
+        const char *env = getenv("FTK_DIRECT_SPREAD");
+        int producers = env ? atoi(env) : 32;
+        producers = producers < 0 ? 0 : (producers > 200 ? 200 : producers);
+        const long long terms = (long long)max_features * p.patch_rows * p.patch_cols;
+        long long min_terms = 64ll * 256;  // below about 256 chunks the producers of one compute unit keep up with the chain
+        if (const char *min_env = getenv("FTK_DIRECT_SPREAD_MIN_TERMS")) {
+            min_terms = atoll(min_env);  // tests: spread even tiny problems (producers whose waves own no chunk)
+        }
+        if (producers > 0 && n_problems == 1 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global && max_features > 0 && terms >= min_terms &&
+            terms < (1ll << 31)) {
+            const size_t ws = ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols);
+            const int rc = ensure_device_buffer(ctx, &ctx->direct_spread, &ctx->direct_spread_bytes, ws);
+            if (rc != FTK_OK) {
+                return rc;
+            }
+            FTK_HIP(ctx, hipMemsetAsync(ctx->direct_spread, 0, ftk::direct_spread_clear_bytes(max_features, p.patch_rows, p.patch_cols), ctx->stream));
+            p.spread = producers;
+            p.spread_ws = static_cast<uint32_t *>(ctx->direct_spread);
+        }
+    }
     FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, feat_in_global ? 0u : max_features, ctx->stream));
     return FTK_OK;
 }

@@ -244,8 +244,14 @@ struct DirectParams {
     int32_t half_rows, half_cols, patch_rows, patch_cols;
     float converge;
     int32_t method;
+    // ONE problem spread over the chip (direct_kernels.hip direct_track_spread_kernel): `spread` producer workgroups beside the
+    // consumer, hand-offs through `spread_ws` (direct_spread_ws_bytes; its first direct_spread_clear_bytes zeroed before the launch)
+    int32_t spread;
+    uint32_t *spread_ws;
 };
 size_t direct_lds_bytes(uint32_t max_features);
+size_t direct_spread_ws_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols);
+size_t direct_spread_clear_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols);
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream);
 
 struct BriefParams {

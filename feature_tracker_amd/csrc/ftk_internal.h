@@ -56,6 +56,9 @@ struct ftk_context {
     // per-workgroup slices of the trackers' large-patch form (ftk_device.h KltParams::spill)
     void *klt_spill = nullptr;
     size_t klt_spill_bytes = 0;
+    // hand-off workspace of the spread direct-method kernel (header, chunk flags, products)
+    void *direct_spread = nullptr;
+    size_t direct_spread_bytes = 0;
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

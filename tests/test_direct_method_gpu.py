@@ -10,6 +10,18 @@ from feature_tracker_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["default", "one-workgroup", "spread-3-tiny"], autouse=True)
+def direct_form(request, monkeypatch):
+    """Every test runs three times: with the default dispatch (ONE problem with enough terms is spread over the chip:
+    direct_track_spread_kernel), with the one-workgroup kernel only (FTK_DIRECT_SPREAD=0), and spread over three producer workgroups
+    whatever the size (problems of one feature included: most producer waves then own no chunk of the stream)."""
+    if request.param == "one-workgroup":
+        monkeypatch.setenv("FTK_DIRECT_SPREAD", "0")
+    elif request.param == "spread-3-tiny":
+        monkeypatch.setenv("FTK_DIRECT_SPREAD", "3")
+        monkeypatch.setenv("FTK_DIRECT_SPREAD_MIN_TERMS", "1")
+
 FX, FY, CX, CY = 400.0, 410.0, 321.5, 238.25
 
 
