@@ -23,7 +23,8 @@ for W in $WORKLOADS; do
   if [ "$W" = hamming ]; then
     CMD="python3 $ROOT/scripts/bench_configs.py --only match --quick"
   else
-    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline --no-upload-leg --no-tree-leg"
+    # (the legs that launch OTHER workloads or isolated calls are off: the trace average of the workload's kernel is then the back-to-back figure bench.py times)
+    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline --no-upload-leg --no-tree-leg --no-configs-leg --no-host-call-leg"
   fi
   echo "== $W: trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $CMD > "$D/trace_stdout.log" 2>&1 || echo "trace failed: $W" >> "$OUT/errors.log"
