@@ -181,8 +181,10 @@ def tracker_config_leg(name, cfg, steps, ctx, dev, stream, source_hash):
     """One BASELINE.json configuration timed the way the headline is (K back-to-back launches on device-resident inputs, wall
     clock around them, one synchronisation on each side), checked against the oracle on the same inputs.  Calls of >= 4096
     features are launched through the launch order of an earlier call (ftk_klt_track_device): repeating ONE call makes that
-    predictor perfect, so the back-to-back figure is the "warm" regime; "cold" (no history: a call with another feature count in
-    between resets it; one bracketed call at a time) is given beside it."""
+    predictor perfect, so the back-to-back figure is the "warm" regime; "cold" (a call with another feature count in between resets
+    the index-keyed history — what a front end that drops and re-detects features does every frame; one bracketed call at a time) is
+    given beside it.  Since round 4 such a call of the LSSD / affine trackers is ordered by what the call before left at its
+    features' positions (ftk_api.cpp, klt_position_order_launch); the Basic trackers run it in list order."""
     import torch
 
     import feature_tracker_amd as F

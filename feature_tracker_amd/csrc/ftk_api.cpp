@@ -122,6 +122,7 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
 
 constexpr uint32_t kSchedMinFeatures = 4096;  // below this every feature is resident from the start: nothing to order
 constexpr size_t kSchedTableWords = (2u << 16) + 2;  // two position tables of 2^16 entries (klt_common.h kSchedTableSize) + the two "no tail" flags behind them
+constexpr size_t kSchedOrderWords = 512;             // behind them: histogram + cursors of the position-keyed launch order (klt_position_order_launch)
 constexpr int32_t kSchedMaxFeatures = 1 << 18;  // the sort block walks the list alone; beyond this it could outlast the launch
 
 int ensure_match_boxes(ftk_context *ctx, size_t count) {
@@ -552,6 +553,9 @@ void ftk_context_destroy(ftk_context *ctx) {
     }
     if (ctx->sched_grid) {
         (void)hipFree(ctx->sched_grid);
+    }
+    if (ctx->sched_pred) {
+        (void)hipFree(ctx->sched_pred);
     }
     if (ctx->sched_claim) {
         (void)hipFree(ctx->sched_claim);
@@ -1113,14 +1117,19 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                     (void)hipFree(ctx->sched_claim);
                     ctx->sched_claim = nullptr;
                 }
+                if (ctx->sched_pred) {
+                    (void)hipFree(ctx->sched_pred);
+                    ctx->sched_pred = nullptr;
+                }
                 ctx->sched_capacity = 0;
                 ctx->sched_n = 0;
                 const size_t cap = ((size_t)n + 4095) / 4096 * 4096;
                 // position-keyed slot swaps: a claim word per launch slot, and (once) the two tables of iteration counts by position
                 FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_claim), sizeof(uint32_t) * cap));
                 FTK_HIP(ctx, hipMemsetAsync(ctx->sched_claim, 0, sizeof(uint32_t) * cap, ctx->stream));
+                FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_pred), cap));
                 if (!ctx->sched_grid) {
-                    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_grid), sizeof(uint32_t) * kSchedTableWords));
+                    FTK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->sched_grid), sizeof(uint32_t) * (kSchedTableWords + kSchedOrderWords)));
                     FTK_HIP(ctx, hipMemsetAsync(ctx->sched_grid, 0, sizeof(uint32_t) * kSchedTableWords, ctx->stream));
                 }
                 for (int k = 0; k < 2; ++k) {
@@ -1155,8 +1164,11 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             // (config 3: 192 / 207 -> 149 / 166 us with no / a stale launch order, +0.5 % with a fitting one); the one-wave kernels
             // run 10 000 - 25 000 cheap features, every late one of which would pay a table look-up for a 3 % gain at best
             // (config 4: +2.9 % with a fitting order, -3 % without; config 5: +1 %).
-            if (swap_allowed && p.waves_per_feature >= 2 && ref_untouched && capture == hipStreamCaptureStatusNone && ctx->sched_grid && ctx->sched_claim &&
-                n > 1024 + 512) {
+            // EVERY such call (outside a capture) leaves its iteration counts in the position table — one or two atomics per feature —
+            // so that the next one can order or trade by position whatever kernel either of them runs.
+            const bool recording = capture == hipStreamCaptureStatusNone && ctx->sched_grid && ctx->sched_claim;
+            uint32_t last_recorded = 0;
+            if (recording) {
                 if (ctx->sched_call < 4u) {
                     ctx->sched_call = 4u;
                 }
@@ -1165,11 +1177,16 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                     FTK_HIP(ctx, hipMemsetAsync(ctx->sched_claim, 0, sizeof(uint32_t) * ctx->sched_capacity, ctx->stream));
                     FTK_HIP(ctx, hipMemsetAsync(ctx->sched_grid, 0, sizeof(uint32_t) * kSchedTableWords, ctx->stream));
                     ctx->sched_call += 4u;
+                    ctx->sched_recorded = 0;
                 }
                 p.sched_grid = ctx->sched_grid;
+                p.sched_call = ctx->sched_call;
+                last_recorded = ctx->sched_recorded;
+                ctx->sched_recorded = ctx->sched_call;
+            }
+            if (recording && swap_allowed && p.waves_per_feature >= 2 && ref_untouched && n > 1024 + 512) {
                 p.sched_flags = ctx->sched_grid + (2u << 16);
                 p.sched_claim = ctx->sched_claim;
-                p.sched_call = ctx->sched_call;
             }
             p.sched_iters = ctx->sched_iters[k & 1];          // this call's counts
             if (k >= 1) {                                     // sort the previous call's counts beside this call's features
@@ -1185,6 +1202,22 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             const bool use_order = order_mode >= 0 ? order_mode != 0 : true;
             if (k >= 2 && use_order) {                        // made during the previous call from the counts before it
                 p.order = ctx->sched_order[k & 1];
+            } else if (use_order && recording && last_recorded != 0u && last_recorded + 1u == ctx->sched_call && ctx->sched_pred && model != FTK_MODEL_BASIC &&
+                       p.sched_claim == nullptr) {
+                // (LSSD and affine KLT: their iteration counts have tails — config 4 without history 206 -> 183 us, with luminance
+                // 357 -> 315; Basic KLT's are flat on most scenes and the ~10 us of the two launches would buy nothing — config 5 shard
+                // 181 -> 190; the multi-wave kernels trade slots by position inside the launch instead)
+                // No index-keyed order (the feature count has just changed, or these are the first calls): order THIS call by what the
+                // last call left at its features' positions — two small launches in front of the tracker's (klt_kernels.hip
+                // klt_position_order_launch; FTK_KLT_POSITION_ORDER=0: list order as before).  The buffer is the one an index-keyed
+                // order of this call would have used: nobody else writes it during this call.
+                static const bool position_order = !(getenv("FTK_KLT_POSITION_ORDER") && atoi(getenv("FTK_KLT_POSITION_ORDER")) == 0);
+                if (position_order) {
+                    const uint32_t *last_table = ctx->sched_grid + (((ctx->sched_call - 1u) & 1u) << 16);
+                    FTK_HIP(ctx, ftk::klt_position_order_launch(p.ref_uv, n, last_table, ctx->sched_call - 1u, ctx->sched_pred, ctx->sched_grid + kSchedTableWords,
+                                                                ctx->sched_order[k & 1], ctx->stream));
+                    p.order = ctx->sched_order[k & 1];
+                }
             }
             if (const char *dump = getenv("FTK_KLT_SWAP_DUMP")) {  // diagnostic: how many trades the PREVIOUS launch of this context made
                 if (p.sched_claim != nullptr && ctx->sched_call > 5u) {

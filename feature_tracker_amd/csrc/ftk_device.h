@@ -144,6 +144,10 @@ size_t klt_lds_bytes(int model, int method, const KltParams &p);
 size_t klt_spill_floats(int model, const KltParams &p);
 // Launches the tracker kernel for (model, method) on `stream`; one workgroup of waves_per_feature wavefronts per feature.
 hipError_t klt_launch(int model, int method, const KltParams &p, hipStream_t stream);
+// Launch order of THIS call from the position table the last call wrote (klt_kernels.hip): order[slot] = feature, predicted-longest
+// first.  last_table: 2^16 words; pred: n bytes; hist_and_cursor: 512 words (zeroed here).
+hipError_t klt_position_order_launch(const float *ref_uv, int32_t n, const uint32_t *last_table, uint32_t last_call, uint8_t *pred, uint32_t *hist_and_cursor,
+                                     int32_t *order, hipStream_t stream);
 // Lane-parallel 6x6 LDLT (klt_common.h) on n systems, one wave each: the test hook behind ftk_ldlt6_solve.
 hipError_t ldlt6_launch(const float *d_a, const float *d_b, float *d_x, int n, hipStream_t stream);
 // Pipelined kernel for (FTK_MODEL_BASIC, FTK_METHOD_INVERSE); klt_launch dispatches to it when p.pb_enabled.

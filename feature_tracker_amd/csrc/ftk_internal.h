@@ -47,6 +47,8 @@ struct ftk_context {
     // position-keyed slot swaps (klt_common.h sched_resolve_slot): iteration counts by position (two hash tables), one claim word per launch slot
     uint32_t *sched_grid = nullptr;
     uint32_t *sched_claim = nullptr;
+    uint8_t *sched_pred = nullptr;    // predicted iteration count of every feature of the call in hand (position-keyed launch order)
+    uint32_t sched_recorded = 0;      // sched_call of the last call that left its counts in the position table (0: none yet)
     uint32_t sched_call = 0;     // calls that used the grid so far (tags its entries and the claims)
     size_t sched_capacity = 0;   // features each buffer holds
     int32_t sched_n = 0;         // feature count of the calls counted in sched_calls

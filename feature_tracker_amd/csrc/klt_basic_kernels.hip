@@ -721,7 +721,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (p.iters) {
             p.iters[id] = iters;
         }
-        sched_grid_record(p, full_ref_u, full_ref_v, iters);  // ... and by position
+        sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }

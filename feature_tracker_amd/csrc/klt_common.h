@@ -1182,10 +1182,17 @@ __device__ __forceinline__ uint32_t sched_prediction(const KltParams &p, float u
     return (word >> 8) == ((p.sched_call - 1u) & 0xFFFFFFu) ? (word & 0xFFu) : 0u;
 }
 
-__device__ __forceinline__ void sched_grid_record(const KltParams &p, float ref_u, float ref_v, uint32_t iters) {
+// ... at the feature's reference position (a caller that tracks the same list again asks there) AND at the position it was tracked to
+// (a caller that tracks frame after frame asks there: the next call's reference positions are this call's results)
+__device__ __forceinline__ void sched_grid_record(const KltParams &p, float ref_u, float ref_v, float out_u, float out_v, uint32_t iters) {
     if (p.sched_grid != nullptr) {
-        atomicMax(&p.sched_grid[((p.sched_call & 1u) << kSchedTableBits) + sched_table_slot(ref_u, ref_v)],
-                  ((p.sched_call & 0xFFFFFFu) << 8) | (iters < 255u ? iters : 255u));
+        const uint32_t word = ((p.sched_call & 0xFFFFFFu) << 8) | (iters < 255u ? iters : 255u);
+        uint32_t *table = p.sched_grid + ((p.sched_call & 1u) << kSchedTableBits);
+        const uint32_t at_ref = sched_table_slot(ref_u, ref_v), at_out = sched_table_slot(out_u, out_v);
+        atomicMax(&table[at_ref], word);
+        if (at_out != at_ref) {
+            atomicMax(&table[at_out], word);
+        }
     }
 }
 

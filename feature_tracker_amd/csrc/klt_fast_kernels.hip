@@ -842,7 +842,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (p.iters) {
             p.iters[id] = iters;
         }
-        sched_grid_record(p, full_ref_u, full_ref_v, iters);
+        sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);
         if (p.sched_iters) {
             p.sched_iters[id] = iters;
         }

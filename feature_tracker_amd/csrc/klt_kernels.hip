@@ -2025,7 +2025,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         if (p.iters) {
             p.iters[id] = iters;
         }
-        sched_grid_record(p, full_ref_u, full_ref_v, iters);  // ... and by position
+        sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)
         }
@@ -2153,6 +2153,112 @@ hipError_t ldlt6_launch(const float *a, const float *b, float *x, int n, hipStre
         return hipSuccess;
     }
     hipLaunchKernelGGL(ldlt6_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, a, b, x, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Launch order from POSITIONS, made before the launch (two small kernels).  The index-keyed order above needs the same feature
+// COUNT three calls in a row; a front end drops and re-detects features every frame, so its calls never get one and run in list
+// order ("cold": config 4 199 us against 147).  Every tracker kernel leaves a feature's iteration count in the position table
+// (sched_grid_record); here every feature of THIS call looks its reference position up in the table the LAST call wrote, the
+// counts are binned, and the features are dealt to launch slots longest first — a counting sort whose order inside a bin is whatever
+// the atomics make it (which slot runs a feature changes nothing in its arithmetic).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+// Adds of many lanes to few addresses are combined per wave first: one atomic per (wave, distinct bin), the lanes of a bin ranked by
+// lane number — atomics to ONE address serialise at ~11 ns each chip-wide (25 000 features with equal counts took 300 us lane by lane).
+// Returns this lane's rank among the wave's lanes of its bin and, through `group_size` / `leader`, the size of that group and whether
+// this lane speaks for it.
+__device__ __forceinline__ uint32_t wave_bin_rank(uint32_t bin, bool active, uint32_t &group_size, bool &leader) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t rank = 0;
+    group_size = 0;
+    leader = false;
+    unsigned long long todo = __ballot(active);
+    while (todo != 0ull) {  // wave-uniform: one trip per distinct bin among the active lanes
+        const int first = (int)__builtin_ctzll(todo);
+        const uint32_t b0 = (uint32_t)__shfl((int)bin, first);
+        const unsigned long long same = __ballot(active && bin == b0);
+        if (active && bin == b0) {
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            group_size = (uint32_t)__popcll(same);
+            leader = lane == first;
+        }
+        todo &= ~same;
+    }
+    return rank;
+}
+
+__global__ void __launch_bounds__(256) klt_predict_hist_kernel(const float *ref_uv, int n, const uint32_t *table, uint32_t last_call, uint8_t *pred,
+                                                               uint32_t *hist) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    uint32_t count = 0;
+    if (i < n) {
+        const uint32_t word = table[sched_table_slot(ref_uv[2 * i], ref_uv[2 * i + 1])];
+        count = (word >> 8) == (last_call & 0xFFFFFFu) ? (word & 0xFFu) : 0u;
+        pred[i] = (uint8_t)count;
+    }
+    uint32_t group_size;
+    bool leader;
+    (void)wave_bin_rank(count, i < n, group_size, leader);
+    if (leader) {
+        atomicAdd(&hist[count], group_size);
+    }
+}
+
+__global__ void __launch_bounds__(256) klt_predict_scatter_kernel(const uint8_t *pred, int n, const uint32_t *hist, uint32_t *cursor, int32_t *order) {
+    __shared__ uint32_t counts[256], start[256];
+    counts[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    {
+        // first launch slot of bin b: the features of every LARGER count come first
+        uint32_t before = 0u;
+        for (int b = 255; b > (int)threadIdx.x; --b) {
+            before += counts[b];
+        }
+        start[threadIdx.x] = before;
+    }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    const uint32_t b = i < n ? pred[i] : 0u;
+    uint32_t group_size;
+    bool leader;
+    const uint32_t rank = wave_bin_rank(b, i < n, group_size, leader);
+    uint32_t base = 0;
+    if (leader) {
+        base = atomicAdd(&cursor[b], group_size);
+    }
+    // the leader's base reaches its group: every lane reads it from the first lane of ITS bin
+    const unsigned long long mine = __ballot(true);  // (all 64 lanes take part in the shuffles below)
+    (void)mine;
+    unsigned long long todo = __ballot(i < n);
+    uint32_t my_base = 0;
+    while (todo != 0ull) {
+        const int first = (int)__builtin_ctzll(todo);
+        const uint32_t b0 = (uint32_t)__shfl((int)b, first);
+        const uint32_t base0 = (uint32_t)__shfl((int)base, first);
+        const unsigned long long same = __ballot(i < n && b == b0);
+        if (i < n && b == b0) {
+            my_base = base0;
+        }
+        todo &= ~same;
+    }
+    if (i < n) {
+        const uint32_t slot = start[b] + my_base + rank;
+        order[slot < (uint32_t)n ? slot : 0u] = i;  // (slot < n always: the bins hold exactly n features)
+    }
+}
+}  // namespace
+
+hipError_t klt_position_order_launch(const float *ref_uv, int32_t n, const uint32_t *last_table, uint32_t last_call, uint8_t *pred, uint32_t *hist_and_cursor,
+                                     int32_t *order, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(hist_and_cursor, 0, sizeof(uint32_t) * 512, stream);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(klt_predict_hist_kernel, dim3(blocks), dim3(256), 0, stream, ref_uv, n, last_table, last_call, pred, hist_and_cursor);
+    hipLaunchKernelGGL(klt_predict_scatter_kernel, dim3(blocks), dim3(256), 0, stream, pred, n, hist_and_cursor, hist_and_cursor + 256, order);
     return hipGetLastError();
 }
 

@@ -540,6 +540,49 @@ def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model,
         assert np.array_equal(g_uv.view(np.uint32), c.view(np.uint32)), name
 
 
+@pytest.mark.parametrize("model,method", [("basic", "fast"), ("basic", "inverse"), ("lssd", "fast"), ("affine", "inverse"), ("affine", "fast")])
+def test_position_keyed_launch_order_when_the_feature_count_changes(ftk, oracle, model, method):
+    """A front end drops and re-detects features every frame, so consecutive calls rarely have the same feature count and never get
+    the index-keyed launch order.  Such a call is ordered by what the LAST call left at its features' positions (two small launches
+    in front of the tracker's: klt_kernels.hip klt_position_order_launch).  The order must be a permutation — every feature tracked
+    exactly once, into output buffers that start poisoned — whatever the counts look like: a growing list, a shrinking one, a list
+    tracked frame after frame (reference positions = the last call's results), a list with equal counts everywhere."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "hard", "similarity")
+    n = 4700
+    uv = synth.make_features(n, 320, 240, margin=20.0, border_fraction=0.03, half=5)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = D.context_on_stream(stream, 0)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, 5, 5, n
+    with torch.cuda.stream(stream):
+        klt = D.DeviceKlt(model, opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+
+        def run(points):
+            m = len(points)
+            d_ref = torch.from_numpy(np.ascontiguousarray(points)).to(dev)
+            d_out = torch.full((m, 2), float("nan"), dtype=torch.float32, device=dev)
+            d_so = torch.full((m,), 0xEE, dtype=torch.uint8, device=dev)
+            klt.track(d_ref, d_ref.clone(), torch.zeros(m, dtype=torch.uint8, device=dev), d_out, d_so)
+            stream.synchronize()
+            return d_out.cpu().numpy(), d_so.cpu().numpy()
+
+        lists = [uv[:4200], uv[:4650], uv, uv[50:4500]]   # growing, growing, shrinking: every call has a count of its own
+        got = [run(pts) for pts in lists]
+        follow = got[2][0].copy()                         # frame after frame: track from where the last call ended
+        follow[~np.isfinite(follow).all(axis=1)] = 1.0
+        lists.append(follow[:4400])
+        got.append(run(lists[-1]))
+    for pts, (g_uv, g_st) in zip(lists, got):
+        ok, c, s, _ = oracle.klt_track_pyramid(model, ref_levels, cur_levels, pts, pts, None, method=method, half=5, max_points=n)
+        assert not (g_st == 0xEE).any(), "a feature was never processed"
+        assert np.array_equal(g_st, s)
+        same = (g_uv.view(np.uint32) == c.view(np.uint32)) | (np.isnan(g_uv) & np.isnan(c))
+        assert same.all()
+
+
 @pytest.mark.parametrize("n", [4603, 8192])
 def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle, n, monkeypatch, tmp_path):
     """Without a tail in the iteration counts the launch order is by image region, dealt XCD-major (klt_common.h klt_order_block,
