@@ -2228,9 +2228,7 @@ __global__ void __launch_bounds__(256) klt_predict_scatter_kernel(const uint8_t 
     if (leader) {
         base = atomicAdd(&cursor[b], group_size);
     }
-    // the leader's base reaches its group: every lane reads it from the first lane of ITS bin
-    const unsigned long long mine = __ballot(true);  // (all 64 lanes take part in the shuffles below)
-    (void)mine;
+    // the leader's base reaches its group: every lane reads it from the first lane of ITS bin (all 64 lanes take part in the shuffles)
     unsigned long long todo = __ballot(i < n);
     uint32_t my_base = 0;
     while (todo != 0ull) {
