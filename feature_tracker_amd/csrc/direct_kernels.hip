@@ -511,19 +511,22 @@ __device__ __forceinline__ bool spread_wait(const uint32_t *flag, uint32_t want,
 
 __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(const DirectParams pp) {
     extern __shared__ float4 dm_lds[];
-    const DirectProblem pr = pp.problems[0];
+    // a few problems side by side: 1 + pp.spread consecutive workgroups each, a workspace each
+    const int group = 1 + pp.spread;
+    const int problem = (int)blockIdx.x / group, role = (int)blockIdx.x - problem * group;
+    const DirectProblem pr = pp.problems[problem];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int n = pr.n;
     const int n_track = (int)((uint32_t)n < pp.max_track_points ? (uint32_t)n : pp.max_track_points);
     const int P = pp.patch_rows * pp.patch_cols;
     const long long total_terms = (long long)n_track * P;
     const int n_chunks = (int)((total_terms + kDmChunk - 1) / kDmChunk);
-    uint32_t *const header = pp.spread_ws;
+    uint32_t *const header = pp.spread_ws + (size_t)problem * pp.spread_ws_words;
     uint32_t *const chunk_flag = header + kSpreadHeaderWords;
     uint32_t *const products = chunk_flag + ((n_chunks + 63) & ~63);  // [n_chunks][kDmTerms][kDmChunk] floats (as bits)
     const float scale = (float)(1 << (pp.n_levels - 1));
 
-    if (blockIdx.x == 0) {
+    if (role == 0) {
         // ================= the consumer =================
         const bool chain_wave = wave == 0;
         if (chain_wave) {
@@ -540,7 +543,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
             reinterpret_cast<uint32_t *>(sums)[80] = 0u;  // "a loader's wait ran out"
         }
         __syncthreads();
-        for (int level = pp.n_levels - 1; level > -1 && !failed; --level) {
+        for (int level = pp.n_levels - 1; level > -1 && !failed && n_track > 0; --level) {  // (a problem of a batch may be empty)
             bool stop = false;
             for (uint32_t iter = 0; iter < pp.max_iteration && !stop && !failed; ++iter) {
                 ++iterations;
@@ -625,8 +628,8 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
     }
 
     // ================= a producer =================
-    const int np = (int)gridDim.x - 1;
-    const int producer = (int)blockIdx.x - 1;
+    const int np = pp.spread;
+    const int producer = role - 1;
     float *const shared = reinterpret_cast<float *>(dm_lds);  // [16]: the pose and level this iteration runs with, then the feature table
     uint32_t *const shared_u = reinterpret_cast<uint32_t *>(dm_lds);
     float4 *const feat = dm_lds + 4;
@@ -670,8 +673,8 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
         const float px = shared[8], py = shared[9], pz = shared[10];
         if (level != cur_level) {
             cur_level = level;
-            ref = pp.problems[0].ref[level];
-            cur = pp.problems[0].cur[level];
+            ref = pp.problems[problem].ref[level];
+            cur = pp.problems[problem].cur[level];
             const float up = (float)(1 << (pp.n_levels - 1 - level));
             fx = (pr.K[0] / scale) * up;
             fy = (pr.K[1] / scale) * up;
@@ -763,7 +766,7 @@ hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t m
     const size_t lds = direct_lds_bytes(max_features);
     void (*kernel)(const DirectParams) = p.tree ? direct_track_kernel<true> : direct_track_kernel<false>;
     if (p.spread > 0) {
-        if (n_problems != 1 || p.tree || !p.spread_ws) {
+        if (p.tree || !p.spread_ws || p.spread_ws_words == 0) {
             return hipErrorInvalidValue;
         }
         kernel = direct_track_spread_kernel;
@@ -774,7 +777,7 @@ hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t m
             return e;
         }
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(p.spread > 0 ? 1 + p.spread : n_problems)), dim3(kDmWaves * kWave), lds, stream, p);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(p.spread > 0 ? n_problems * (1 + p.spread) : n_problems)), dim3(kDmWaves * kWave), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -2045,30 +2045,39 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     p.patch_cols = 2 * opt->half_cols + 1;
     p.converge = opt->max_converge_step;
     p.method = opt->method;
-    // ONE problem with enough terms: spread over the chip (direct_track_spread_kernel) — the one-workgroup kernel is bound by what a
-    // single compute unit can issue per iteration.  Exact sums only; FTK_DIRECT_SPREAD=0 keeps the one-workgroup kernel, =n sets the
-    // number of producer workgroups (default 32).
+    // ONE problem (or a handful: a stereo pair, a small rig) with enough terms: spread over the chip (direct_track_spread_kernel) — the
+    // one-workgroup kernel is bound by what a single compute unit can issue per iteration.  Exact sums only; FTK_DIRECT_SPREAD=0 keeps
+    // the one-workgroup kernel, =n sets the number of producer workgroups per problem (default 32).  Larger batches fill the chip with
+    // one workgroup per problem.
     p.spread = 0;
     p.spread_ws = nullptr;
+    p.spread_ws_words = 0;
     {
         const char *env = getenv("FTK_DIRECT_SPREAD");
         int producers = env ? atoi(env) : 32;
         producers = producers < 0 ? 0 : (producers > 200 ? 200 : producers);
+        if (n_problems > 1 && producers > 0) {
+            producers = std::min(producers, std::max(8, 224 / n_problems - 1));  // every workgroup of the launch resident at once, one per CU
+        }
         const long long terms = (long long)max_features * p.patch_rows * p.patch_cols;
         long long min_terms = 64ll * 256;  // below about 256 chunks the producers of one compute unit keep up with the chain
         if (const char *min_env = getenv("FTK_DIRECT_SPREAD_MIN_TERMS")) {
             min_terms = atoll(min_env);  // tests: spread even tiny problems (producers whose waves own no chunk)
         }
-        if (producers > 0 && n_problems == 1 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global && max_features > 0 && terms >= min_terms &&
+        if (producers > 0 && n_problems <= 6 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global && max_features > 0 && terms >= min_terms &&
             terms < (1ll << 31)) {
-            const size_t ws = ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols);
-            const int rc = ensure_device_buffer(ctx, &ctx->direct_spread, &ctx->direct_spread_bytes, ws);
+            const size_t ws = align_up(ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols), 256);
+            const int rc = ensure_device_buffer(ctx, &ctx->direct_spread, &ctx->direct_spread_bytes, ws * (size_t)n_problems);
             if (rc != FTK_OK) {
                 return rc;
             }
-            FTK_HIP(ctx, hipMemsetAsync(ctx->direct_spread, 0, ftk::direct_spread_clear_bytes(max_features, p.patch_rows, p.patch_cols), ctx->stream));
+            for (int32_t k = 0; k < n_problems; ++k) {  // header + chunk flags of every problem: zero before the launch
+                FTK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->direct_spread) + ws * (size_t)k, 0,
+                                            ftk::direct_spread_clear_bytes(max_features, p.patch_rows, p.patch_cols), ctx->stream));
+            }
             p.spread = producers;
             p.spread_ws = static_cast<uint32_t *>(ctx->direct_spread);
+            p.spread_ws_words = (uint32_t)(ws / sizeof(uint32_t));
         }
     }
     FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, feat_in_global ? 0u : max_features, ctx->stream));

@@ -252,6 +252,7 @@ struct DirectParams {
     // consumer, hand-offs through `spread_ws` (direct_spread_ws_bytes; its first direct_spread_clear_bytes zeroed before the launch)
     int32_t spread;
     uint32_t *spread_ws;
+    uint32_t spread_ws_words;  // words between the workspaces of consecutive problems
 };
 size_t direct_lds_bytes(uint32_t max_features);
 size_t direct_spread_ws_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols);

@@ -159,3 +159,42 @@ def test_world_frame_overload(ftk, oracle):
     assert np.array_equal(c.view(np.uint32), c_c.view(np.uint32)) and np.array_equal(st, st_c)
     assert np.array_equal(q_wc.view(np.uint32), oracle.quat_mul(ref_q, q_rc).view(np.uint32))
     assert np.array_equal(p_wc.view(np.uint32), (oracle.quat_rotate(ref_q, p_rc) + ref_p).astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("sizes", [(300, 300), (300, 1, 0, 120), (40, 260, 500)])
+def test_small_batches_of_problems_match_the_oracle_problem_by_problem(ftk, oracle, sizes):
+    """ftk_direct_track_batch_device with two to four problems of different sizes (one of a single feature, one empty): on the default
+    dispatch each problem is spread over its own group of workgroups with its own workspace; every problem's pose, positions, status
+    and iteration count must be those of the oracle run on that problem alone."""
+    import torch
+    from feature_tracker_amd import device as D
+    rl, cl, uv_all, pts_all = scene(n=max(max(sizes), 1), levels=3)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        rp, cp = D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev)
+        problems, host = [], []
+        for k, n in enumerate(sizes):
+            uv = np.ascontiguousarray(uv_all[k:k + n] if k + n <= len(uv_all) else uv_all[:n])
+            pts = np.ascontiguousarray(pts_all[k:k + n] if k + n <= len(pts_all) else pts_all[:n])
+            host.append((uv, pts))
+            problems.append(dict(ref=rp, cur=cp, K=[FX, FY, CX, CY], p_c_in_ref=torch.from_numpy(pts).to(dev).reshape(-1, 3),
+                                 ref_uv=torch.from_numpy(uv).to(dev).reshape(-1, 2), cur_uv=torch.from_numpy(uv.copy()).to(dev).reshape(-1, 2),
+                                 pose=torch.tensor([1, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=dev),
+                                 status=torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)[:n], status_valid=False,
+                                 iterations=torch.zeros(1, dtype=torch.int32, device=dev)))
+        opt = ftk.DirectMethodOptions()
+        opt.kMaxTrackPointsNumber = 500
+        D.DeviceDirectBatch(opt, problems, ctx).track()
+        stream.synchronize()
+    for (uv, pts), pr in zip(host, problems):
+        if len(uv) == 0:
+            assert np.array_equal(pr["pose"].cpu().numpy(), np.float32([1, 0, 0, 0, 0, 0, 0]))
+            continue
+        ok, c, q, p, st, it = oracle.direct_track(rl, cl, [FX, FY, CX, CY], pts, uv, max_points=500)
+        pose = pr["pose"].cpu().numpy()
+        assert np.array_equal(pose[:4].view(np.uint32), np.float32(q).view(np.uint32)) and np.array_equal(pose[4:].view(np.uint32), np.float32(p).view(np.uint32))
+        assert np.array_equal(pr["cur_uv"].cpu().numpy().view(np.uint32), c.view(np.uint32))
+        assert np.array_equal(pr["status"].cpu().numpy(), st)
+        assert int(pr["iterations"].cpu().numpy()[0]) == it
