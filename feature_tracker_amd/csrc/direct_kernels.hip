@@ -568,7 +568,9 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                         const int chunk = round * kDmProducers + (wave - 1);
                         if (chunk < n_chunks) {
                             uint32_t seen;
-                            if (!spread_wait(chunk_flag + chunk, g + 1u, g + 1u, seen)) {
+                            // (a wave whose wait has run out once does not wait again: the iteration is lost anyway, and a second
+                            // full wait per remaining round would turn one bounded wait into minutes)
+                            if (!wait_failed && !spread_wait(chunk_flag + chunk, g + 1u, g + 1u, seen)) {
                                 wait_failed = true;
                             }
                             const uint32_t *src = products + (size_t)chunk * (kDmTerms * kDmChunk) + lane;
