@@ -478,6 +478,60 @@ def test_one_wave_features_packed_into_workgroups(ftk, oracle, monkeypatch, grou
     assert_parity(gpu, cpu, f"group={group} lssd/fast luminance")
 
 
+@pytest.mark.parametrize("group", [None, 1, 3])
+def test_affine_fast_one_wave_kernel_on_the_edge_cases(ftk, oracle, monkeypatch, group):
+    """The affine tracker's `fast` method runs klt_fast_kernel<affine> only from 513 features on (a smaller call is its slowest
+    feature, and that one is faster on the generic kernel's three waves: ftk_api.cpp fk_model), so the edge-case tests above — all
+    of 64 - 400 features — reach it on the generic kernel.  The same cases at 520 - 700 features: border and outside features (clamped
+    reference rows instead of the register-fed interior form, zero valid pixels), predictions, incoming failures and a cap that cuts
+    a workgroup's group of features, a rectangular patch with tight options, pyramid levels smaller than the patch, the single-level
+    overload with its affine prior.  Default packing, one feature per workgroup, and three (ragged last group)."""
+    if group is not None:
+        monkeypatch.setenv("FTK_KLT_GROUP", str(group))
+    # border / outside
+    ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
+    rs = np.random.RandomState(11)
+    n = 700
+    uv = np.empty((n, 2), np.float32)
+    uv[:, 0] = rs.uniform(-12, 332, n)
+    uv[:, 1] = rs.uniform(-12, 252, n)
+    uv[:8] = [[0, 0], [319, 239], [0, 239], [319, 0], [0.5, 0.5], [318.5, 238.5], [-3, 100], [400, 400]]
+    gpu, cpu = run_pyramid(ftk, oracle, "affine", "fast", ref_levels, cur_levels, uv, half=5)
+    assert_parity(gpu, cpu, "affine/fast one-wave: border")
+    # predictions, incoming status, a cap inside a group of four
+    uv = scenes.features(601, 320, 240, half=6)
+    pred = uv + np.float32([2.5, -1.5])
+    status = (np.arange(601) % 5).astype(np.uint8)
+    gpu, cpu = run_pyramid(ftk, oracle, "affine", "fast", ref_levels, cur_levels, uv, half=6, cur_uv=pred, status=status, max_points=533)
+    assert_parity(gpu, cpu, "affine/fast one-wave: prediction, status, cap")
+    skip = (status > 1) | (np.arange(601) >= 533)
+    assert np.array_equal(gpu[1][skip], pred[skip]) and np.array_equal(gpu[2][skip], status[skip])
+    # rectangular patch, tight options, hard motion
+    hard_ref, hard_cur = scenes.scene(320, 240, 4, "hard", "similarity")
+    uv = scenes.features(520, 320, 240, half=7, seed=3)
+    gpu, cpu = run_pyramid(ftk, oracle, "affine", "fast", hard_ref, hard_cur, uv, half=3, half_cols=7, kMaxIteration=6, kMaxToleranceLargeStep=2,
+                           kMaxConvergeStep=1e-3)
+    assert_parity(gpu, cpu, "affine/fast one-wave: rectangular")
+    gpu, cpu = run_pyramid(ftk, oracle, "affine", "fast", hard_ref, hard_cur, uv, half=7, half_cols=2)
+    assert_parity(gpu, cpu, "affine/fast one-wave: rectangular, tall")
+    # levels smaller than the patch footprint
+    ref, cur = synth.make_image_pair(64, 48, (1.3, -0.8))
+    tiny_ref, tiny_cur = synth.build_pyramid(ref, 3), synth.build_pyramid(cur, 3)
+    uv = scenes.features(530, 64, 48, half=6, border_fraction=0.2)
+    gpu, cpu = run_pyramid(ftk, oracle, "affine", "fast", tiny_ref, tiny_cur, uv, half=6)
+    assert_parity(gpu, cpu, "affine/fast one-wave: tiny image")
+    # the single-level overload: predict_affine is honoured only here (affine_klt.cpp:70)
+    one_ref, one_cur = scenes.scene(320, 240, 1, "easy", "similarity")
+    uv = scenes.features(600, 320, 240, half=6)
+    pred = uv + np.float32([3.0, -2.0])
+    prior = np.float32([[1.01, 0.02], [-0.02, 0.99]])
+    klt = make_tracker(ftk, "affine", "fast", 6)
+    klt.predict_affine = prior
+    ok, c, s = klt.TrackFeatures(one_ref[0], one_cur[0], uv, pred, None)
+    cpu = oracle.klt_track_single("affine", one_ref[0], one_cur[0], uv, pred, None, prior=prior, **oracle_kwargs("fast", 6))
+    assert_parity((ok, c, s, klt.last_iterations), cpu, "affine/fast one-wave: single level with prior")
+
+
 def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
     """The chunked one-wave LSSD-fast level (64-pixel ring, sums in registers) against the oracle on border / hard-motion /
     rectangular-patch inputs, and against the plain level (FTK_LSSD_CHUNKED=0)."""
