@@ -647,7 +647,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     if (consumer && b.lane < kTerms) {
                         for (int q = 0; q < np; ++q) {
                             if (s * np + q < n_chunks) {
-                                acc = chain_chunk(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + b.lane) * kRingRow);
+                                acc = chain_chunk_left(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + b.lane) * kRingRow, p.P - (s * np + q) * kChunk);
                             }
                         }
                     }

@@ -942,6 +942,32 @@ __device__ __forceinline__ float chain_chunk(float acc, const float *row) {
     acc = chain_consume_all(acc, qb);
     return acc;
 }
+
+// The chunk a patch ENDS in: its lanes [left, 64) wrote exact zeros, and x + (+-0) == x for every value a sum can hold (the sums start
+// at +0 and -0 never arises: +0 + (-0) == +0), so only the 16-term batches that hold a patch pixel are read and added — at 13 x 13
+// (41 pixels in the third chunk) 48 adds and 12 reads instead of 64 and 16, in every chain pass of every iteration.  Same adds in the
+// same order up to the last patch pixel: bit-identical.  `left` = patch pixels in this chunk (wave-uniform; >= 64 for a full chunk).
+__device__ __forceinline__ float chain_chunk_left(float acc, const float *row, int left) {
+    if (left > 3 * 4 * kChainRound) {
+        return chain_chunk(acc, row);
+    }
+    const float4 *t = reinterpret_cast<const float4 *>(row);
+    float4 qa[kChainRound], qb[kChainRound];
+    chain_load(qa, t);
+    if (left > 2 * 4 * kChainRound) {  // 33 .. 48 pixels: three batches
+        chain_load(qb, t + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        chain_load(qa, t + 2 * kChainRound + chain_tie(acc));
+        acc = chain_consume_all(acc, qb);
+        return chain_consume_all(acc, qa);
+    }
+    if (left > 4 * kChainRound) {  // 17 .. 32: two
+        chain_load(qb, t + kChainRound);
+        acc = chain_consume_all(acc, qa);
+        return chain_consume_all(acc, qb);
+    }
+    return chain_consume_all(acc, qa);  // 1 .. 16: one
+}
 #endif
 
 

@@ -1550,7 +1550,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                     part[k] += ring[k * kChunkRow + b.lane];
                 }
             } else if (b.lane < 9) {
-                acc = chain_chunk(acc, ring + b.lane * kChunkRow);
+                acc = chain_chunk_left(acc, ring + b.lane * kChunkRow, p.P - chunk * kChunkPixels);
             }
             blk_sync(b);
         }
@@ -1703,7 +1703,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const 
                 ring[b.lane] = interior ? value : 0.0f;
                 blk_sync(b);
                 if (b.lane == 0) {
-                    mean_acc = chain_chunk(mean_acc, ring);
+                    mean_acc = chain_chunk_left(mean_acc, ring, p.P - chunk * kChunkPixels);
                 }
                 blk_sync(b);
             }
@@ -1743,7 +1743,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const 
                 seen_valid = seen_valid || ok;
                 blk_sync(b);
                 if (b.lane < 9) {
-                    acc = chain_chunk(acc, ring + b.lane * kChunkRow);
+                    acc = chain_chunk_left(acc, ring + b.lane * kChunkRow, p.P - chunk * kChunkPixels);
                 }
                 blk_sync(b);
             }
