@@ -315,6 +315,7 @@ template <bool SOLO, int HR, int HC, bool TREE>
 __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_bounds__(256) klt_basic_inverse_pipelined_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument (p_arg.ref / p_arg.cur): a local copy whose
     // arrays are indexed with a run-time level would be placed in scratch memory (measured: the kernel twice as slow).
+    klt_touch_kernarg<sizeof(KltParams)>();  // every line of the argument block requested up front (klt_common.h)
     KltParams p = p_arg;
     if constexpr (HR > 0 && HC > 0) {
         p.half_rows = HR;
@@ -383,8 +384,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     if (p.order) {
         id = (uint32_t)p.order[id];  // launch slot -> feature: longest first by the previous call's iteration counts
     }
-    const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
+    // the three per-feature inputs are requested together (one global round trip, not two one after the other)
+    const float2 in_uv = reinterpret_cast<const float2 *>(p.cur_uv_in)[id];
+    const float2 full_ref = reinterpret_cast<const float2 *>(p.ref_uv)[id];
     uint8_t status = p.status_in[id];
+    const float in_u = in_uv.x, in_v = in_uv.y;
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through (basic_klt.cpp:9,15)
     if (id >= p.n_track || status > FTK_TRACKED) {
         if (b.tid == 0) {
@@ -415,7 +419,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     const int ring_mask = pb_ring_slots(b.nwaves) - 1;
 
     // basic_klt.cpp:10,18-19 (pyramid) / :59-86 (single level)
-    const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
+    const float full_ref_u = full_ref.x, full_ref_v = full_ref.y;
     const float scale = p.single_level ? 1.0f : (float)(1 << (p.n_levels - 1));
     float ref_u = p.single_level ? full_ref_u : full_ref_u / scale;
     float ref_v = p.single_level ? full_ref_v : full_ref_v / scale;

@@ -87,6 +87,21 @@ __device__ __forceinline__ Blk opaque_blk(const Blk &b) {
     return o;
 }
 
+// The argument block is ~0.7 KB = a dozen 64-byte lines of the scalar cache, cold at the start of a launch, and the compiler loads a
+// field where it is first needed — a dependent miss (an L2 round trip) every few dozen instructions of the prologue, for every
+// wave of the launch at once.  One dword of every line is requested up front instead: the misses overlap into one round trip and
+// the later loads hit.
+template <size_t kBytes>
+__device__ __forceinline__ void klt_touch_kernarg() {
+    const __attribute__((address_space(4))) uint32_t *ka = (const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink = 0;
+#pragma unroll
+    for (size_t off = 0; off < kBytes; off += 64) {
+        sink |= ka[off / 4];
+    }
+    asm volatile("" ::"s"(sink));
+}
+
 // All features of a call are resident at once and the hardware arbitrates oldest-wave-first, which
 // lets the first-dispatched features finish early and leaves the youngest ones to run the tail
 // alone at single-wave issue rate.  Waves therefore raise their own priority while they are

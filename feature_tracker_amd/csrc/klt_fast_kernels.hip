@@ -213,21 +213,6 @@ __device__ __forceinline__ void ldlt2_apply(const Ldlt2 &f, float b0, float b1, 
 #define FTK_WAVES_PER_EU 4
 #endif
 
-// The argument block is ~0.7 KB = a dozen 64-byte lines of the scalar cache, cold at the start of a launch, and the compiler loads a
-// field where it is first needed — a dependent miss (an L2 round trip) every few dozen instructions of the prologue, for every
-// wave of the launch at once.  One dword of every line is requested up front instead: the misses overlap into one round trip and
-// the later loads hit.
-template <size_t kBytes>
-__device__ __forceinline__ void fk_touch_kernarg() {
-    const __attribute__((address_space(4))) uint32_t *ka = (const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t sink = 0;
-#pragma unroll
-    for (size_t off = 0; off < kBytes; off += 64) {
-        sink |= ka[off / 4];
-    }
-    asm volatile("" ::"s"(sink));
-}
-
 // MODEL: FTK_MODEL_BASIC or FTK_MODEL_AFFINE.
 // HR / HC: the half patch sizes as compile-time constants (the geometry folds into immediates), or 0 / 0 for "as passed".
 template <int MODEL, int HR, int HC>
@@ -235,7 +220,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 #ifdef FTK_STAMPS
     const unsigned long long stamp_kernel_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    fk_touch_kernarg<sizeof(KltParams)>();
+    klt_touch_kernarg<sizeof(KltParams)>();
     KltParams p = p_arg;  // everything but the level tables (a run-time level index into a local copy would put it in scratch)
     if constexpr (HR > 0 && HC > 0) {
         p.half_rows = HR;

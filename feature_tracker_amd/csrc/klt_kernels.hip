@@ -1821,6 +1821,7 @@ template <int MODEL, int METHOD, bool SOLO, int H, bool TREE = false, bool LUM =
 __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel(const KltParams p_arg) {
     // `p` carries everything but the level tables, which stay in the kernel argument: a local copy whose arrays are indexed
     // with a run-time level would live in scratch memory
+    klt_touch_kernarg<sizeof(KltParams)>();  // every line of the argument block requested up front (klt_common.h)
     KltParams p = p_arg;
     if constexpr (H > 0) {
         p.half_rows = H;
@@ -1877,8 +1878,11 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         }
     }
     const uint32_t id = p.order ? (uint32_t)p.order[list_slot] : list_slot;
-    const float in_u = p.cur_uv_in[2 * id], in_v = p.cur_uv_in[2 * id + 1];
+    // the three per-feature inputs are requested together (one global round trip, not two one after the other)
+    const float2 in_uv = reinterpret_cast<const float2 *>(p.cur_uv_in)[id];
+    const float2 full_ref = reinterpret_cast<const float2 *>(p.ref_uv)[id];
     uint8_t status = p.status_in[id];
+    const float in_u = in_uv.x, in_v = in_uv.y;
     // features beyond kMaxTrackPointsNumber and features that already failed are passed through
     if (id >= p.n_track || status > FTK_TRACKED) {
         if (b.tid == 0) {
@@ -1919,7 +1923,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         zero_term_padding(b, c.terms, K, p);
     }
 
-    const float full_ref_u = p.ref_uv[2 * id], full_ref_v = p.ref_uv[2 * id + 1];
+    const float full_ref_u = full_ref.x, full_ref_v = full_ref.y;
     const float scale = p.single_level ? 1.0f : (float)(1 << (p.n_levels - 1));
     float ref_u = p.single_level ? full_ref_u : full_ref_u / scale;
     float ref_v = p.single_level ? full_ref_v : full_ref_v / scale;
