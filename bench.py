@@ -304,10 +304,35 @@ def host_call_leg(cfg, ref_levels, cur_levels, uv, expect_uv, expect_st):
         ok, c, st = klt.TrackFeatures(rp, cp, uv)
         lat.append(time.perf_counter() - t0)
     med = float(np.median(lat))
+    # The same call as a C / C++ caller makes it: ftk_klt_track itself on prepared host arrays (what host/src/optical_flow.cpp does after
+    # its input normalisation) — without the Python mirror's per-call numpy conversions, option marshalling and result arrays.
+    import ctypes as C
+    from feature_tracker_amd import _native as NL
+    from feature_tracker_amd.tracker import default_context
+    ctx = default_context()
+    opt = klt.options().to_native()
+    n = int(cfg["n"])
+    h_ref = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    h_cur, h_st = h_ref.copy(), np.zeros(n, dtype=np.uint8)
+    fn = NL.lib().ftk_klt_track
+    args = (ctx.handle, klt._model, C.byref(opt), rp.handle, cp.handle, h_ref.ctypes.data_as(C.c_void_p), h_cur.ctypes.data_as(C.c_void_p),
+            h_st.ctypes.data_as(C.c_void_p), n, None, 0, 0, None)
+    lat_c, rc = [], 0
+    for k in range(65):
+        h_cur[:] = h_ref  # no prediction: cur = ref (optical_flow.cpp:12-14); the caller's preparation, outside the timed call
+        h_st[:] = 0
+        t0 = time.perf_counter()
+        rc |= int(fn(*args))
+        if k >= 5:
+            lat_c.append(time.perf_counter() - t0)
+    med_c = float(np.median(lat_c))
     return {"ms": med * 1e3, "features_per_s": cfg["n"] / med, "calls": len(lat), "p10_ms": float(np.percentile(lat, 10)) * 1e3, "p90_ms": float(np.percentile(lat, 90)) * 1e3,
             "bit_identical_to_resident_path": bool(ok and np.array_equal(c.view(np.uint32), expect_uv.view(np.uint32)) and np.array_equal(st, expect_st)),
             "what": "one synchronous ftk_klt_track per call through the Python mirror of feature_tracker.h (host float vectors in and out over PCIe, "
-                    "pyramids resident in HBM); the C++ class adds nothing to it"}
+                    "pyramids resident in HBM); c_abi_*: the same call on prepared host arrays, as the C++ class makes it",
+            "c_abi_ms": med_c * 1e3, "c_abi_features_per_s": cfg["n"] / med_c, "c_abi_p10_ms": float(np.percentile(lat_c, 10)) * 1e3,
+            "c_abi_p90_ms": float(np.percentile(lat_c, 90)) * 1e3,
+            "c_abi_bit_identical_to_resident_path": bool(rc == 0 and np.array_equal(h_cur.view(np.uint32), expect_uv.view(np.uint32)) and np.array_equal(h_st, expect_st))}
 
 
 def sharded_steps(slots, d_ref, d_in, d_st, steps, collective):
