@@ -258,7 +258,19 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             waves = n <= 2048 ? (p.P > 128 ? 3 : 2) : (n <= 6144 ? 2 : 1);
         } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT) {
             waves = n <= 1024 ? waves : (n <= 4096 ? 2 : 1);
+        } else if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) {
+            // (scripts/wave_policy_sweep2.sh, one / two waves: 2 400 features 190 / 155 us, 3 000: 258 / 243, 4 000: 200 / 178, 5 000: 188 / 159,
+            // 6 000: 177 / 189, 8 000: 225 / 261)
+            waves = n <= 2048 ? waves : (n <= 5632 ? 2 : 1);
         }
+    }
+    // LSSD fast with consider_patch_luminance: the chunked one-wave level that keeps a lane's sampled values in registers between the mean
+    // pass and the product pass beats the generic kernel's TWO waves wherever those would be chosen (13 x 13, one / two / three waves:
+    // 1 200 features 123 / 147 / 130 us, 1 600: 138 / 159 / 182, 2 000: 142 / 154 / 202; up to 1 024 features three waves and one wave are
+    // within 2 % of each other and the default stays)
+    if (model == FTK_MODEL_LSSD && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && p.consider_luminance && !p.tree && p.P <= 256 &&
+        n > 1024 && waves == 2) {
+        waves = 1;
     }
     if (const char *env = getenv("FTK_KLT_WAVES")) {
         waves = atoi(env);  // experiment override
