@@ -245,7 +245,16 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         waves = 4;
     }
     if (n > 1024 && waves > 2) {
-        waves = 2;
+        // Four-wave features fill the chip's 4 096 wave slots at 1 024.  THREE-wave features (13 x 13) stay up to 1 536 — six per CU — for
+        // the variants whose sweep shows it (scripts/wave_policy_sweep4.sh, three against two waves at 1 100 / 1 250 / 1 350 / 1 450 / 1 550
+        // features: LSSD fast -7 / -9 / -8 / -9 / +31 %, LSSD direct -15 / -14 / -14 / -14 / +9 %, affine direct -13 / -12 / -20 / -11 / +14 %,
+        // Basic direct -7 / -6 / -7 / -6 / -5 %; affine inverse +0 ... +5 % and the pipelined Basic inverse kernel keep two).
+        const bool nonfast = opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT;
+        const bool three_pays = (model == FTK_MODEL_LSSD && !nonfast && !p.consider_luminance) || (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) ||
+                                (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_DIRECT) || (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT);
+        if (!(waves == 3 && n <= 1536 && three_pays && !p.tree)) {
+            waves = 2;
+        }
     }
     if (n > 2048 && p.P <= 256 && !(model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT))) {
         waves = 1;
@@ -257,7 +266,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_INVERSE) {
             waves = n <= 2048 ? (p.P > 128 ? 3 : 2) : (n <= 6144 ? 2 : 1);
         } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT) {
-            waves = n <= 1024 ? waves : (n <= 4096 ? 2 : 1);
+            waves = n <= 1536 ? waves : (n <= 4096 ? 2 : 1);  // (waves: three up to 1 536 features, above)
         } else if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) {
             // (scripts/wave_policy_sweep2.sh, one / two waves: 2 400 features 190 / 155 us, 3 000: 258 / 243, 4 000: 200 / 178, 5 000: 188 / 159,
             // 6 000: 177 / 189, 8 000: 225 / 261)

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Experiment (GPU box): LSSD fast + luminance at small feature counts and LSSD direct at large ones, by waves per feature.
 SPECS=""
 for n in 200 400 600 800 1000; do SPECS="$SPECS lssd:fast:$n:6:lum"; done
 for n in 2400 3000 4000 5000 6000 8000 10000; do SPECS="$SPECS lssd:direct:$n:6"; done
