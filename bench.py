@@ -208,8 +208,15 @@ def tracker_config_leg(name, cfg, steps, ctx, dev, stream, source_hash):
     iters = d_it.cpu().numpy().astype(np.uint32)
     first_uv, first_st = outs[0][0].cpu().numpy().copy(), outs[0][1].cpu().numpy().copy()
     launches = [klt.bind(d_ref, d_in, d_st, o[0], o[1], None) for o in outs]
-    for k in range(6):
+    # Untimed launches for at least 10 ms: the leg before this one ended with its CPU oracle (0.1 - 0.5 s during which the device idles and
+    # drops its clock), and a 20-step timed region of 3 ms would otherwise sit inside the ramp back up (config 4: 153 us per step at 20
+    # steps against 143 at 100 — the same launches).  What is measured is the steady back-to-back rate, as for the headline.
+    t_warm, k = time.perf_counter(), 0
+    while k < 6 or time.perf_counter() - t_warm < 10e-3:
         launches[k & 1]()
+        k += 1
+        if k % 8 == 0:
+            stream.synchronize()
     stream.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -263,8 +270,12 @@ def matcher_config_leg(steps, ctx, dev, stream):
     d_ref = torch.from_numpy(F.pack_brief(ref).view(np.int32)).to(dev)
     d_cur = torch.from_numpy(F.pack_brief(cur).view(np.int32)).to(dev)
     d_idx = torch.full((n_ref,), -1, dtype=torch.int32, device=dev)
-    for _ in range(4):
+    t_warm, k = time.perf_counter(), 0
+    while k < 4 or time.perf_counter() - t_warm < 10e-3:  # as in tracker_config_leg: out of the clock ramp that follows an idle device
         D.hamming_match_device(ctx, d_ref, d_cur, 256, 60.0, d_idx)
+        k += 1
+        if k % 8 == 0:
+            stream.synchronize()
     stream.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
