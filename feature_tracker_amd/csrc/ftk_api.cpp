@@ -281,6 +281,23 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         n > 1024 && waves == 2) {
         waves = 1;
     }
+    // Large patches (from about 20 x 20; swept at 21 x 21, scripts/wave_policy_sweep5.sh): a feature's per-pixel arrays then take so much
+    // LDS that few features fit a CU whatever their wave count, and the "two waves beyond 1 024 features" rule — made for 13 x 13 — only
+    // halves the lanes that share a feature's pixel loops.  Four against two waves at 1 200 / 2 000 / 3 000 / 5 000 features: affine direct
+    // 128 / 250 / 341 / 382 against 243 / 475 / 579 / 558 us, affine inverse 175 / 172 / 309 / 385 against 251 / 220 / 410 / 489, LSSD direct
+    // -14 ... -18 %, LSSD inverse -11 ... -15 %, affine fast (generic kernel, up to 2 048 features) -22 %.  LSSD fast: four waves up to
+    // 1 536 features (88 against 100 us at 1 200), beyond that the chunked ONE-wave level (2 000 features 114 against 169 us, 5 000: 229
+    // against 285; with luminance 237 against 345 and 381 against 519) where the patch allows it.  Basic KLT keeps its rules (mixed).
+    if (p.P > 384 && n > 1024 && !p.tree) {
+        const bool nonfast = opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT;
+        if ((model == FTK_MODEL_AFFINE || model == FTK_MODEL_LSSD) && nonfast) {
+            waves = 4;
+        } else if (model == FTK_MODEL_LSSD) {
+            waves = (n > 1536 && (!p.consider_luminance || p.P <= 512)) ? 1 : 4;
+        } else if (model == FTK_MODEL_AFFINE && n <= 2048) {
+            waves = 4;
+        }
+    }
     if (const char *env = getenv("FTK_KLT_WAVES")) {
         waves = atoi(env);  // experiment override
     }
