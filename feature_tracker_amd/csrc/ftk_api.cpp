@@ -252,7 +252,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         const bool nonfast = opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT;
         const bool three_pays = (model == FTK_MODEL_LSSD && !nonfast && !p.consider_luminance) || (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) ||
                                 (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_DIRECT) || (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT);
-        if (!(waves == 3 && n <= 1536 && three_pays && !p.tree)) {
+        // (15 x 15, four waves: the same at 1 200 features, LSSD -8 ... -10 %, affine direct -20 %: kept up to 1 280)
+        if (!(three_pays && !p.tree && ((waves == 3 && n <= 1536) || (waves == 4 && n <= 1280 && p.P <= 256)))) {
             waves = 2;
         }
     }
@@ -296,6 +297,25 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             waves = (n > 1536 && (!p.consider_luminance || p.P <= 512)) ? 1 : 4;
         } else if (model == FTK_MODEL_AFFINE && n <= 2048) {
             waves = 4;
+        }
+    }
+    // Between the two (15 x 15 and 17 x 17 swept, scripts/wave_policy_sweep6.sh; 1 200 / 2 000 / 3 000 features): affine direct wants four
+    // waves at every count (15 x 15: 75 / 142 / 179 against 94 / 206 / 229 us on two; 17 x 17: 116 / 159 / 121 against 175 / 228 / 146), affine
+    // inverse three (17 x 17: -19 / -17 / -11 %, 15 x 15: -5 / -6 / -7 %), affine fast on the generic kernel three (17 x 17: -10 %); LSSD fast
+    // beyond 2 048 features its chunked one-wave level also above 256 pixels (17 x 17, 3 000 features: 138 -> 103 us, with luminance
+    // 310 -> 225), and the pipelined Basic inverse kernel one wave from 17 x 17 x 3 000 on (63 -> 46 us).
+    if (p.P > 192 && p.P <= 384 && n > 1024 && !p.tree) {
+        const bool fast_like_m = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
+        if (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_DIRECT) {
+            waves = 4;
+        } else if (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_INVERSE) {
+            waves = 3;
+        } else if (model == FTK_MODEL_AFFINE && fast_like_m && p.P > 256 && n <= 2048) {
+            waves = 3;
+        } else if (model == FTK_MODEL_LSSD && fast_like_m && p.P > 256 && n > 2048) {
+            waves = 1;
+        } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.P > 256 && p.P <= 324 && n > 2560) {
+            waves = 1;
         }
     }
     if (const char *env = getenv("FTK_KLT_WAVES")) {
