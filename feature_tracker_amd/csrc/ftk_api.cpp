@@ -271,7 +271,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         } else if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) {
             // (scripts/wave_policy_sweep2.sh, one / two waves: 2 400 features 190 / 155 us, 3 000: 258 / 243, 4 000: 200 / 178, 5 000: 188 / 159,
             // 6 000: 177 / 189, 8 000: 225 / 261)
-            waves = n <= 2048 ? waves : (n <= 5632 ? 2 : 1);
+            // (9 x 9 and 11 x 11, scripts/wave_policy_sweep7.sh: at 6 000 features two waves are still 14 - 23 % ahead)
+            waves = n <= 2048 ? waves : (n <= (p.P <= 128 ? 7168 : 5632) ? 2 : 1);
         }
     }
     // LSSD fast with consider_patch_luminance: the chunked one-wave level that keeps a lane's sampled values in registers between the mean
@@ -280,6 +281,11 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // within 2 % of each other and the default stays)
     if (model == FTK_MODEL_LSSD && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && p.consider_luminance && !p.tree && p.P <= 256 &&
         n > 1024 && waves == 2) {
+        waves = 1;
+    }
+    // Small patches (9 x 9, 11 x 11: two waves by pixel count): LSSD fast is 5 - 15 % faster on its chunked one-wave level from 600
+    // features on (scripts/wave_policy_sweep7.sh: 1 500 features 67 -> 59 and 70 -> 61 us); every other variant sits on its best column there.
+    if (model == FTK_MODEL_LSSD && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && p.P <= 128 && n > 512 && waves == 2 && !p.tree) {
         waves = 1;
     }
     // Large patches (from about 20 x 20; swept at 21 x 21, scripts/wave_policy_sweep5.sh): a feature's per-pixel arrays then take so much
