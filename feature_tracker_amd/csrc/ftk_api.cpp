@@ -240,6 +240,9 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     //    with ONE wave per feature (no barriers, no redundant uniform work: 25 000 features at 13x13
     //    take 252 us instead of 346 us), larger patches keep 2 waves (the chain / sampling overlap
     //    still pays), and so do the non-fast affine variants (24 chains per feature).
+    // These three rules were made at 13 x 13 and 21 x 21 for Basic KLT; the blocks below refine them per variant and patch size from the
+    // sweeps of round 4 (scripts/wave_policy_sweep*.sh, profiles/r4_wave_policy_sweep.txt: every variant x 9 x 9 ... 21 x 21 x 200 ... 6 000
+    // features x 1 - 4 waves).  Whatever is chosen here changes the launch shape only, never a result.
     int waves = (p.P + 63) / 64;
     if (waves > 4) {
         waves = 4;
