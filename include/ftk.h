@@ -180,6 +180,8 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
  * Same computation on device-resident buffers, asynchronous on the context's stream.
  * d_cur_uv_out / d_status_out may alias the *_in buffers (in-place, as the reference) or be
  * separate (repeatable launches for benchmarking).  d_iters may be NULL.
+ * The (u, v) arrays are read and written a PAIR at a time (one 64-bit access per feature): pass them 8-byte aligned — any
+ * hipMalloc'ed / pinned buffer and any offset into one by whole features is.
  * Launch order (performance only, results are independent of it): calls of >= 4 096 features keep every feature's
  * iteration count in the context, and from the third consecutive call with the same n on the features are launched
  * longest-first by the counts of two calls before (sorted by one extra workgroup of the launch in between; frame-to-frame
