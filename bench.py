@@ -297,6 +297,107 @@ def matcher_config_leg(steps, ctx, dev, stream):
     }
 
 
+REAL_PAIR = (os.path.join(ROOT, "tests", "data", "optical_flow", "ref_image.png"), os.path.join(ROOT, "tests", "data", "optical_flow", "cur_image.png"))
+
+
+def real_image_features(ref_img, n, half, ctx):
+    """The reference's own front end (test/test_optical_flow.cpp:34-39: Harris corners, kMinValidResponse 40) on the reference's own
+    example frame, topped up to n on a jittered grid (the reference's test stops at 300 corners; a front end that keeps 2 000 tracks
+    alive fills in weaker points the same way)."""
+    import feature_tracker_amd as F
+
+    det = F.FeaturePointHarrisDetector(ctx)
+    det.options().kMinFeatureDistance, det.options().kMinValidResponse = 15, 40.0
+    _, uv = det.DetectGoodFeatures(ref_img, n)
+    rows, cols = ref_img.shape
+    margin = 4 * half + 8
+    k = np.arange(max(0, n - uv.shape[0]), dtype=np.int64)
+    fill = np.stack([margin + (k * 37) % (cols - 2 * margin) + 0.25 * (k % 4), margin + (k * 53) % (rows - 2 * margin) + 0.5 * (k % 2)], axis=1).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([uv, fill], axis=0)[:n], dtype=np.float32), int(uv.shape[0])
+
+
+def real_images_leg(steps, ctx, dev, stream):
+    """The workload the reference's users have: the reference's example pair (test/test_optical_flow.cpp:31-32; the
+    two PNGs are data files its tests load, committed under tests/data/), Harris corners topped up to 300 and 2 000, 13 x 13 patches,
+    4 levels (test_optical_flow.cpp:24-27), every model x method.  Real frames hold features that never converge and run kMaxIteration
+    iterations on every level, so a call of fewer than 4 096 features lasts as long as its slowest feature.  Per row: K back-to-back
+    launches on device-resident buffers (ms_per_step, as the headline is timed), ONE synchronous host-vector call (ftk_klt_track, median),
+    and the first launch's (u, v, status, iteration counts) against the oracle on the same inputs."""
+    import ctypes as C
+
+    import torch
+    from PIL import Image
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import _native as NL
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+    from tests import oracle_lib
+
+    ref_img = np.ascontiguousarray(np.array(Image.open(REAL_PAIR[0]).convert("L"), dtype=np.uint8))
+    cur_img = np.ascontiguousarray(np.array(Image.open(REAL_PAIR[1]).convert("L"), dtype=np.uint8))
+    levels, half = 4, 6
+    ref_levels, cur_levels = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+    rp, cp = D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev)
+    rows = {}
+    t_leg = time.perf_counter()
+    for n in (300, 2000):
+        uv, n_harris = real_image_features(ref_img, n, half, ctx)
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_in, d_st = d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev)
+        outs = [(torch.empty_like(d_ref), torch.empty_like(d_st)) for _ in range(2)]
+        d_it = torch.zeros(n, dtype=torch.int32, device=dev)
+        for model in ("basic", "affine", "lssd"):
+            for method in ("inverse", "direct", "fast"):
+                opt = F.OpticalFlowOptions()
+                opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, half, half, n
+                klt = D.DeviceKlt(model, opt, rp, cp, ctx)
+                klt.track(d_ref, d_in, d_st, outs[0][0], outs[0][1], d_it)
+                stream.synchronize()
+                iters = d_it.cpu().numpy().astype(np.uint32)
+                g_uv, g_st = outs[0][0].cpu().numpy().copy(), outs[0][1].cpu().numpy().copy()
+                launches = [klt.bind(d_ref, d_in, d_st, o[0], o[1], None) for o in outs]
+                t_warm, k = time.perf_counter(), 0
+                while k < 6 or time.perf_counter() - t_warm < 5e-3:  # out of the clock ramp that follows the oracle of the row before
+                    launches[k & 1]()
+                    k += 1
+                    if k % 8 == 0:
+                        stream.synchronize()
+                stream.synchronize()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    launches[k & 1]()
+                stream.synchronize()
+                ms = (time.perf_counter() - t0) / steps * 1e3
+                l_uv, l_st = outs[(steps - 1) & 1][0].cpu().numpy(), outs[(steps - 1) & 1][1].cpu().numpy()
+                # the literal call: host vectors in and out, one synchronous ftk_klt_track (what the C++ class does after its normalisation)
+                h_ref, h_cur, h_st = uv.copy(), uv.copy(), np.zeros(n, dtype=np.uint8)
+                o_n = opt.to_native()
+                fn = NL.lib().ftk_klt_track
+                a = (ctx.handle, NL.MODELS[model], C.byref(o_n), rp.handle, cp.handle, h_ref.ctypes.data_as(C.c_void_p), h_cur.ctypes.data_as(C.c_void_p),
+                     h_st.ctypes.data_as(C.c_void_p), n, None, 0, 0, None)
+                lat, rc = [], 0
+                for k in range(24):
+                    h_cur[:] = h_ref
+                    h_st[:] = 0
+                    t0 = time.perf_counter()
+                    rc |= int(fn(*a))
+                    if k >= 4:
+                        lat.append(time.perf_counter() - t0)
+                ok, c_uv, c_st, c_it = oracle_lib.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=half, max_points=n)
+                same = lambda u, s: bool(np.array_equal(u.view(np.uint32), c_uv.view(np.uint32)) and np.array_equal(s, c_st))
+                rows[f"{model}_{method}_{n}"] = {
+                    "ms_per_step": ms, "host_call_ms": float(np.median(lat)) * 1e3, "features_per_s": n / (ms * 1e-3), "tracked": int((g_st == 1).sum()),
+                    "mean_iterations_per_feature": float(iters.mean()), "max_iterations_of_a_feature": int(iters.max()),
+                    "features_at_max_iterations": int((iters >= levels * int(o_n.max_iteration)).sum()),
+                    "bit_identical": bool(same(g_uv, g_st) and same(l_uv, l_st) and rc == 0 and same(h_cur, h_st) and np.array_equal(iters, c_it)),
+                    "harris_corners": n_harris}
+    return {"what": "the reference's example pair (tests/data/optical_flow/{ref,cur}_image.png, 752x480), Harris corners (min distance 15, min response 40) topped up to n on a "
+                    "jittered grid, 13x13 patch, 4 levels, defaults otherwise; keys: model_method_n; ms_per_step = back-to-back device-resident launches, host_call_ms = one "
+                    "synchronous ftk_klt_track with host vectors (median of 20); bit_identical = first and last launch, the host call and the iteration counts against the oracle",
+            "steps": steps, "rows": rows, "all_bit_identical": all(r["bit_identical"] for r in rows.values()), "seconds_spent": time.perf_counter() - t_leg}
+
+
 def host_call_leg(cfg, ref_levels, cur_levels, uv, expect_uv, expect_st):
     """SURVEY.md 8(d), literally: N / wall time of ONE TrackFeatures call — host vectors in, host vectors out, one synchronous
     ftk_klt_track (H2D of ref_uv / cur_uv / status, the tracker launch, D2H) with both pyramids already resident
@@ -352,6 +453,210 @@ def sharded_steps(slots, d_ref, d_in, d_st, steps, collective):
     for k in range(steps):
         slots[k & 1].launch_local(d_ref, d_in, d_st)
         slots[k & 1].gather(force_collective=collective)
+
+
+CONFIG5_TOTAL = 200000  # BASELINE.json configs[4]: 200 000 features, 1920x1080, 4 levels, sharded over the GPUs of the node
+
+
+def config5_sharded_leg(steps, warmup, world, rank, dev, make_tracker, native=None, total=CONFIG5_TOTAL, use_graph=True):
+    """BASELINE.json configs[4] — the one configuration that IS multi-GPU — measured by every `bench.py --gpus N` run with N > 1 (or with
+    FTK_BENCH_FORCE_DIST=1 at N = 1) without further flags: `total` features block-sharded over the ranks, ONE all-gather of the packed
+    (uv, status) shards per step, strong scaling.  Runs on EVERY rank (it contains collectives) after the weak-scaling region and returns
+    the `config5_sharded` object: per-step time (max over ranks), the kernel and the all-gather timed separately, gathered == unsharded.
+
+    Device-agnostic on purpose: `--dry-launch` calls this same function over gloo with a stand-in tracker on the CPU, so that the step
+    loop, the slots, the timing reductions and the object's schema have met N > 1 ranks before the first 8-GPU lease (tests/
+    test_bench_launch_cpu.py).  make_tracker(total) -> (tracker, d_ref, d_in, d_st, unsharded(d_uv_out, d_st_out)); native(total, d_ref,
+    d_in, d_st) -> dict for the C-ABI path (ftk_klt_track_sharded_device: RCCL issued by libftk_hip.so), or None where there is no device."""
+    import torch
+    import torch.distributed as dist
+
+    from feature_tracker_amd import dist as FD
+
+    gpu = torch.device(dev).type == "cuda"
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, count):
+        """fn() `count` times back to back, barrier + synchronise on both sides, max over ranks; seconds per call."""
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for k in range(count):
+            fn(k)
+        sync()
+        dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0) / count
+
+    tracker, d_ref, d_in, d_st, unsharded = make_tracker(total)
+    slots = [FD.ShardedKlt(tracker, total, dev, world, rank) for _ in range(2)]  # two alternating result slots
+    sharded_steps(slots, d_ref, d_in, d_st, max(2, warmup), True)
+    sync()
+    graph = None
+    if gpu and use_graph and steps >= 2 and os.environ.get("FTK_BENCH_NO_GRAPH") != "1":
+        # as in the weak-scaling region: the K steps captured once, gather k on a side stream beside kernel k + 1; every rank must take
+        # the same path, so capture success is all-reduced
+        ok = 1
+        stream = torch.cuda.current_stream()
+        try:
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            side = torch.cuda.Stream(device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                cap_stream = torch.cuda.current_stream()
+                gather_done = {}
+                for k in range(steps):
+                    slot = slots[k & 1]
+                    if k >= 2:
+                        cap_stream.wait_event(gather_done[k - 2])
+                    slot.launch_local(d_ref, d_in, d_st)
+                    kernel_done = torch.cuda.Event()
+                    kernel_done.record(cap_stream)
+                    side.wait_event(kernel_done)
+                    with torch.cuda.stream(side):
+                        slot.gather(force_collective=True)
+                        gather_done[k] = torch.cuda.Event()
+                        gather_done[k].record(side)
+                cap_stream.wait_stream(side)
+            graph = g
+        except Exception as exc:
+            ok, graph = 0, None
+            if rank == 0:
+                print(f"bench.py: config5_sharded: graph capture unavailable ({type(exc).__name__}: {exc}); using the per-step loop", file=sys.stderr)
+        torch.cuda.synchronize()
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            graph = None
+        if graph is not None:
+            graph.replay()
+            torch.cuda.synchronize()
+    if graph is not None:
+        per_step = timed(lambda k: graph.replay(), 1) / steps
+    else:
+        per_step = timed(lambda k: (slots[k & 1].launch_local(d_ref, d_in, d_st), slots[k & 1].gather(force_collective=True)), steps)
+    loop_step = per_step if graph is None else timed(lambda k: (slots[k & 1].launch_local(d_ref, d_in, d_st), slots[k & 1].gather(force_collective=True)), steps)
+    kernel_s = timed(lambda k: slots[k & 1].launch_local(d_ref, d_in, d_st), steps)
+    gather_s = timed(lambda k: slots[k & 1].gather(force_collective=True), steps)
+    # every rank holds every rank's shard: the gathered result must equal ONE unsharded launch over all features on this rank
+    want_uv, want_st = torch.empty_like(d_ref), torch.empty_like(d_st)
+    unsharded(want_uv, want_st)
+    sync()
+    same = True
+    for sl in slots:
+        guv, gst = FD.unpack_gathered(sl.gathered, total, world)
+        same = same and bool(torch.equal(guv.view(torch.int32), want_uv.view(torch.int32)) and torch.equal(gst, want_st))
+    flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    tracked = float((want_st == 1).float().mean().item())
+    cap = FD.shard_capacity(total, world)
+    out = {
+        "workload": f"BASELINE configs[4]: {total} features in total block-sharded x{world}, one all-gather of packed (uv, status) per step; strong scaling",
+        "total_features": int(total), "features_per_rank": int(cap), "packed_bytes_per_rank": int(FD.packed_bytes(cap)), "rccl_ranks": int(dist.get_world_size()),
+        "backend": dist.get_backend(), "steps": int(steps),
+        "torch": {"ms_per_step": per_step * 1e3, "features_per_s": total / per_step, "ms_per_step_plain_loop": loop_step * 1e3,
+                  "kernel_us": kernel_s * 1e6, "all_gather_us": gather_s * 1e6, "graph": graph is not None,
+                  "gathered_equals_unsharded_bitwise": bool(flag.item() == 1), "tracked_fraction": tracked,
+                  "what": "feature_tracker_amd.dist.ShardedKlt: ftk_klt_track_device on this rank's block + torch.distributed all_gather_into_tensor; "
+                          "every figure is the max over ranks between barriers; kernel_us / all_gather_us: the two halves of a step timed alone, back to back"},
+    }
+    if native is not None:
+        try:
+            out["native_comm"] = native(total, d_ref, d_in, d_st, want_uv, want_st, timed)
+        except Exception as exc:  # reported, never fatal for the line (every rank takes the same branch: the failure modes are local set-up errors)
+            out["native_comm"] = {"error": f"{type(exc).__name__}: {exc}"}
+    else:
+        out["native_comm"] = {"skipped": "no device on this path (dry launch)"}
+    return out
+
+
+def _config5_device_parts(world, rank, local_rank, dev, ctx):
+    """make_tracker / native for config5_sharded_leg on a HIP device (bench.py main and run_native_comm)."""
+    import torch
+    import torch.distributed as dist
+
+    import feature_tracker_amd as F
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd import synth
+
+    cfg = dict(synth.CONFIGS["config5_shard"])
+    w, h, levels, half = cfg["width"], cfg["height"], cfg["levels"], cfg["half"]
+    state = {}
+
+    def make_tracker(total):
+        ref_img, cur_img = synth.make_image_pair(w, h, (3.3, -2.1))
+        ref_levels, cur_levels = synth.build_pyramid(ref_img, levels), synth.build_pyramid(cur_img, levels)
+        uv = synth.make_features(total, w, h, half=half)  # the same full list on every rank
+        opt = F.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = cfg["method"], half, half, total
+        klt = D.DeviceKlt(cfg["model"], opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        d_ref = torch.from_numpy(uv).to(dev)
+        d_in, d_st = d_ref.clone(), torch.zeros(total, dtype=torch.uint8, device=dev)
+        state["klt"] = klt
+        return klt, d_ref, d_in, d_st, (lambda o_uv, o_st: klt.track(d_ref, d_in, d_st, o_uv, o_st, None))
+
+    def native(total, d_ref, d_in, d_st, want_uv, want_st, timed):
+        from feature_tracker_amd import _native as NL
+
+        klt = state["klt"]
+        stream = torch.cuda.current_stream()
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(D.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        stream.synchronize()
+        comm = D.Comm(ctx, rank, world, bytes(uid.cpu().numpy().tobytes()))
+        try:
+            d_out, d_sto = torch.zeros_like(d_ref), torch.zeros_like(d_st)
+            launch = klt.bind_sharded(comm, d_ref, d_in, d_st, d_out, d_sto)
+            for _ in range(3):
+                launch()
+            steps = state.get("steps", 20)
+            per_step = timed(lambda k: launch(), steps)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(d_out.view(torch.int32), want_uv.view(torch.int32)) and torch.equal(d_sto, want_st))
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return {"ms_per_step": per_step * 1e3, "features_per_s": total / per_step, "rccl_ranks": int(NL.lib().ftk_comm_world(comm.handle)),
+                    "gathered_equals_unsharded_bitwise": bool(flag.item() == 1), "steps": steps,
+                    "what": "ftk_klt_track_sharded_device per step: tracker kernel on this rank's block, ncclAllGather issued by libftk_hip.so on the context "
+                            "stream, scatter kernel; plain per-step loop; max over ranks between barriers"}
+        finally:
+            comm.close()
+
+    return make_tracker, native, state
+
+
+def run_config5_leg(args, world, rank, local_rank, dev, ctx, stream, out):
+    """The config5_sharded object of an N > 1 (or forced-dist) run, under a deadline: if the leg does not finish (a collective that never
+    completes on a first 8-GPU lease), rank 0 still prints the weak-scaling line — with the failure named — and every rank leaves."""
+    import threading
+
+    import torch
+
+    def expire():
+        if rank == 0 and out is not None:
+            out["config5_sharded"] = {"error": f"did not finish within {args.config5_timeout:.0f} s; the weak-scaling figures above are complete"}
+            print(json.dumps(out), flush=True)
+        os._exit(0 if rank == 0 else 5)
+
+    guard = threading.Timer(args.config5_timeout, expire)
+    guard.daemon = True
+    guard.start()
+    try:
+        with torch.cuda.stream(stream):
+            make_tracker, native, state = _config5_device_parts(world, rank, local_rank, dev, ctx)
+            steps = max(5, min(args.steps, 50))
+            state["steps"] = steps
+            leg = config5_sharded_leg(steps, min(args.warmup, 5), world, rank, dev, make_tracker, native, total=args.config5_total)
+    finally:
+        guard.cancel()
+    return leg
 
 
 def run_sharded(args, cfg, world, rank, local_rank, dev, use_dist):
@@ -526,8 +831,9 @@ def run_native_comm(args, cfg, world, rank, local_rank, dev):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    out = None
     if rank == 0:
-        print(json.dumps({
+        out = {
             "metric": "tracked features/sec (2000 pts, 640x480, 4-lvl pyr)", "value": n * args.steps / elapsed, "unit": "tracked features/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -535,8 +841,14 @@ def run_native_comm(args, cfg, world, rank, local_rank, dev):
                                    f"{2 * half + 1}x{2 * half + 1} patch",
                        "parallelism": f"features sharded x{world}, pyramids replicated, one ncclAllGather of packed (uv,status) per step issued by "
                                       "libftk_hip.so (ftk_klt_track_sharded_device) + scatter kernel; plain per-step loop",
-                       "tracked_fraction": tracked, "gathered_block_equals_local_launch": ok}}), flush=True)
-    if world > 1:
+                       "tracked_fraction": tracked, "gathered_block_equals_local_launch": ok}}
+    if dist.is_initialized() and not args.no_config5_leg:
+        leg = run_config5_leg(args, world, rank, local_rank, dev, ctx, stream, out)
+        if out is not None:
+            out["config5_sharded"] = leg
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -594,6 +906,23 @@ def self_launch(n_ranks: int, argv, timeout_s: float) -> int:
     return rc
 
 
+class _DryTracker:
+    """Rehearsal scaffolding of --dry-launch only: a stand-in for the device tracker that writes a known function of the GLOBAL feature
+    index, so that the sharding bookkeeping around it can be checked over gloo on the CPU.  Never part of a measurement."""
+
+    def __init__(self, cap):
+        self.max_track_points = int(cap)
+
+    def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters, max_track_points=None):
+        import torch
+
+        m = ref_uv.shape[0]
+        limit = m if max_track_points is None else int(max_track_points)
+        tracked = torch.arange(m) < limit
+        cur_uv_out.copy_(torch.where(tracked[:, None], ref_uv * 2.0 + 1.0, cur_uv_in))
+        status_out.copy_(torch.where(tracked, (ref_uv[:, 0].to(torch.int64) % 3).to(torch.uint8), status_in))
+
+
 def dry_launch(args, world: int, rank: int) -> None:
     """--dry-launch: the rank plumbing of an N-rank run without any device work (gloo on the CPU): every rank joins the
     process group, one all-reduce counts the ranks, one all-gather moves a packed result shard of the workload's size, and rank 0
@@ -622,24 +951,14 @@ def dry_launch(args, world: int, rank: int) -> None:
         # device tracker that writes a known function of the GLOBAL feature index (rehearsal scaffolding of this flag only).
         total, cap_global = args.shard_total, args.shard_total - args.shard_total // 7  # a cap that cuts into the last blocks
 
-        class _DryTracker:
-            max_track_points = cap_global
-
-            def track(self, ref_uv, cur_uv_in, status_in, cur_uv_out, status_out, iters, max_track_points=None):
-                m = ref_uv.shape[0]
-                limit = m if max_track_points is None else int(max_track_points)
-                tracked = torch.arange(m) < limit
-                cur_uv_out.copy_(torch.where(tracked[:, None], ref_uv * 2.0 + 1.0, cur_uv_in))
-                status_out.copy_(torch.where(tracked, (ref_uv[:, 0].to(torch.int64) % 3).to(torch.uint8), status_in))
-
         idx = torch.arange(total, dtype=torch.float32)
         d_ref = torch.stack([idx, -idx], dim=1).contiguous()
         d_in, d_st = d_ref + 0.5, torch.full((total,), 9, dtype=torch.uint8)
-        slots = [FD.ShardedKlt(_DryTracker(), total, "cpu", world, rank) for _ in range(2)]
+        slots = [FD.ShardedKlt(_DryTracker(cap_global), total, "cpu", world, rank) for _ in range(2)]
         sharded_steps(slots, d_ref, d_in, d_st, max(2, args.steps), True)
         results = [FD.unpack_gathered(sl.gathered, total, world) for sl in slots]
         want_uv, want_st = torch.empty_like(d_ref), torch.empty_like(d_st)
-        _DryTracker().track(d_ref, d_in, d_st, want_uv, want_st, None, max_track_points=cap_global)
+        _DryTracker(cap_global).track(d_ref, d_in, d_st, want_uv, want_st, None, max_track_points=cap_global)
         bounds = [FD.shard_bounds(total, world, r) for r in range(world)]
         sharded = {"total": total, "global_cap": cap_global, "capacity": FD.shard_capacity(total, world), "packed_bytes": FD.packed_bytes(FD.shard_capacity(total, world)),
                    "blocks_cover_the_list": bounds[0][0] == 0 and bounds[-1][1] == total and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1)),
@@ -647,13 +966,27 @@ def dry_launch(args, world: int, rank: int) -> None:
         flag = torch.tensor([1 if (sharded["gathered_equals_unsharded"] and sharded["blocks_cover_the_list"]) else 0], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank holds every rank's result: all must agree
         sharded["all_ranks_agree"] = bool(flag.item() == 1)
+    # The config5_sharded object of an N > 1 run (BASELINE configs[4]), through the SAME function the GPU run calls — step loop, result
+    # slots, timing reductions, the gathered == unsharded check, the schema — around the stand-in tracker.
+    config5 = None
+    if not args.no_config5_leg:
+        def make_dry(total):
+            idx = torch.arange(total, dtype=torch.float32)
+            d_ref = torch.stack([idx, -idx], dim=1).contiguous()
+            d_in, d_st = d_ref + 0.5, torch.full((total,), 9, dtype=torch.uint8)
+            trk = _DryTracker(total)
+            return trk, d_ref, d_in, d_st, (lambda o_uv, o_st: trk.track(d_ref, d_in, d_st, o_uv, o_st, None))
+
+        config5 = config5_sharded_leg(max(2, min(args.steps, 5)), 1, world, rank, "cpu", make_dry, None, total=args.config5_total)
     dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": int(dist.get_world_size()), "ranks_counted": int(ones.item()),
                           "backend": "gloo", "all_gather_ok": shards_ok, "self_launched": os.environ.get("FTK_BENCH_SELF_LAUNCHED") == "1",
-                          "steps": args.steps, "warmup": args.warmup, "sharded": sharded}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "sharded": sharded, "config5_sharded": config5}), flush=True)
     dist.destroy_process_group()
     if not shards_ok or int(ones.item()) != world or (sharded is not None and not sharded["all_ranks_agree"]):
+        raise SystemExit(4)
+    if config5 is not None and not config5["torch"]["gathered_equals_unsharded_bitwise"]:
         raise SystemExit(4)
 
 
@@ -668,6 +1001,7 @@ def main():
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the with_pyramid_upload measurement (N = 1 only; it runs after the timed region)")
     ap.add_argument("--no-configs-leg", action="store_true", help="skip the `configs` object (the other BASELINE configurations, N = 1 only; after the timed region)")
     ap.add_argument("--no-host-call-leg", action="store_true", help="skip the `host_call` object (one synchronous host-vector TrackFeatures call; N = 1 only)")
+    ap.add_argument("--no-real-images-leg", action="store_true", help="skip the `real_images` object (the reference's example pair, every variant; N = 1 only)")
     ap.add_argument("--shard-total", type=int, default=0,
                     help="strong-scaling variant (BASELINE.json configs[4] style): this many features in total, block-sharded over the "
                          "ranks with feature_tracker_amd.dist.ShardedKlt; 0 = the contractual weak-scaling workload")
@@ -677,6 +1011,9 @@ def main():
                          "of torch.distributed's all_gather_into_tensor; same workload, same metric ($FTK_BENCH_NATIVE_COMM=1 selects it too)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.0,
                     help="experiment knob: keep the device busy with untimed steps for this long before the W warmup steps (clock ramp study)")
+    ap.add_argument("--no-config5-leg", action="store_true", help="N > 1 (or FTK_BENCH_FORCE_DIST=1): skip the `config5_sharded` object")
+    ap.add_argument("--config5-total", type=int, default=CONFIG5_TOTAL, help="features in total of the config5_sharded leg (BASELINE configs[4]: 200 000)")
+    ap.add_argument("--config5-timeout", type=float, default=300.0, help="seconds the config5_sharded leg may take before the line is printed without it")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rank plumbing only: gloo on the CPU, no device work (CPU test of the N-rank launch)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 runs: seconds before the ranks are ended")
@@ -921,6 +1258,12 @@ def main():
             configs_leg["seconds_spent"] = time.perf_counter() - t_cfg
         if world == 1 and args.features == 0 and not args.no_host_call_leg:
             host_call = host_call_leg(cfg, ref_levels, cur_levels, uv, first_uv, first_st)
+        real_images = None
+        if world == 1 and args.features == 0 and not args.no_real_images_leg:
+            try:
+                real_images = real_images_leg(max(20, min(args.steps, 100)), ctx, dev, stream)
+            except (ImportError, FileNotFoundError) as exc:  # no PIL / no data files on this machine: say so in the line
+                real_images = {"skipped": f"{type(exc).__name__}: {exc}"}
         if use_dist:
             # every rank must now hold every rank's result shard: spot-check the own shard inside the gathered buffer
             per = FD.packed_bytes(n)
@@ -997,6 +1340,8 @@ def main():
             out["with_pyramid_upload"] = upload
         if host_call is not None:
             out["host_call"] = host_call
+        if real_images is not None:
+            out["real_images"] = real_images
         if configs_leg is not None:
             # the headline workload in the same shape, so that the object covers all five BASELINE configurations
             configs_leg[args.workload] = {
@@ -1008,6 +1353,14 @@ def main():
             out["configs"] = configs_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ref_levels, cur_levels, uv)
+    else:
+        out = None
+    if use_dist and not args.no_config5_leg:
+        # BASELINE.json configs[4] (200 000 features sharded over the ranks): measured by every N > 1 run, after the weak-scaling region
+        leg = run_config5_leg(args, world, rank, local_rank, dev, ctx, stream, out)
+        if out is not None:
+            out["config5_sharded"] = leg
+    if out is not None:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

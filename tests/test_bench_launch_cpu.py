@@ -87,3 +87,22 @@ def test_two_ranks_rehearse_config5_strong_scaling_bookkeeping():
     assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
     sh = [l for o in outs for l in _json_lines(o[0])][0]["sharded"]
     assert sh["capacity"] == 33335 and sh["gathered_equals_unsharded"] and sh["all_ranks_agree"]
+
+
+CONFIG5_KEYS = {"workload", "total_features", "features_per_rank", "packed_bytes_per_rank", "rccl_ranks", "backend", "steps", "torch", "native_comm"}
+CONFIG5_TORCH_KEYS = {"ms_per_step", "features_per_s", "ms_per_step_plain_loop", "kernel_us", "all_gather_us", "graph", "gathered_equals_unsharded_bitwise",
+                      "tracked_fraction", "what"}
+
+
+def test_two_ranks_produce_the_config5_sharded_object_without_extra_flags():
+    # `bench.py --gpus N` (N > 1) with the DRIVER's arguments must carry BASELINE configs[4] — 200 000 features sharded
+    # over the ranks, one all-gather per step — in its one line.  The dry launch runs the same config5_sharded_leg() the GPU run calls
+    # (step loop, slots, timing reductions, gathered == unsharded), over gloo around a stand-in tracker: schema and bookkeeping at 2 ranks.
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-launch"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    c5 = _json_lines(res.stdout)[0]["config5_sharded"]
+    assert set(c5) == CONFIG5_KEYS and set(c5["torch"]) == CONFIG5_TORCH_KEYS
+    assert c5["total_features"] == 200000 and c5["features_per_rank"] == 100000 and c5["rccl_ranks"] == 2 and c5["packed_bytes_per_rank"] == 900000
+    assert c5["torch"]["gathered_equals_unsharded_bitwise"] is True
+    assert c5["torch"]["ms_per_step"] > 0 and c5["torch"]["kernel_us"] > 0 and c5["torch"]["all_gather_us"] > 0
+    assert abs(c5["torch"]["features_per_s"] - 200000 / (c5["torch"]["ms_per_step"] * 1e-3)) < 1e-3 * c5["torch"]["features_per_s"]
