@@ -9,12 +9,12 @@ native library; the first compute call does, and fails loudly if it has not been
 from . import synth  # noqa: F401
 from .tracker import (  # noqa: F401
     BriefDescriptor, BriefMatcher, CosineMatcher, DirectMethod, DirectMethodOptions, DiskMatcher, SuperpointMatcher, Context, FeaturePointHarrisDetector, DescriptorMatcherOptions, ImagePyramid, OpticalFlow, OpticalFlowAffineKlt, OpticalFlowBasicKlt,
-    OpticalFlowLssdKlt, OpticalFlowOptions, default_context, pack_brief, unpack_brief,
+    OpticalFlowLssdKlt, OpticalFlowOptions, default_context, pack_brief, unpack_brief, refresh_env_switches,
     NOT_TRACKED, TRACKED, LARGE_RESIDUAL, OUTSIDE, NUMERIC_ERROR,
 )
 
 __all__ = [
     "BriefDescriptor", "BriefMatcher", "CosineMatcher", "DirectMethod", "DirectMethodOptions", "DiskMatcher", "SuperpointMatcher", "Context", "FeaturePointHarrisDetector", "DescriptorMatcherOptions", "ImagePyramid", "OpticalFlow", "OpticalFlowAffineKlt", "OpticalFlowBasicKlt",
-    "OpticalFlowLssdKlt", "OpticalFlowOptions", "default_context", "pack_brief", "unpack_brief", "synth",
+    "OpticalFlowLssdKlt", "OpticalFlowOptions", "default_context", "pack_brief", "unpack_brief", "refresh_env_switches", "synth",
     "NOT_TRACKED", "TRACKED", "LARGE_RESIDUAL", "OUTSIDE", "NUMERIC_ERROR",
 ]

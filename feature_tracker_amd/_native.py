@@ -24,7 +24,7 @@ METHODS = {"inverse": 0, "direct": 1, "fast": 2, "sse": 3, "neon": 4}
 
 # every symbol include/ftk.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "ftk_abi_version", "ftk_build_info", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize", "ftk_warmup", "ftk_set_reduction_mode", "ftk_pyramid_update",
+    "ftk_abi_version", "ftk_build_info", "ftk_device_count", "ftk_context_create", "ftk_context_destroy", "ftk_last_error", "ftk_synchronize", "ftk_warmup", "ftk_set_reduction_mode", "ftk_context_refresh_env", "ftk_pyramid_update",
     "ftk_default_klt_options", "ftk_pyramid_upload", "ftk_pyramid_wrap_device", "ftk_pyramid_build", "ftk_pyramid_levels",
     "ftk_pyramid_level", "ftk_pyramid_download_level", "ftk_pyramid_destroy", "ftk_klt_track", "ftk_klt_track_device",
     "ftk_extract_extend_patch", "ftk_hamming_match", "ftk_hamming_match_device", "ftk_cosine_match", "ftk_cosine_match_device", "ftk_ldlt6_solve", "ftk_default_direct_options", "ftk_direct_track", "ftk_direct_track_batch_device", "ftk_fill_matched_pixels",
@@ -120,6 +120,7 @@ def lib() -> C.CDLL:
     l.ftk_synchronize.argtypes = [vp]
     l.ftk_warmup.argtypes = [vp, C.c_uint]
     l.ftk_set_reduction_mode.argtypes = [vp, C.c_int]
+    l.ftk_context_refresh_env.argtypes = [vp]
     l.ftk_pyramid_update.argtypes = [vp, vp, vp, C.c_int]
     l.ftk_default_klt_options.argtypes = [C.POINTER(KltOptions)]
     l.ftk_default_klt_options.restype = None

@@ -496,12 +496,32 @@ constexpr int kSpreadHeaderWords = 64;           // iter_tag, error, level, -, p
 __device__ __forceinline__ uint32_t spread_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void spread_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void spread_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The flag itself: a RELEASE store at agent scope after the storing wave has waited for its data stores, and an ACQUIRE fence in the
+// wave whose poll saw it (with relaxed flags the order of the guarded loads behind the poll rested on how gfx950 happens to
+// issue sc1 accesses, not on the memory model).  The data accesses stay relaxed agent-scope atomics.  -DFTK_SPREAD_FENCES=0: the
+// round-4 form, for A / B timing only.
+#ifndef FTK_SPREAD_FENCES
+#define FTK_SPREAD_FENCES 1
+#endif
+__device__ __forceinline__ void spread_publish(uint32_t *p, uint32_t v) {
+#if FTK_SPREAD_FENCES
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    spread_store(p, v);
+#endif
+}
+__device__ __forceinline__ void spread_acquired() {
+#if FTK_SPREAD_FENCES
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
 
 // Polls *flag until it equals `want` (or `also`); false when the wait ran out.  Whole wave, uniform address.
 __device__ __forceinline__ bool spread_wait(const uint32_t *flag, uint32_t want, uint32_t also, uint32_t &seen) {
     for (uint32_t polls = 0; polls < kSpreadMaxPolls; ++polls) {
         seen = spread_load(flag);
         if (seen == want || seen == also) {
+            spread_acquired();
             return true;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -538,7 +558,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
         Quat q = {pr.pose[1], pr.pose[2], pr.pose[3], pr.pose[0]};
         float px = pr.pose[4], py = pr.pose[5], pz = pr.pose[6];
         uint32_t iterations = 0, g = 0;
-        bool failed = false;
+        bool failed = pp.spread_poison != 0;
         if (tid == 0) {
             reinterpret_cast<uint32_t *>(sums)[80] = 0u;  // "a loader's wait ran out"
         }
@@ -558,7 +578,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                     spread_store(header + 9, __float_as_uint(py));
                     spread_store(header + 10, __float_as_uint(pz));
                     spread_stores_done();
-                    spread_store(header, g + 1u);
+                    spread_publish(header, g + 1u);
                 }
                 // ---- the stream: loaders bring chunk round r + 1 into the ring while wave 0 adds round r ----
                 float acc = 0.0f;
@@ -614,7 +634,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                 spread_store(header + 1, 1u);
                 q.x = q.y = q.z = q.w = px = py = pz = __uint_as_float(0x7FC00000u);
             }
-            spread_store(header, kSpreadStop);  // the producers leave
+            spread_publish(header, kSpreadStop);  // the producers leave
             pr.pose[0] = q.w;
             pr.pose[1] = q.x;
             pr.pose[2] = q.y;
@@ -652,6 +672,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                 seen = spread_load(header);
                 if (seen != last_tag) {
                     ok = true;
+                    spread_acquired();
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -718,7 +739,7 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
             }
             spread_stores_done();
             if (lane == 0) {
-                spread_store(chunk_flag + chunk, tag);
+                spread_publish(chunk_flag + chunk, tag);
             }
             ti += step_i;
             tpix += step_pix;
@@ -759,6 +780,23 @@ size_t direct_spread_clear_bytes(uint32_t n_track, int32_t patch_rows, int32_t p
     const long long total_terms = (long long)n_track * patch_rows * patch_cols;
     const long long n_chunks = (total_terms + kDmChunk - 1) / kDmChunk;
     return sizeof(uint32_t) * (size_t)(kSpreadHeaderWords + ((n_chunks + 63) & ~63ll));  // header + chunk flags: zero before every launch
+}
+
+// How many workgroups of the spread kernel the device can hold AT ONCE (the consumer and its producers wait for each other, so a
+// launch that is not co-resident cannot finish: its bounded waits run out and the pose is poisoned).  Occupancy per compute unit
+// from the runtime (LDS and registers as launched) x the compute units this process sees — 256 on a whole MI355X, 32 on a CPX partition.
+int direct_spread_resident_groups(uint32_t max_features, int device) {
+    const size_t lds = direct_lds_bytes(max_features);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(direct_track_spread_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        return 0;
+    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, direct_track_spread_kernel, kDmWaves * kWave, lds) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        return 0;
+    }
+    return per_cu * cus;
 }
 
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream) {

@@ -1520,13 +1520,12 @@ hipError_t cosine_launch_small(const CosineParams &p, hipStream_t stream) {
 
 }  // namespace
 
-bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby) {
-    const char *env = getenv("FTK_COSINE_SMALL");  // experiment switch, read per call
-    if (env && atoi(env) == 0) {
+bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby, bool small_off, bool small_any) {
+    if (small_off) {  // FTK_COSINE_SMALL=0 (experiment switch of the context)
         return false;
     }
-    const char *any = getenv("FTK_COSINE_SMALL_ANY");  // experiment: no size limit (scripts/cosine_small_ab.py)
-    const bool fits = (any && atoi(any) != 0) || (n_ref <= kCosineSmallRefMax && n_cur <= (nearby ? kCosineSmallCurNearby : kCosineSmallCurForce));
+    // small_any: FTK_COSINE_SMALL_ANY=1, no size limit (scripts/cosine_small_ab.py)
+    const bool fits = small_any || (n_ref <= kCosineSmallRefMax && n_cur <= (nearby ? kCosineSmallCurNearby : kCosineSmallCurForce));
     return (dim == 64 || dim == 128 || dim == 256) && fits;
 }
 
@@ -1544,7 +1543,7 @@ hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream) {
     if (p.n_ref <= 0 || p.n_cur <= 0) {
         return hipSuccess;
     }
-    if (cosine_small_form(p.n_ref, p.n_cur, p.dim, p.pred_uv != nullptr)) {
+    if (cosine_small_form(p.n_ref, p.n_cur, p.dim, p.pred_uv != nullptr, p.small_off != 0, p.small_any != 0)) {
         switch (p.dim) {
             case 64: return cosine_launch_small<8>(p, stream);
             case 128: return cosine_launch_small<16>(p, stream);

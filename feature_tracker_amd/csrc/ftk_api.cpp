@@ -177,6 +177,10 @@ int ftk_ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t 
 
 namespace {
 
+constexpr uint32_t kTailLongFrom = 24;  // iterations of a call's longest feature from which the call counts as tail-bound
+constexpr uint32_t kTailHold = 8;       // launches of the variant for which one such report holds
+constexpr uint32_t kTailFresh = 256;    // launches of the context a report may lag behind (the host enqueues far ahead of the device)
+
 int ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t bytes) { return ftk_ensure_device_buffer(ctx, buf, have, bytes); }
 
 int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, const ftk_pyramid *ref, const ftk_pyramid *cur, int32_t n,
@@ -327,7 +331,36 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             waves = 1;
         }
     }
-    if (const char *env = getenv("FTK_KLT_WAVES")) {
+    // Tail-aware (round 5).  The ladder above was swept on a scene whose features all take the same five iterations; a real frame
+    // holds a few that never converge and run kMaxIteration iterations on every level, and a call of a few thousand features then lasts
+    // as long as its slowest one (the reference's example pair, Basic inverse: 44 iterations at 2 000 features).  For such a feature
+    // the pipelined Basic-inverse kernel is fastest with ONE wave — produce a chunk, chain it, no barrier, no hand-off (same box,
+    // default / one wave: 300 features 63.5 / 60.0 us, 1 200: 81.0 / 73.0, 2 000: 84.2 / 76.8) — while level entries, which more waves
+    // share, dominate the short calls.  The kernels report each call's longest feature (klt_common.h tail_report); when this
+    // variant's recent calls had one of kTailLongFrom iterations or more, the call runs one wave per feature.
+    p.long_tail = 0;
+    if (ctx && ctx->tail_host && !ftk_env::off(FTK_ENV(ctx, klt_tail)) && model >= 0 && model < 3) {
+        const int mi = opt->method == FTK_METHOD_INVERSE ? 0 : (opt->method == FTK_METHOD_DIRECT ? 1 : 2);
+        ftk_context::TailState &ts = ctx->tail[model][mi];
+        // this variant's own word: {call number << 8 | iterations} of the longest feature of its most recent launch that has got that
+        // far.  The host may be many launches ahead of the device (back-to-back calls), so a report counts while it is at most
+        // kTailFresh launches of the context old, and one long report holds for kTailHold launches of the variant.
+        const uint32_t seen = reinterpret_cast<volatile uint32_t *>(ctx->tail_host)[model * 3 + mi];
+        const uint32_t age = (ctx->tail_call - (seen >> 8)) & 0xFFFFFFu;
+        if (seen != 0 && age <= kTailFresh && (seen & 0xFFu) >= kTailLongFrom) {
+            ts.long_until = ts.launches + kTailHold;
+            ts.longest = seen & 0xFFu;
+        }
+        p.long_tail = ts.launches < ts.long_until ? 1 : 0;
+        if (FTK_ENV(ctx, klt_tail) && atoi(FTK_ENV(ctx, klt_tail)) == 2 && ts.launches < 12) {  // diagnostic
+            fprintf(stderr, "[ftk tail] model %d method %d launch %u (context launch %u): host word call %u iterations %u, long_until %u -> long_tail %d\n", model, mi,
+                    ts.launches, ctx->tail_call, seen >> 8, seen & 0xFFu, ts.long_until, p.long_tail);
+        }
+        if (p.long_tail && model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.P <= 256 && p.patch_rows <= 64 && p.patch_cols <= 64 && !p.tree) {
+            waves = 1;
+        }
+    }
+    if (const char *env = FTK_ENV(ctx, klt_waves)) {
         waves = atoi(env);  // experiment override
     }
     p.waves_per_feature = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
@@ -340,7 +373,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         // that was before the compile-time geometry removed the SGPR spill traffic — the one-wave kernel is bound by how many
         // features are in flight, not by vector issue: the throughput mode, which drops 20 % of its VALU work, runs no faster.)
         int group = 4;
-        if (const char *env = getenv("FTK_KLT_GROUP")) {
+        if (const char *env = FTK_ENV(ctx, klt_group)) {
             group = atoi(env);  // experiment override
         }
         p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
@@ -353,13 +386,18 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         for (int i = 0; i < p.n_levels; ++i) {
             small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);
         }
-        const char *env = getenv("FTK_KLT_PIPELINED");
+        const char *env = FTK_ENV(ctx, klt_pipelined);
         p.pb_enabled = (small && !(env && atoi(env) == 0)) ? 1 : 0;
     }
     // The `fast` method (the reference's default) of Basic KLT runs the one-wave kernel of klt_fast_kernels.hip at every feature
     // count: with 1 - 2 iterations per level a feature's life is its level entries, which that kernel walks without a barrier and with
     // the next level's windows in flight (2 000 x 13 x 13: 28.8 us on the generic two-wave kernel).  Not in the throughput mode (the
     // generic kernel's instantiations serve it), not for patches whose per-pixel records would crowd the LDS.
+    // (the chunked one-wave LSSD levels choose their chain form at run time: quads while every feature of the call is resident at once)
+    p.quad_chain = n <= 4096 ? 1 : 0;
+    if (const char *env = FTK_ENV(ctx, klt_quad)) {
+        p.quad_chain = atoi(env) != 0 ? 1 : 0;  // experiment override
+    }
     p.fk_enabled = 0;
     // One wave walks all P pixels of every pass: up to 15 x 15 that beats the generic kernel's 2 - 4 waves at every feature count
     // (2 000 x 13 x 13: 22.6 vs 27.5 us; 10 000: 58.6 vs 82.9 us); larger patches only where the call is throughput-bound anyway
@@ -374,7 +412,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         for (int i = 0; i < p.n_levels; ++i) {
             small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);
         }
-        const char *env = getenv("FTK_KLT_FAST_KERNEL");
+        const char *env = FTK_ENV(ctx, klt_fast_kernel);
         ftk::KltParams one = p;
         one.features_per_group = 1;
         if (small && !(env && atoi(env) == 0) && ftk::klt_fast_lds_bytes(model, one) <= 40 * 1024) {
@@ -400,7 +438,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         }
     }
     const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
-    const char *chunk_env = getenv("FTK_LSSD_CHUNKED");
+    const char *chunk_env = FTK_ENV(ctx, lssd_chunked);
     // (with consider_patch_luminance: the variant that keeps the sampled values in registers — patches up to 512 pixels, klt_kernels.hip kLumChunks)
     if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && (!p.consider_luminance || (p.P <= 512 && !p.tree)) && !(chunk_env && atoi(chunk_env) == 0)) {
         p.lssd_chunked = 1;
@@ -411,7 +449,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     }
     if (p.fk_enabled) {
         int group = 4;  // one-wave features that never meet, several to a workgroup (the 16-workgroups-per-CU cap)
-        if (const char *env = getenv("FTK_KLT_GROUP")) {
+        if (const char *env = FTK_ENV(ctx, klt_group)) {
             group = atoi(env);  // experiment override
         }
         p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
@@ -425,7 +463,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
         p.features_per_group = 1;  // the generic kernel's workgroup is one feature ...
         if (p.waves_per_feature == 1) {
             int group = 2;  // ... or, one-wave variants, a few features that never meet (config 4, 10 000 features: 153 / 140.5 / 141 us at 1 / 2 / 4)
-            if (const char *env = getenv("FTK_KLT_GROUP")) {
+            if (const char *env = FTK_ENV(ctx, klt_group)) {
                 group = atoi(env);  // experiment override
             }
             p.features_per_group = group < 1 ? 1 : (group > 4 ? 4 : group);
@@ -443,7 +481,7 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // for the non-fast affine variants) runs the generic multi-wave kernel with those arrays in a per-workgroup slice of device
     // memory (ftk_device.h KltParams::spill) — same code, same sums.  Exact mode only.  FTK_KLT_SPILL=1 forces the form for any
     // patch, 2 also drops the LDS image windows (what happens by itself from about 280 x 280): the tests walk every variant through both.
-    const char *spill_env = getenv("FTK_KLT_SPILL");
+    const char *spill_env = FTK_ENV(ctx, klt_spill);
     const int spill_force = spill_env ? atoi(spill_env) : 0;
     if (lds > 160 * 1024 || spill_force > 0) {
         p.spill = 1;
@@ -572,7 +610,8 @@ int ftk_context_create(int device, void *stream, ftk_context **out) {
         }
         ctx->owns_stream = true;
     }
-    if (const char *env = getenv("FTK_REDUCTION")) {  // experiment switch: contexts start in the throughput mode ("tree"); default exact
+    ctx->env.read();
+    if (const char *env = FTK_ENV(ctx, reduction)) {  // experiment switch: contexts start in the throughput mode ("tree"); default exact
         ctx->reduction = (strcmp(env, "tree") == 0) ? FTK_REDUCTION_TREE : FTK_REDUCTION_EXACT;
     }
     *out = ctx;
@@ -618,6 +657,12 @@ void ftk_context_destroy(ftk_context *ctx) {
     if (ctx->match_pad) {
         (void)hipFree(ctx->match_pad);
     }
+    if (ctx->tail_host) {
+        (void)hipHostFree(ctx->tail_host);
+    }
+    if (ctx->tail_dev) {
+        (void)hipFree(ctx->tail_dev);
+    }
     if (ctx->sched_grid) {
         (void)hipFree(ctx->sched_grid);
     }
@@ -659,6 +704,15 @@ int ftk_synchronize(ftk_context *ctx) {
 }
 
 static int ensure_brief_pattern(ftk_context *ctx, int32_t n_bits, int32_t half);
+
+int ftk_context_refresh_env(ftk_context *ctx) {
+    if (!ctx) {
+        return fail(nullptr, FTK_E_INVALID_ARGUMENT, "context_refresh_env: null context");
+    }
+    FTK_LOCK(ctx);
+    ctx->env.read();
+    return FTK_OK;
+}
 
 int ftk_set_reduction_mode(ftk_context *ctx, int mode) {
     if (!ctx) {
@@ -937,7 +991,7 @@ int ftk_pyramid_build(ftk_context *ctx, const uint8_t *image, int32_t rows, int3
     // synchronisation (CreateImagePyramid x 2 sits inside the reference's timed region, test_optical_flow.cpp:69-73: 57 us per
     // build before).  One-level pyramids and FTK_PYRAMID_ZEROCOPY=0 / FTK_PYRAMID_FUSED=0 keep the copy.
     ftk_context::ImageStage *stage = nullptr;
-    static const bool stage_allowed = !(getenv("FTK_PYRAMID_ZEROCOPY") && atoi(getenv("FTK_PYRAMID_ZEROCOPY")) == 0);
+    const bool stage_allowed = !(FTK_ENV(ctx, pyramid_zerocopy) && atoi(FTK_ENV(ctx, pyramid_zerocopy)) == 0);
     if (!image_on_device && stage_allowed && n_levels >= 2 && ftk::pyramid_fused_enabled()) {
         rc = acquire_image_stage(ctx, (size_t)rows * cols, &stage);
         if (rc != FTK_OK) {
@@ -1015,7 +1069,7 @@ int ftk_pyramid_update(ftk_context *ctx, ftk_pyramid *pyr, const uint8_t *image,
     // the copy engine takes ~20 us per 300 KB frame, the kernel's own PCIe read a third of that, and a launch gap goes with it.
     // FTK_PYRAMID_ZEROCOPY=0 keeps the copy (experiment switch); pageable or unmapped memory takes it anyway.
     const uint8_t *direct_src = nullptr;
-    static const bool zero_copy_allowed = !(getenv("FTK_PYRAMID_ZEROCOPY") && atoi(getenv("FTK_PYRAMID_ZEROCOPY")) == 0);
+    const bool zero_copy_allowed = !(FTK_ENV(ctx, pyramid_zerocopy) && atoi(FTK_ENV(ctx, pyramid_zerocopy)) == 0);
     if (image_location == FTK_IMAGE_HOST_ASYNC && zero_copy_allowed && pyr->n_levels >= 2 && ftk::pyramid_fused_enabled()) {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, image) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr) {
@@ -1110,12 +1164,46 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
     if (!d_ref_uv || !d_cur_uv_in || !d_cur_uv_out || !d_status_in || !d_status_out) {
         return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track_device: null buffer");
     }
+    // The kernels read and write a feature's (u, v) as ONE 8-byte access (include/ftk.h: "8-byte aligned"): a pair array at an odd
+    // float offset — legal through round 3 — is refused here instead of becoming misaligned 64-bit accesses on the device.
+    if (((reinterpret_cast<uintptr_t>(d_ref_uv) | reinterpret_cast<uintptr_t>(d_cur_uv_in) | reinterpret_cast<uintptr_t>(d_cur_uv_out)) & 7u) != 0) {
+        return fail(ctx, FTK_E_INVALID_ARGUMENT, "klt_track_device: the (u, v) arrays must be 8-byte aligned (ref %p, in %p, out %p)", (const void *)d_ref_uv,
+                    (const void *)d_cur_uv_in, (const void *)d_cur_uv_out);
+    }
     ftk::KltParams p;
     const int rc = fill_klt_params(ctx, model, opt, ref, cur, n, prior, consider_luminance, single_level, &p);
     if (rc != FTK_OK) {
         return rc;
     }
     p.tree = (ctx->reduction == FTK_REDUCTION_TREE && !p.spill) ? 1 : 0;
+    {
+        // this launch's number, for the report of its longest feature (tail-aware wave policy, fill_klt_params)
+        if (!ctx->tail_host) {
+            void *host = nullptr;
+            if (hipHostMalloc(&host, 64, hipHostMallocDefault) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&ctx->tail_dev), 64) == hipSuccess) {
+                memset(host, 0, 64);
+                ctx->tail_host = static_cast<uint32_t *>(host);
+                (void)hipMemsetAsync(ctx->tail_dev, 0, 64, ctx->stream);
+            } else {
+                (void)hipGetLastError();
+                if (host) {
+                    (void)hipHostFree(host);
+                }
+            }
+        }
+        if (ctx->tail_host && ctx->tail_dev) {
+            ctx->tail_call = (ctx->tail_call + 1u) & 0xFFFFFFu;
+            if (ctx->tail_call == 0u) {
+                ctx->tail_call = 1u;  // (after 16 M launches the device word's running maximum starts over with the host's)
+                (void)hipMemsetAsync(ctx->tail_dev, 0, 64, ctx->stream);
+            }
+            const int mi = opt->method == FTK_METHOD_INVERSE ? 0 : (opt->method == FTK_METHOD_DIRECT ? 1 : 2);
+            ++ctx->tail[model][mi].launches;
+            p.tail_dev = ctx->tail_dev + (model * 3 + mi);    // a word per variant
+            p.tail_host = ctx->tail_host + (model * 3 + mi);  // (hipHostMalloc'ed memory is device-visible under the same address)
+            p.tail_call = ctx->tail_call;
+        }
+    }
     p.ref_uv = d_ref_uv;
     p.cur_uv_in = d_cur_uv_in;
     p.cur_uv_out = d_cur_uv_out;
@@ -1128,11 +1216,20 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
         // FTK_KLT_SPILL_BUDGET_MB), otherwise in batches of consecutive features — a feature's result does not depend on the others.
         const size_t per = sizeof(float) * (size_t)p.spill_stride_floats;
         size_t budget = (size_t)4096 << 20;
-        if (const char *env = getenv("FTK_KLT_SPILL_BUDGET_MB")) {
+        if (const char *env = FTK_ENV(ctx, klt_spill_budget_mb)) {
             budget = (size_t)(atoll(env) > 0 ? atoll(env) : 1) << 20;
         }
         size_t batch = budget / per;
         batch = batch < 1 ? 1 : (batch > (size_t)n ? (size_t)n : batch);
+        if (batch * per > ctx->klt_spill_bytes) {
+            // the slices would have to grow: a hipFree / hipMalloc (and a synchronisation) that a stream capture cannot contain
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+                return fail(ctx, FTK_E_UNSUPPORTED, "klt_track_device: a %d x %d patch needs %zu MB of device memory for its per-feature slices, which cannot be "
+                            "allocated while the stream is being captured: make one such call before the capture (the buffer is kept)", p.patch_rows, p.patch_cols,
+                            (batch * per) >> 20);
+            }
+        }
         const int rc_buf = ftk_ensure_device_buffer(ctx, &ctx->klt_spill, &ctx->klt_spill_bytes, batch * per);
         if (rc_buf != FTK_OK) {
             return rc_buf;
@@ -1168,7 +1265,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
         // run, and call k + 1 uses the result — so from the third call with the same feature count on, with a predictor two
         // calls old.  Which slot runs a feature changes nothing in its arithmetic.  Only for calls with more features than
         // fit the chip at once; FTK_KLT_SCHED=0 keeps list order.
-        static const bool sched_allowed = !(getenv("FTK_KLT_SCHED") && atoi(getenv("FTK_KLT_SCHED")) == 0);
+        const bool sched_allowed = !(FTK_ENV(ctx, klt_sched) && atoi(FTK_ENV(ctx, klt_sched)) == 0);
         if (sched_allowed && p.n_track >= kSchedMinFeatures && n <= kSchedMaxFeatures) {
             if ((size_t)n > ctx->sched_capacity) {
                 FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1216,7 +1313,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             // Position-keyed swaps ride on every such call, whatever the list did since the last one (FTK_KLT_SWAP=0: off).  Call
             // numbers start at 4 (an all-zero grid / claim word is never "recent") and tag 23 bits of a claim word: the claims are
             // wiped before a tag could repeat.
-            static const bool swap_allowed = !(getenv("FTK_KLT_SWAP") && atoi(getenv("FTK_KLT_SWAP")) == 0);
+            const bool swap_allowed = !(FTK_ENV(ctx, klt_swap) && atoi(FTK_ENV(ctx, klt_swap)) == 0);
             // (never inside a stream capture: a replayed launch would carry this call's number again and read its own old claims)
             hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) {
@@ -1265,7 +1362,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                 // stale entries, a write past order[n - 1].  Such a call gets the iteration-count / identity order instead.
                 p.sort_ref_uv = ref_untouched ? p.ref_uv : nullptr;
             }
-            static const int order_mode = getenv("FTK_KLT_ORDER") ? atoi(getenv("FTK_KLT_ORDER")) : -1;  // experiment: 0 = never, 1 = always
+            const int order_mode = FTK_ENV(ctx, klt_order) ? atoi(FTK_ENV(ctx, klt_order)) : -1;  // experiment: 0 = never, 1 = always
             const bool use_order = order_mode >= 0 ? order_mode != 0 : true;
             if (k >= 2 && use_order) {                        // made during the previous call from the counts before it
                 p.order = ctx->sched_order[k & 1];
@@ -1278,7 +1375,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                 // last call left at its features' positions — two small launches in front of the tracker's (klt_kernels.hip
                 // klt_position_order_launch; FTK_KLT_POSITION_ORDER=0: list order as before).  The buffer is the one an index-keyed
                 // order of this call would have used: nobody else writes it during this call.
-                static const bool position_order = !(getenv("FTK_KLT_POSITION_ORDER") && atoi(getenv("FTK_KLT_POSITION_ORDER")) == 0);
+                const bool position_order = !(FTK_ENV(ctx, klt_position_order) && atoi(FTK_ENV(ctx, klt_position_order)) == 0);
                 if (position_order) {
                     const uint32_t *last_table = ctx->sched_grid + (((ctx->sched_call - 1u) & 1u) << 16);
                     FTK_HIP(ctx, ftk::klt_position_order_launch(p.ref_uv, n, last_table, ctx->sched_call - 1u, ctx->sched_pred, ctx->sched_grid + kSchedTableWords,
@@ -1286,7 +1383,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                     p.order = ctx->sched_order[k & 1];
                 }
             }
-            if (const char *dump = getenv("FTK_KLT_SWAP_DUMP")) {  // diagnostic: how many trades the PREVIOUS launch of this context made
+            if (const char *dump = FTK_ENV(ctx, klt_swap_dump)) {  // diagnostic: how many trades the PREVIOUS launch of this context made
                 if (p.sched_claim != nullptr && ctx->sched_call > 5u) {
                     std::vector<uint32_t> h((size_t)n);
                     FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_claim, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1304,7 +1401,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
                     }
                 }
             }
-            if (const char *dump = getenv("FTK_KLT_SCHED_DUMP")) {  // diagnostic: the permutation in use and the counts it came from
+            if (const char *dump = FTK_ENV(ctx, klt_sched_dump)) {  // diagnostic: the permutation in use and the counts it came from
                 if (k >= 2) {
                     std::vector<int32_t> h((size_t)n * 2);
                     FTK_HIP(ctx, hipMemcpyAsync(h.data(), ctx->sched_order[k & 1], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1337,7 +1434,7 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
             fprintf(stderr, "[ftk stamps] memtime ticks/feature: ref_stage %.0f setup %.0f cur_stage %.0f phaseA %.0f count %.0f chain %.0f solve %.0f total %.0f\n",
                     avg[0] / n, avg[1] / n, avg[2] / n, avg[3] / n, avg[4] / n, avg[5] / n, avg[6] / n, avg[7] / n);
         }
-        if (const char *dump = getenv("FTK_STAMPS_DUMP")) {
+        if (const char *dump = FTK_ENV(ctx, stamps_dump)) {
             if (FILE *f = fopen(dump, "wb")) {
                 fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
                 fclose(f);
@@ -1423,7 +1520,7 @@ int ftk_klt_track(ftk_context *ctx, int model, const ftk_klt_options *opt, const
     // their queue latency, not by bytes: the kernel then reads (ref_uv, cur_uv, status) from and writes its 9 B per
     // feature straight into the pinned host block over PCIe — no H2D / D2H at all (2 000 features: 89 -> ~60 us per
     // call).  Larger calls keep the bulk copies.  FTK_KLT_ZEROCOPY=0 disables it.
-    static const bool zero_copy_allowed = !(getenv("FTK_KLT_ZEROCOPY") && atoi(getenv("FTK_KLT_ZEROCOPY")) == 0);
+    const bool zero_copy_allowed = !(FTK_ENV(ctx, klt_zerocopy) && atoi(FTK_ENV(ctx, klt_zerocopy)) == 0);
     void *mapped = nullptr;
     if (zero_copy_allowed && n <= 16384 && hipHostGetDevicePointer(&mapped, ctx->pinned, 0) == hipSuccess && mapped != nullptr) {
         uint8_t *mbase = static_cast<uint8_t *>(mapped);
@@ -1774,6 +1871,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     }
     ftk::MatchParams p;
     p.keys_clean = p_keys_clean;
+    p.small_off = ftk_env::off(FTK_ENV(ctx, match_small)) ? 1 : 0;
     p.ref_words = d_ref_words;
     p.cur_words = d_cur_words;
     p.pred_uv = d_pred_uv;
@@ -1792,10 +1890,10 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     // splits take 85 / 74 / 69 us; the scan is pure VALU work and small workgroups even out the tail.
     const int row_blocks = (n_ref + ftk::kMatchRowsPerBlock - 1) / ftk::kMatchRowsPerBlock;
     int splits = (4096 + row_blocks - 1) / row_blocks;
-    if (const char *env = getenv("FTK_MATCH_WGS")) {
+    if (const char *env = FTK_ENV(ctx, match_wgs)) {
         splits = (atoi(env) + row_blocks - 1) / row_blocks;  // experiment: target number of workgroups
     }
-    if (const char *env = getenv("FTK_MATCH_SPLITS")) {
+    if (const char *env = FTK_ENV(ctx, match_splits)) {
         splits = atoi(env);  // experiment override
     }
     const int max_splits = (n_cur + 63) / 64;
@@ -1806,7 +1904,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         splits = 1;
     }
     int per = (n_cur + splits - 1) / splits;
-    if (!(getenv("FTK_MATCH_ANY_PER") && atoi(getenv("FTK_MATCH_ANY_PER")) == 1)) {
+    if (!(FTK_ENV(ctx, match_any_per) && atoi(FTK_ENV(ctx, match_any_per)) == 1)) {
         per = (per + 63) / 64 * 64;
     }
     p.matrix_cores = 0;
@@ -1814,7 +1912,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         // Which scan: 256- and 512-bit descriptors go to the matrix cores (matcher_kernels.hip, hamming_match_mfma_kernel:
         // faster at every size measured, 300 x 300 to 10 000 x 10 000, scripts/match_shapes.py); other widths to the popcount
         // scan with the candidates on the scalar path.  FTK_MATCH_KERNEL=mfma|scalar|lds forces one (experiment switch).
-        const char *env = getenv("FTK_MATCH_KERNEL");
+        const char *env = FTK_ENV(ctx, match_kernel);
         p.lds_tiles = (env && !strcmp(env, "lds")) ? 1 : 0;
         // (the matrix-core scan addresses the candidates with 32-bit byte offsets)
         bool mfma = n_bits > 0 && (n_words == 8 || n_words == 16) && (long long)n_cur * n_words * 4 < (1ll << 31);
@@ -1827,7 +1925,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
             // (registers): one round of at most 2048 waves, the splits whole tiles and as even as the tile count allows.
             const int mfma_row_blocks = (n_ref + 63) / 64;
             int target = 2048;
-            if (const char *wgs = getenv("FTK_MATCH_WGS")) {
+            if (const char *wgs = FTK_ENV(ctx, match_wgs)) {
                 target = atoi(wgs);
             }
             int mfma_splits = target / mfma_row_blocks;
@@ -1844,7 +1942,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
     // NearbyMatch from a few thousand candidates on: bounding boxes for the early exit of workgroups whose candidates
     // cannot reach any window of their rows (matcher_kernels.hip)
     p.boxes = nullptr;
-    const bool boxes_off = getenv("FTK_MATCH_BOXES") && atoi(getenv("FTK_MATCH_BOXES")) == 0;  // experiment switch
+    const bool boxes_off = FTK_ENV(ctx, match_boxes) && atoi(FTK_ENV(ctx, match_boxes)) == 0;  // experiment switch
     if (d_pred_uv && n_bits > 0 && n_cur >= 2048 && !boxes_off) {
         const size_t n_boxes = (size_t)row_blocks + (size_t)((n_cur + per - 1) / per);
         const int rc = ensure_match_boxes(ctx, n_boxes);
@@ -1867,7 +1965,7 @@ int ftk_hamming_match_device(ftk_context *ctx, const uint32_t *d_ref_words, int3
         std::vector<unsigned long long> h(4 * n_wg);
         FTK_HIP(ctx, hipMemcpyAsync(h.data(), d_st, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
         FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (const char *dump = getenv("FTK_MATCH_STAMPS_DUMP")) {
+        if (const char *dump = FTK_ENV(ctx, match_stamps_dump)) {
             if (FILE *f = fopen(dump, "wb")) {
                 fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
                 fclose(f);
@@ -2119,21 +2217,53 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
     p.spread = 0;
     p.spread_ws = nullptr;
     p.spread_ws_words = 0;
+    p.spread_poison = ftk_env::on(FTK_ENV(ctx, direct_spread_poison)) ? 1 : 0;
+    ctx->direct_spread_launched = 0;
     {
-        const char *env = getenv("FTK_DIRECT_SPREAD");
+        const char *env = FTK_ENV(ctx, direct_spread);
         int producers = env ? atoi(env) : 32;
         producers = producers < 0 ? 0 : (producers > 200 ? 200 : producers);
-        if (n_problems > 1 && producers > 0) {
-            producers = std::min(producers, std::max(8, 224 / n_problems - 1));  // every workgroup of the launch resident at once, one per CU
-        }
         const long long terms = (long long)max_features * p.patch_rows * p.patch_cols;
         long long min_terms = 64ll * 256;  // below about 256 chunks the producers of one compute unit keep up with the chain
-        if (const char *min_env = getenv("FTK_DIRECT_SPREAD_MIN_TERMS")) {
+        if (const char *min_env = FTK_ENV(ctx, direct_spread_min_terms)) {
             min_terms = atoll(min_env);  // tests: spread even tiny problems (producers whose waves own no chunk)
         }
-        if (producers > 0 && n_problems <= 6 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global && max_features > 0 && terms >= min_terms &&
-            terms < (1ll << 31)) {
-            const size_t ws = align_up(ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols), 256);
+        bool spread = producers > 0 && !ctx->direct_spread_off && n_problems <= 6 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global &&
+                      max_features > 0 && terms >= min_terms && terms < (1ll << 31);
+        if (spread) {
+            // Every workgroup of the launch must be resident at once (consumer and producers wait for each other): size the producers from
+            // what THIS device holds — occupancy of the kernel as launched x its compute units (256 on a whole MI355X, 32 on a CPX partition),
+            // an eighth left free for whatever else runs — and keep the one-workgroup kernel when fewer than 1 + 8 fit per problem.
+            if (ctx->direct_spread_resident < 0 || ctx->direct_spread_resident_features != max_features) {
+                ctx->direct_spread_resident = ftk::direct_spread_resident_groups(max_features, ctx->device);
+                ctx->direct_spread_resident_features = max_features;
+            }
+            int resident = ctx->direct_spread_resident;
+            if (const char *cap_env = FTK_ENV(ctx, direct_spread_resident)) {
+                resident = std::min(resident, atoi(cap_env));  // tests: pretend to be a small partition
+            }
+            const int usable = resident - resident / 8;
+            const int fit = usable / n_problems - 1;
+            producers = std::min(producers, fit);
+            spread = producers >= 8 || (env && producers >= 1 && producers == std::min(atoi(env), fit));  // (an explicit FTK_DIRECT_SPREAD=n < 8 that fits is honoured: tests)
+        }
+        size_t ws = 0;
+        if (spread) {
+            // Workspace: [chunk][27][64] products per problem.  Not beyond 512 MB in total (127 x 127 patches x 768 features would be
+            // 1.3 GB per problem: such problems keep the one-workgroup kernel), word offsets must fit 32 bits, and a buffer that would have
+            // to GROW while the stream is being captured is an error the caller can act on, not a hipMalloc inside the capture.
+            ws = align_up(ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols), 256);
+            if (ws / sizeof(uint32_t) > 0xFFFFFFFFull || ws * (size_t)n_problems > (512ull << 20)) {
+                spread = false;
+            }
+        }
+        if (spread && ws * (size_t)n_problems > ctx->direct_spread_bytes) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+                spread = false;  // the one-workgroup kernel needs no workspace: same result, capturable
+            }
+        }
+        if (spread) {
             const int rc = ensure_device_buffer(ctx, &ctx->direct_spread, &ctx->direct_spread_bytes, ws * (size_t)n_problems);
             if (rc != FTK_OK) {
                 return rc;
@@ -2145,6 +2275,8 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
             p.spread = producers;
             p.spread_ws = static_cast<uint32_t *>(ctx->direct_spread);
             p.spread_ws_words = (uint32_t)(ws / sizeof(uint32_t));
+            ctx->direct_spread_launched = n_problems;
+            ctx->direct_spread_stride = ws;
         }
     }
     FTK_HIP(ctx, ftk::direct_track_launch(p, n_problems, feat_in_global ? 0u : max_features, ctx->stream));
@@ -2210,6 +2342,36 @@ int ftk_direct_track(ftk_context *ctx, const ftk_direct_options *opt, const ftk_
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
+    if (ctx->direct_spread_launched > 0) {
+        // The spread kernel's bounded waits ran out (its 1 + NP workgroups were not co-resident: a CU mask, a partition smaller than the
+        // runtime reported, long kernels of other streams): header word 1 is set and the pose is NaN.  A synchronous caller must never
+        // get that with FTK_OK — run the problem again on the one-workgroup kernel (same sums, same result as a good spread launch).
+        uint32_t poisoned = 0;
+        FTK_HIP(ctx, hipMemcpyAsync(&poisoned, static_cast<uint32_t *>(ctx->direct_spread) + 1, sizeof(poisoned), hipMemcpyDeviceToHost, ctx->stream));
+        FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (poisoned != 0) {
+            FTK_HIP(ctx, hipMemcpyAsync(d_cur, cur_uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            FTK_HIP(ctx, hipMemcpyAsync(d_st, status, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            for (int i = 0; i < 4; ++i) {
+                pose[i] = q_rc_wxyz[i];
+            }
+            for (int i = 0; i < 3; ++i) {
+                pose[4 + i] = p_rc[i];
+            }
+            FTK_HIP(ctx, hipMemcpyAsync(d_pose, pose, sizeof(pose), hipMemcpyHostToDevice, ctx->stream));
+            FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->direct_spread_off = true;
+            rc = ftk_direct_track_batch_device(ctx, opt, &prob, 1);
+            ctx->direct_spread_off = false;
+            if (rc != FTK_OK) {
+                (void)hipStreamSynchronize(ctx->stream);
+                return rc;
+            }
+            ++ctx->direct_spread_reruns;
+            // not a failure — the result below is the one-workgroup kernel's — but worth telling: ftk_last_error() carries the note
+            ctx->error = "note: ftk_direct_track: the spread launch was not co-resident (its bounded waits ran out); the problem was re-run on one workgroup";
+        }
+    }
     uint32_t it = 0;
     FTK_HIP(ctx, hipMemcpyAsync(cur_uv, d_cur, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     FTK_HIP(ctx, hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -2251,6 +2413,8 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     }
     FTK_HIP(ctx, hipSetDevice(ctx->device));
     ftk::CosineParams p;
+    p.small_off = ftk_env::off(FTK_ENV(ctx, cosine_small)) ? 1 : 0;
+    p.small_any = ftk_env::on(FTK_ENV(ctx, cosine_small_any)) ? 1 : 0;
     p.ref = d_ref_desc;
     p.cur = d_cur_desc;
     p.pred_uv = d_pred_uv;
@@ -2265,8 +2429,8 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     // dim <= 256 (SuperPoint, DISK): the ref fragments stay on chip for the whole walk over cur — in registers
     // (cosine_gemm_rr_kernel, 512 ref rows per workgroup; the default) or in LDS (cosine_gemm_rs_kernel, 128 rows;
     // FTK_COSINE_KERNEL=rs).  Longer descriptors, or FTK_COSINE_KERNEL=chunked, use the chunked kernel.
-    const char *kernel_env = getenv("FTK_COSINE_KERNEL");
-    const bool want_chunked = (kernel_env && !strcmp(kernel_env, "chunked")) || (getenv("FTK_COSINE_CHUNKED") && atoi(getenv("FTK_COSINE_CHUNKED")) == 1);
+    const char *kernel_env = FTK_ENV(ctx, cosine_kernel);
+    const bool want_chunked = (kernel_env && !strcmp(kernel_env, "chunked")) || (FTK_ENV(ctx, cosine_chunked) && atoi(FTK_ENV(ctx, cosine_chunked)) == 1);
     p.ref_stationary = (p.dim_pad <= 256 && !want_chunked) ? ((kernel_env && !strcmp(kernel_env, "rs")) ? 1 : 2) : 0;
     const int cur_tile = p.ref_stationary == 2 ? 64 : (p.ref_stationary == 1 ? 256 : 128);
     const int row_group = p.ref_stationary == 2 ? 512 : 128;
@@ -2280,11 +2444,11 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     // than slightly longer runs.
     const int row_tiles = p.n_ref_pad / row_group, tiles_total = p.n_cur_pad / cur_tile;
     int splits = (p.ref_stationary ? 256 : 512) / row_tiles;
-    if (const char *env = getenv("FTK_COSINE_SPLITS")) {
+    if (const char *env = FTK_ENV(ctx, cosine_splits)) {
         splits = atoi(env);  // experiment override
     }
     splits = std::max(1, std::min(splits, tiles_total));
-    if (p.ref_stationary == 2 && !getenv("FTK_COSINE_SPLITS")) {
+    if (p.ref_stationary == 2 && !FTK_ENV(ctx, cosine_splits)) {
         // At least TWO tiles per split: a walk's first step has no running maximum to cut against yet, so it lists its whole share
         // of every row; with one-tile splits that is all there is, the rows' lists overflow (kCosineCandCap) and the recheck falls
         // back to the exact scan of every pair — 2 000 x 2 000 x 256: 32 splits 17.6 + 3 591 us (contraction + recheck), 16 splits
@@ -2317,7 +2481,7 @@ int ftk_cosine_match_device(ftk_context *ctx, const float *d_ref_desc, int32_t n
     // the on-chip-ref kernels walk cur ONCE (running row maximum + scored candidate lists); FTK_COSINE_TWO_PASS=1 with
     // FTK_COSINE_KERNEL=rs keeps the maximum-then-collect pair of launches for comparison
     const bool single_walk =
-        p.ref_stationary == 2 || (p.ref_stationary == 1 && !(getenv("FTK_COSINE_TWO_PASS") && atoi(getenv("FTK_COSINE_TWO_PASS")) == 1));
+        p.ref_stationary == 2 || (p.ref_stationary == 1 && !(FTK_ENV(ctx, cosine_two_pass) && atoi(FTK_ENV(ctx, cosine_two_pass)) == 1));
     const size_t o_cand_score = single_walk ? carve(sizeof(float) * (size_t)p.n_ref_pad * ftk::kCosineCandCap) : 0;
     const size_t o_irr_list = carve(sizeof(int32_t) * ftk::kCosineIrregularCap);
     const int rc = ensure_cosine_ws(ctx, off);

@@ -40,6 +40,11 @@ struct KltParams {
     uint32_t *sched_claim;
     uint32_t *sched_flags;  // [2]: (call number << 1 | "the counts that call sorted had no tail"), written by the sort block of a launch
     uint32_t sched_call;
+    // the call's longest feature, reported for the next call's wave policy (klt_common.h tail_report; null: not reported)
+    uint32_t *tail_dev;
+    uint32_t *tail_host;
+    uint32_t tail_call;
+    int32_t long_tail;          // host-side note: this variant's recent calls had a feature of many iterations (ftk_api.cpp, tail-aware policy)
     const uint32_t *sort_iters;  // may be null: the previous call's counts; one extra workgroup (block 0) sorts them ...
     int32_t *sort_order_out;     // ... into this permutation, longest first (klt_common.h, klt_order_block)
     const float *sort_ref_uv;    // reference positions the sort block may use for the spatial (tile) order: ref_uv, or null when this
@@ -53,7 +58,7 @@ struct KltParams {
     float prior[4];
     int32_t consider_luminance;
     // derived patch geometry
-    int32_t patch_rows, patch_cols, P, Ppad;  // Ppad = P rounded up to a multiple of 4
+    int32_t patch_rows, patch_cols, P, Ppad;  // Ppad = P rounded up to a multiple of 16
     int32_t ex_rows, ex_cols, E;
     int32_t a0_floats;  // size of the first LDS array: max(E padded, axis tables)
     uint32_t magic_pc;   // ceil(2^32 / patch_cols): row = umulhi(p, magic_pc)
@@ -66,6 +71,9 @@ struct KltParams {
     uint32_t magic_rwq, magic_cwq;  // division by window cols / 4
     int32_t waves_per_feature;  // workgroup = 64 * waves_per_feature lanes
     int32_t px_floats;          // per-pixel floats behind a0 in the generic kernel's LDS carve: 3, 4 (one float4 record: non-fast affine) or 6 (chunked LSSD)
+    int32_t quad_chain;         // chunked one-wave LSSD levels: 1 = the exact-order sums through the DPP network (klt_common.h "quad chain": fewer
+                                // instructions on a lone feature's critical path), 0 = one lane per sum (fewer LDS bytes and plain adds: better when
+                                // the launch oversubscribes the chip — config 4: 136 against 141 us, with luminance 255 against 285)
     int32_t terms_floats;       // floats of the generic kernel's `terms` LDS region: K * Ppad, or the 64-pixel ring of a chunked variant
     int32_t lssd_chunked;       // LSSD fast, one wave per feature, no luminance scaling: chunked sweep / chain (klt_kernels.hip)
     int32_t features_per_group; // > 1 (only with waves_per_feature == 1): that many one-wave features share a workgroup, without
@@ -99,7 +107,7 @@ __host__ __device__ constexpr void klt_fill_geometry(KltParams &p) {
     p.patch_rows = 2 * p.half_rows + 1;
     p.patch_cols = 2 * p.half_cols + 1;
     p.P = p.patch_rows * p.patch_cols;
-    p.Ppad = (p.P + 3) & ~3;
+    p.Ppad = (p.P + 15) & ~15;  // (a multiple of 16 since round 5: the quad chains add 16 terms per step, klt_common.h; the padding holds exact zeros)
     p.ex_rows = p.patch_rows + 2;
     p.ex_cols = p.patch_cols + 2;
     p.E = p.ex_rows * p.ex_cols;
@@ -179,10 +187,11 @@ struct MatchParams {
     int32_t lds_tiles;      // experiment (FTK_MATCH_KERNEL=lds): candidates staged through LDS tiles instead of the scalar path
     float4 *boxes;          // NearbyMatch, optional: ceil(n_ref / 512) prediction boxes, then one candidate box per split
                             // ({u min, u max, v min, v max}; hamming_box_kernel fills them, the scan leaves early on them)
+    int32_t small_off;      // experiment (FTK_MATCH_SMALL=0, read once per context): never the one-launch form
 };
 hipError_t match_launch(const MatchParams &p, hipStream_t stream);
 // Whether match_launch runs a call of this shape as ONE launch without the keys workspace or the NearbyMatch boxes (small calls).
-bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits);
+bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits, bool small_off);
 
 // Float-descriptor (cosine distance) matcher: float_matcher_kernels.hip.
 constexpr int kCosineCandCap = 64;       // candidates kept per ref row before the row falls back to the exact scan
@@ -212,12 +221,13 @@ struct CosineParams {
                               // 1: cosine_gemm_rs_kernel (ref rows in LDS; n_cur_pad % 256 == 0, tiles_per_split)
     int32_t splits;
     float max_distance, max_col, max_row;
+    int32_t small_off, small_any;  // experiments (FTK_COSINE_SMALL=0 / FTK_COSINE_SMALL_ANY=1, read once per context)
 };
 size_t cosine_rs_lds_bytes(int dim_pad);
 size_t cosine_rr_lds_bytes(int dim_pad);
 hipError_t cosine_match_launch(const CosineParams &p, hipStream_t stream);
 // Whether cosine_match_launch runs a call of this shape as one exact launch without the workspace (small calls).
-bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby);
+bool cosine_small_form(int n_ref, int n_cur, int dim, bool nearby, bool small_off, bool small_any);
 
 // DirectMethod (direct_kernels.hip): one workgroup per pose problem; all problems of a launch share
 // the pyramid depth and the options.
@@ -253,10 +263,13 @@ struct DirectParams {
     int32_t spread;
     uint32_t *spread_ws;
     uint32_t spread_ws_words;  // words between the workspaces of consecutive problems
+    int32_t spread_poison;     // tests only (FTK_DIRECT_SPREAD_POISON=1): the consumer behaves as if its first wait had run out — the
+                               // launch ends at once with header word 1 set and a NaN pose, as a launch that was not co-resident would
 };
 size_t direct_lds_bytes(uint32_t max_features);
 size_t direct_spread_ws_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols);
 size_t direct_spread_clear_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols);
+int direct_spread_resident_groups(uint32_t max_features, int device);  // workgroups of the spread kernel the device holds at once (0: unknown)
 hipError_t direct_track_launch(const DirectParams &p, int n_problems, uint32_t max_features, hipStream_t stream);
 
 struct BriefParams {

@@ -13,6 +13,48 @@
 
 using ftk::DevImage;
 
+// The FTK_* experiment switches of the library, read ONCE per context (ftk_context_create; ftk_context_refresh_env re-reads them for
+// a test or a sweep that flips one): no getenv on any call path.  None of them changes a result — they pick launch shapes and kernels.
+#define FTK_ENV_SWITCHES(X)                                                                                                        \
+    X(klt_waves, "FTK_KLT_WAVES") X(klt_group, "FTK_KLT_GROUP") X(klt_pipelined, "FTK_KLT_PIPELINED") X(klt_fast_kernel, "FTK_KLT_FAST_KERNEL") \
+    X(lssd_chunked, "FTK_LSSD_CHUNKED") X(klt_spill, "FTK_KLT_SPILL") X(klt_spill_budget_mb, "FTK_KLT_SPILL_BUDGET_MB") X(klt_sched, "FTK_KLT_SCHED") \
+    X(klt_swap, "FTK_KLT_SWAP") X(klt_order, "FTK_KLT_ORDER") X(klt_position_order, "FTK_KLT_POSITION_ORDER") X(klt_swap_dump, "FTK_KLT_SWAP_DUMP") \
+    X(klt_sched_dump, "FTK_KLT_SCHED_DUMP") X(stamps_dump, "FTK_STAMPS_DUMP") X(klt_zerocopy, "FTK_KLT_ZEROCOPY") X(pyramid_zerocopy, "FTK_PYRAMID_ZEROCOPY") \
+    X(match_wgs, "FTK_MATCH_WGS") X(match_splits, "FTK_MATCH_SPLITS") X(match_any_per, "FTK_MATCH_ANY_PER") X(match_kernel, "FTK_MATCH_KERNEL") \
+    X(match_boxes, "FTK_MATCH_BOXES") X(match_stamps_dump, "FTK_MATCH_STAMPS_DUMP") X(match_small, "FTK_MATCH_SMALL") \
+    X(direct_spread, "FTK_DIRECT_SPREAD") X(direct_spread_min_terms, "FTK_DIRECT_SPREAD_MIN_TERMS") X(direct_spread_resident, "FTK_DIRECT_SPREAD_RESIDENT") X(direct_spread_poison, "FTK_DIRECT_SPREAD_POISON") \
+    X(cosine_kernel, "FTK_COSINE_KERNEL") X(cosine_chunked, "FTK_COSINE_CHUNKED") X(cosine_splits, "FTK_COSINE_SPLITS") X(cosine_two_pass, "FTK_COSINE_TWO_PASS") \
+    X(cosine_small, "FTK_COSINE_SMALL") X(cosine_small_any, "FTK_COSINE_SMALL_ANY") X(reduction, "FTK_REDUCTION") X(klt_policy, "FTK_KLT_POLICY") X(klt_quad, "FTK_KLT_QUAD") X(klt_tail, "FTK_KLT_TAIL")
+
+struct ftk_env {
+#define X(field, name) const char *field = nullptr;
+    FTK_ENV_SWITCHES(X)
+#undef X
+    enum { kCount = 0
+#define X(field, name) +1
+    FTK_ENV_SWITCHES(X)
+#undef X
+    };
+    std::string keep[kCount];  // the values' storage: the environment may change under a pointer getenv returned
+    void read() {
+        int k = 0;
+#define X(field, name)                     \
+    if (const char *v = getenv(name)) {    \
+        keep[k] = v;                       \
+        field = keep[k].c_str();           \
+    } else {                               \
+        field = nullptr;                   \
+    }                                      \
+    ++k;
+        FTK_ENV_SWITCHES(X)
+#undef X
+    }
+    static bool off(const char *v) { return v && atoi(v) == 0; }  // "FTK_X=0" switches a default-on feature off
+    static bool on(const char *v) { return v && atoi(v) != 0; }
+};
+
+#define FTK_ENV(ctx, field) ((ctx) ? (ctx)->env.field : nullptr)
+
 struct ftk_context {
     // Every entry point that takes a context holds this lock for its whole duration: the scratch / pinned / workspace
     // buffers below are reused (and regrown) by every call, so calls on ONE context from several threads — e.g. the
@@ -23,6 +65,7 @@ struct ftk_context {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string error;
+    ftk_env env;  // the experiment switches as they were when the context was made (or last refreshed)
     // cached device scratch for the host-buffer entry points
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -53,6 +96,17 @@ struct ftk_context {
     size_t sched_capacity = 0;   // features each buffer holds
     int32_t sched_n = 0;         // feature count of the calls counted in sched_calls
     uint32_t sched_calls = 0;    // consecutive calls with that feature count so far
+    // Tail-aware wave policy (round 5): the trackers' kernels report the iteration count of a call's LONGEST feature (features below
+    // kTailReportFrom stay silent) into a device word per variant (atomicMax) whose raisers forward it to `tail_host`, device-visible host words
+    // a later call's policy reads without any synchronisation: {call number << 8 | iterations}; feature 0 always reports, so every launch refreshes its word.  A heuristic input, never a result.
+    uint32_t *tail_host = nullptr;
+    uint32_t *tail_dev = nullptr;
+    uint32_t tail_call = 0;                 // tracker launches of this context so far (tags the reports)
+    struct TailState {
+        uint32_t launches = 0;              // launches of this variant so far
+        uint32_t long_until = 0;            // "this variant's calls have a long tail" while launches < long_until
+        uint32_t longest = 0;               // the last long report's iteration count
+    } tail[3][3];                           // [model][inverse, direct, fast]
     void *match_pad = nullptr;
     size_t match_pad_bytes = 0;
     // per-workgroup slices of the trackers' large-patch form (ftk_device.h KltParams::spill)
@@ -61,6 +115,12 @@ struct ftk_context {
     // hand-off workspace of the spread direct-method kernel (header, chunk flags, products)
     void *direct_spread = nullptr;
     size_t direct_spread_bytes = 0;
+    int direct_spread_resident = -1;            // workgroups of the spread kernel this device holds at once (-1: not asked yet)
+    uint32_t direct_spread_resident_features = 0;
+    int direct_spread_launched = 0;             // problems the LAST ftk_direct_track_batch_device call spread over the chip (0: one workgroup each)
+    size_t direct_spread_stride = 0;            // bytes of workspace per problem of that launch (header word 1 != 0: its waits ran out)
+    bool direct_spread_off = false;             // set around the re-run of a poisoned spread launch
+    uint32_t direct_spread_reruns = 0;          // such re-runs so far (tests)
     // pinned host staging for the host-buffer entry points (one H2D + one D2H per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

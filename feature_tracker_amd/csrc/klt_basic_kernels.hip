@@ -32,6 +32,9 @@
 //
 // Arithmetic contract as in klt_kernels.hip: IEEE fp32, no contraction, correctly rounded division.
 #define FTK_CHAIN_ROUND 4  // 16 terms per round: the consumer wave holds 32 VGPRs of prefetched terms
+#ifndef FTK_PB_QUAD_CHAIN
+#define FTK_PB_QUAD_CHAIN 1  // the exact-order chain through the DPP network (klt_common.h chain_quads_left); 0: one lane per sum (round 4)
+#endif
 #include "klt_common.h"
 
 #include <stdlib.h>
@@ -42,7 +45,12 @@ namespace {
 constexpr int kChunk = 64;  // pixels per chunk = one producer wave round
 // Ring rows are kChunk + 4 floats apart: the consumer's lanes read 16 bytes each from DIFFERENT rows
 // at the same column, and a row pitch of 256 B would put all of them on the same four banks.
-constexpr int kRingRow = kChunk + 4;
+#ifndef FTK_PB_RING_PAD
+#define FTK_PB_RING_PAD 16
+#endif
+// (round 5: the quad chain reads 16 bytes per lane, the four lanes of a quad 64 consecutive bytes of ONE row; a pitch of 80 floats puts
+// the rows of the two quads of an 8-lane group on the two halves of the banks.  Its quads follow klt_common.h chain_quads_left.)
+constexpr int kRingRow = kChunk + FTK_PB_RING_PAD;
 constexpr int kTerms = 5;   // 0 H00, 1 H11, 2 H01, 3 -fx*ft, 4 -fy*ft (basic_klt.cpp:139-144)
 constexpr int kCurQuads = 4;  // 8-byte window loads a thread may hold in flight (current window)
 constexpr int kRefQuads = 3;  // ... (next level's reference window)
@@ -648,6 +656,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                         }
                     }
                     pb_sync(solo);
+#if FTK_PB_QUAD_CHAIN
+                    if (consumer) {
+                        // the whole wave: quad k = lanes 4 k .. 4 k + 3 carries sum k (klt_common.h, "quad chain"); the quads behind the
+                        // fifth follow its rows and are ignored
+                        const int sum = min(b.lane >> 2, kTerms - 1);
+                        for (int q = 0; q < np; ++q) {
+                            if (s * np + q < n_chunks) {
+                                acc = chain_quads_left(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + sum) * kRingRow + 4 * (b.lane & 3), p.P - (s * np + q) * kChunk);
+                            }
+                        }
+                    }
+#else
                     if (consumer && b.lane < kTerms) {
                         for (int q = 0; q < np; ++q) {
                             if (s * np + q < n_chunks) {
@@ -655,6 +675,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                             }
                         }
                     }
+#endif
                 }
     #ifndef FTK_STAMPS_FINE
                 FTK_STAMP_END(b, 3);
@@ -662,11 +683,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                 if (consumer) {
                     float m[2][2], bb[2], sol[2];
                     const int acc_bits = __float_as_int(acc);
+                    constexpr int kSumLanes = FTK_PB_QUAD_CHAIN ? 4 : 1;  // sum k ends in lane 4 k (every lane of its quad) / in lane k
                     m[0][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0));
-                    m[1][1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
-                    m[0][1] = m[1][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2));
-                    bb[0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
-                    bb[1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4));
+                    m[1][1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1 * kSumLanes));
+                    m[0][1] = m[1][0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2 * kSumLanes));
+                    bb[0] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3 * kSumLanes));
+                    bb[1] = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4 * kSumLanes));
                     ldlt_solve<2>(m, bb, sol);  // basic_klt.cpp:97
                     if (b.lane == 0) {
                         c.sol[0] = sol[0];
@@ -725,6 +747,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (p.iters) {
             p.iters[id] = iters;
         }
+        tail_report(p, iters, id);  // the longest feature of the call, for the next call's wave policy
         sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)

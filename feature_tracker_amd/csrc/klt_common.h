@@ -986,6 +986,96 @@ __device__ __forceinline__ float chain_chunk_left(float acc, const float *row, i
 #endif
 
 
+// ---------------------------------------------------------------------------------------------
+// The exact-order chain through the DPP network ("quad chain", round 5).
+//
+// chain_chunk above gives every sum ONE lane, which reads 4 of its terms per ds_read_b128 and adds them: one read instruction per
+// 4 terms — and a lone wave issues one instruction of ANY kind per 4 cycles and pays 9 - 14 for an LDS read, so a term costs 8.5 - 10.7
+// cycles although the dependent add itself needs 4 (scripts/microbench/dpp_quad_chain.hip, V0).  Here every sum has a QUAD of lanes,
+// all four holding the same running value: lane i of quad q reads the float4 at terms 16 j + 4 i of sum q, so ONE ds_read_b128 brings
+// 16 consecutive terms of up to 16 sums into the wave, and sixteen `v_add_f32_dpp acc, T, acc quad_perm:[i,i,i,i]` add them in
+// order — quad lane 0's x, y, z, w, then lane 1's, ... — the DPP network broadcasting lane i's register to its quad.  The same
+// IEEE adds in the same order (the DPP operand is the TERM; the accumulator is the plain src1, forwarded from the add before:
+// no wait state, 64 000 random sums of 448 terms bit-identical), 4.84 cycles per term from registers, 6.6 with a chunk's four reads
+// issued up front (V2 / V4 of the microbenchmark) against 10.7.  The loads are ordinary C++ loads (the compiler places their waits);
+// the adds are one asm block per 16 terms.  Every lane of the wave must be active (EXEC all ones: no VALU write of EXEC in front of
+// a DPP instruction); quads beyond the last sum follow any valid row and their results are ignored.
+// ---------------------------------------------------------------------------------------------
+#define FTK_QADD(i, reg) "v_add_f32_dpp %0, " reg ", %0 quad_perm:[" #i "," #i "," #i "," #i "] row_mask:0xf bank_mask:0xf\n"
+#define FTK_QADD4(i) FTK_QADD(i, "%1") FTK_QADD(i, "%2") FTK_QADD(i, "%3") FTK_QADD(i, "%4")
+// acc += the quad's 16 terms in order.  `s_nop 1`: should the compiler have MOVED a term register with a VALU instruction right in
+// front of this block, the two wait states a DPP operand needs after a VALU write are there (it cannot see the DPP in the asm).
+__device__ __forceinline__ float chain_quad_step16(float acc, const float4 q) {
+    asm volatile("s_nop 1\n" FTK_QADD4(0) FTK_QADD4(1) FTK_QADD4(2) FTK_QADD4(3) : "+v"(acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+    return acc;
+}
+
+// One chunk row of up to 64 terms: `quad_row` = the row of THIS lane's quad's sum + 4 * (lane & 3) floats (16-byte aligned);
+// `left` = terms that count (wave-uniform, >= 1; anything >= 64 is a full chunk); terms up to the next multiple of 16 are read and
+// added, so they must be exact zeros (x + (+-0) == x for every value a sum can hold: the sums start at +0).  All four reads of the
+// chunk are issued first; each 16-add block waits only for its own.
+__device__ __forceinline__ float chain_quads_left(float acc, const float *quad_row, int left) {
+    const float4 *t = reinterpret_cast<const float4 *>(quad_row);
+    const float4 q0 = t[0];
+    if (left > 48) {
+        const float4 q1 = t[4], q2 = t[8], q3 = t[12];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, q0);
+        acc = chain_quad_step16(acc, q1);
+        acc = chain_quad_step16(acc, q2);
+        return chain_quad_step16(acc, q3);
+    }
+    if (left > 32) {
+        const float4 q1 = t[4], q2 = t[8];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, q0);
+        acc = chain_quad_step16(acc, q1);
+        return chain_quad_step16(acc, q2);
+    }
+    if (left > 16) {
+        const float4 q1 = t[4];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, q0);
+        return chain_quad_step16(acc, q1);
+    }
+    return chain_quad_step16(acc, q0);
+}
+
+// A whole row of `n16` 16-term steps (n16 >= 1, wave-uniform): two register pairs, the reads two steps ahead of the adds.
+__device__ __forceinline__ float chain_quads_row(float acc, const float *quad_row, int n16) {
+    const float4 *t = reinterpret_cast<const float4 *>(quad_row);
+    float4 qa = t[0], qb = t[n16 > 1 ? 4 : 0], qc, qd;
+    int j = 0;
+#pragma nounroll
+    for (; j + 4 <= n16; j += 4) {
+        qc = t[(j + 2) * 4];
+        qd = t[(j + 3) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, qa);
+        acc = chain_quad_step16(acc, qb);
+        qa = t[(j + 4 < n16 ? j + 4 : 0) * 4];  // (wave-uniform selects; a read past the row's end is never made)
+        qb = t[(j + 5 < n16 ? j + 5 : 0) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, qc);
+        acc = chain_quad_step16(acc, qd);
+    }
+    const int rem = n16 - j;  // 0 .. 3 steps left; qa / qb hold the first two
+    if (rem > 2) {
+        qc = t[(j + 2) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rem > 0) {
+        acc = chain_quad_step16(acc, qa);
+    }
+    if (rem > 1) {
+        acc = chain_quad_step16(acc, qb);
+    }
+    if (rem > 2) {
+        acc = chain_quad_step16(acc, qc);
+    }
+    return acc;
+}
+
 constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked sweep / chain loops = one wave round
 constexpr int kChunkRow = kChunkPixels + 4;   // ring row pitch in floats: the chain lanes' 16-byte reads of different rows hit different banks
 
@@ -1233,6 +1323,22 @@ __device__ __forceinline__ void sched_grid_record(const KltParams &p, float ref_
         atomicMax(&table[at_ref], word);
         if (at_out != at_ref) {
             atomicMax(&table[at_out], word);
+        }
+    }
+}
+
+// The iteration count of a call's longest feature, for the NEXT call's wave policy (ftk_api.cpp "tail-aware"): features that ran at
+// least kTailReportFrom iterations raise a device word with atomicMax — an L2 load for most, an atomic for the few that raise it —
+// and whoever raised it forwards the new value to a device-visible host word with one system-scope store.  A lower value may land
+// after a higher one (two raisers racing over PCIe): the host treats the word as a hint.  One lane per feature calls this.
+constexpr uint32_t kTailReportFrom = 12;
+__device__ __forceinline__ void tail_report(const KltParams &p, uint32_t iters, uint32_t id) {
+    if (p.tail_dev != nullptr && (iters >= kTailReportFrom || id == 0u)) {  // (feature 0 always: every launch refreshes the variant's word)
+        const uint32_t word = (p.tail_call << 8) | (iters < 255u ? iters : 255u);
+        if (word > __hip_atomic_load(p.tail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (atomicMax(p.tail_dev, word) < word) {
+                __hip_atomic_store(p.tail_host, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

@@ -26,6 +26,9 @@
 // Arithmetic contract as in klt_kernels.hip: IEEE fp32, no contraction, correctly rounded division, every sum strictly in
 // row-major pixel order on one lane.  Results are bit-identical to the generic kernel and to the oracle (tests/test_klt_gpu.py).
 #define FTK_CHAIN_ROUND 4
+#ifndef FTK_FK_QUAD_CHAIN
+#define FTK_FK_QUAD_CHAIN 1  // the whole-row exact-order chains through the DPP network (klt_common.h "quad chain"); 0: one lane per sum (round 4)
+#endif
 #include "klt_common.h"
 
 #include <stdlib.h>
@@ -41,7 +44,15 @@ constexpr int kFkTerms = 5;  // rows of `terms`: 0 -(dx * dt), 1 -(dy * dt) (eve
 __host__ __device__ inline int fk_pad4(int x) { return (x + 3) & ~3; }
 // Row pitch of `terms` in floats: congruent 4 mod 8, so that the 16-byte reads of the five chain lanes (one row each, same column)
 // fall on five different groups of four banks
-__host__ __device__ inline int fk_term_pitch(const KltParams &p) { return (p.Ppad & 7) == 4 ? p.Ppad : p.Ppad + 4; }
+// (round 5, quad chains: the four lanes of a quad read 64 consecutive bytes of ONE row and the two quads of an 8-lane group two
+// different rows — a pitch congruent 16 mod 32 floats puts those on the two halves of the banks)
+__host__ __device__ inline int fk_term_pitch(const KltParams &p) {
+#if FTK_FK_QUAD_CHAIN
+    return (p.Ppad & 31) == 16 ? p.Ppad : p.Ppad + 16;
+#else
+    return (p.Ppad & 7) == 4 ? p.Ppad : p.Ppad + 4;
+#endif
+}
 
 constexpr int kAfRows = 24;     // rows of the affine ring: 0 - 5 the bias products (every iteration), 6 + A_* the 18 Hessian products (first iteration)
 constexpr int kAfSumFloats = 56;  // [0, 36) the dense 6 x 6 Hessian the factorisation reads, [40, 46) the bias sums, [48, 54) the solution
@@ -526,17 +537,24 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     // the exact-order sums: lanes 0 / 1 the bias, and in the level's first iteration lanes 2 - 4 the Hessian
                     const int chains = iter == 0 ? kFkTerms : 2;
                     float acc = 0.0f;
+#if FTK_FK_QUAD_CHAIN
+                    // every lane: quad q carries sum q (klt_common.h "quad chain"); the quads behind the last sum follow its row, ignored
+                    constexpr int kSumLanes = 4;
+                    acc = chain_quads_row(0.0f, c.terms + min(lane >> 2, chains - 1) * pitch + 4 * (lane & 3), p.Ppad >> 4);
+#else
+                    constexpr int kSumLanes = 1;
                     if (lane < chains) {
                         acc = chain_lane(c.terms + lane * pitch, p.Ppad);
                     }
+#endif
                     const int acc_bits = __float_as_int(acc);
                     FTK_STAMP_END(b, 5);
                     if (iter == 0) {
-                        fac = ldlt2_factor(__int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3)),
-                                           __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)));
+                        fac = ldlt2_factor(__int_as_float(__builtin_amdgcn_readlane(acc_bits, 2 * kSumLanes)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3 * kSumLanes)),
+                                           __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4 * kSumLanes)));
                     }
                     float v0, v1;
-                    ldlt2_apply(fac, __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1)), v0, v1, lane);  // basic_klt_fast.cpp:44
+                    ldlt2_apply(fac, __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1 * kSumLanes)), v0, v1, lane);  // basic_klt_fast.cpp:44
                     if (isnan(v0) || isnan(v1)) {
                         status = FTK_NUMERIC_ERROR;
                         break;
@@ -710,9 +728,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                         }
                         fk_fence();
                         FTK_STAMP_END(b, 3);
+#if FTK_FK_QUAD_CHAIN
+                        acc = chain_quads_row(0.0f, c.terms + imul(min(lane >> 2, 5), pitch) + 4 * (lane & 3), p.Ppad >> 4);  // quad q carries bias sum q
+#else
                         if (lane < 6) {
                             acc = chain_lane(c.terms + imul(lane, pitch), p.Ppad);
                         }
+#endif
                         fk_fence();
                     }
                     FTK_STAMP_END(b, 5);
@@ -747,9 +769,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     }
                     // (the substitutions with L broadcast into wave-uniform registers — ~130 straight-line instructions instead of ~290
                     // with a cross-lane broadcast per term — were built and measured: 0.08 us per iteration SLOWER; docs/LAB_NOTES.md)
+#if FTK_FK_QUAD_CHAIN
+                    if (first ? lane < 6 : ((lane & 3) == 0 && lane < 24)) {  // the ring's chain lanes / the quads' first lanes hold the six bias sums
+                        c.sums[40 + (first ? lane : lane >> 2)] = acc;
+                    }
+#else
                     if (lane < 6) {
                         c.sums[40 + lane] = acc;
                     }
+#endif
                     fk_fence();
                     ldlt6_solve(fac, c.sums + 40, c.sums + 48, lane);  // affine_klt_fast.cpp:42
                     fk_fence();
@@ -827,6 +855,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
         if (p.iters) {
             p.iters[id] = iters;
         }
+        tail_report(p, iters, id);  // the longest feature of the call, for the next call's wave policy
         sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);
         if (p.sched_iters) {
             p.sched_iters[id] = iters;

@@ -180,6 +180,24 @@ __device__ __forceinline__ uint32_t collect_count(const Blk &b, const uint32_t *
     return total;
 }
 
+#ifndef FTK_KLT_QUAD_CHAIN
+#define FTK_KLT_QUAD_CHAIN 1  // sums of up to 16 term rows through the DPP network (klt_common.h "quad chain"); 0: one lane per sum (round 4)
+#endif
+
+// The chunked LSSD levels leave sum k in lane 4 k when they ran the quad chains (KltParams::quad_chain), in lane k otherwise.
+__device__ __forceinline__ int sum_lanes(const KltParams &p) { return (FTK_KLT_QUAD_CHAIN && p.quad_chain) ? 4 : 1; }
+
+// The K <= 16 sums of `terms[K][Ppad]` by ALL lanes of one wave: quad q = lanes 4 q .. 4 q + 3 carries sum q (the quads behind the last
+// sum follow its row and are ignored), Ppad / 16 steps of 16 ordered adds each; lane 4 q publishes sum q.  Same adds, same order as
+// chain_lane on lane q.  Ppad is a multiple of 16 and the rows' padding holds exact zeros (klt_fill_geometry, zero_term_padding).
+__device__ __forceinline__ void chain_rows_quads(const float *terms, int K, int Ppad, float *sums, int lane) {
+    const int q = lane >> 2;
+    const float acc = chain_quads_row(0.0f, terms + (q < K ? q : K - 1) * Ppad + 4 * (lane & 3), Ppad >> 4);
+    if ((lane & 3) == 0 && q < K) {
+        sums[q] = acc;
+    }
+}
+
 __device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int K, int Ppad, float *sums, bool leading_barrier = false) {
     if (leading_barrier) {
         blk_sync(b);  // phase A's terms (and published counts) become visible
@@ -187,6 +205,8 @@ __device__ __forceinline__ void chain_sums(const Blk &b, const float *terms, int
     if (b.wave == 0) {
         if (b.tree) {
             tree_sums(terms, K, Ppad, sums, b.lane);  // throughput mode: not the reference's order
+        } else if (FTK_KLT_QUAD_CHAIN && K <= 16) {
+            chain_rows_quads(terms, K, Ppad, sums, b.lane);
         } else if (b.lane < K) {
             sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
         }
@@ -207,6 +227,8 @@ __device__ __forceinline__ void chain_then(const Blk &b, const float *terms, int
         if (b.tree) {
             tree_sums(terms, K, Ppad, sums, b.lane);  // throughput mode: not the reference's order
             __builtin_amdgcn_wave_barrier();
+        } else if (FTK_KLT_QUAD_CHAIN && K <= 16) {
+            chain_rows_quads(terms, K, Ppad, sums, b.lane);
         } else if (b.lane < K) {
             sums[b.lane] = chain_lane(terms + b.lane * Ppad, Ppad);
         }
@@ -1549,6 +1571,10 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
                 for (int k = 0; k < 9; ++k) {
                     part[k] += ring[k * kChunkRow + b.lane];
                 }
+            } else if (FTK_KLT_QUAD_CHAIN && p.quad_chain) {
+                // every lane: quad q carries sum q (klt_common.h "quad chain"); the quads behind the ninth follow its row and are ignored.
+                // A launch that oversubscribes the chip keeps one lane per sum (KltParams::quad_chain): there the instruction COUNT decides.
+                acc = chain_quads_left(acc, ring + min(b.lane >> 2, 8) * kChunkRow + 4 * (b.lane & 3), p.P - chunk * kChunkPixels);
             } else if (b.lane < 9) {
                 acc = chain_chunk_left(acc, ring + b.lane * kChunkRow, p.P - chunk * kChunkPixels);
             }
@@ -1564,7 +1590,7 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                acc = (b.lane == k) ? part[k] : acc;  // the sums where the exact path leaves them: lanes 0..8
+                acc = (b.lane == k * sum_lanes(p)) ? part[k] : acc;  // the sums where the exact path leaves them: lanes 0..8 (quad chains: 0, 4 .. 32)
             }
         }
         FTK_STAMP_END(b, 3);  // window check + the chunks (sampling, products, chains)
@@ -1573,11 +1599,12 @@ __device__ __forceinline__ void lssd_level_fast_chunked(const Blk &b, const KltP
         }
         // the nine sums sit in lanes 0..8: broadcast and solve (lssd_solve on registers)
         const int acc_bits = __float_as_int(acc);
-        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
-        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
-        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5));
-        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7)),
-                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8))};
+        const int sl = __builtin_amdgcn_readfirstlane(sum_lanes(p));
+        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1 * sl));
+        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2 * sl)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3 * sl));
+        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4 * sl)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5 * sl));
+        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6 * sl)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7 * sl)),
+                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8 * sl))};
         float v[3];
         ldlt3_solve<true>(h00, h01, h02, h11, h12, h22, bb, v, b.lane);
         if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
@@ -1702,7 +1729,9 @@ __device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const 
                 cur_valid_num += (uint32_t)__popcll(wave_ballot(ok_cur));
                 ring[b.lane] = interior ? value : 0.0f;
                 blk_sync(b);
-                if (b.lane == 0) {
+                if (FTK_KLT_QUAD_CHAIN && p.quad_chain) {
+                    mean_acc = chain_quads_left(mean_acc, ring + 4 * (b.lane & 3), p.P - chunk * kChunkPixels);  // every quad carries the one sum
+                } else if (b.lane == 0) {
                     mean_acc = chain_chunk_left(mean_acc, ring, p.P - chunk * kChunkPixels);
                 }
                 blk_sync(b);
@@ -1742,7 +1771,9 @@ __device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const 
                 ring[8 * kChunkRow + b.lane] = -(dy * residual);
                 seen_valid = seen_valid || ok;
                 blk_sync(b);
-                if (b.lane < 9) {
+                if (FTK_KLT_QUAD_CHAIN && p.quad_chain) {
+                    acc = chain_quads_left(acc, ring + min(b.lane >> 2, 8) * kChunkRow + 4 * (b.lane & 3), p.P - chunk * kChunkPixels);
+                } else if (b.lane < 9) {
                     acc = chain_chunk_left(acc, ring + b.lane * kChunkRow, p.P - chunk * kChunkPixels);
                 }
                 blk_sync(b);
@@ -1752,11 +1783,12 @@ __device__ __forceinline__ void lssd_level_fast_chunked_lum(const Blk &b, const 
             break;  // :80-83
         }
         const int acc_bits = __float_as_int(acc);
-        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1));
-        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3));
-        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5));
-        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7)),
-                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8))};
+        const int sl = __builtin_amdgcn_readfirstlane(sum_lanes(p));
+        const float h00 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 0)), h01 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 1 * sl));
+        const float h02 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 2 * sl)), h11 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 3 * sl));
+        const float h12 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 4 * sl)), h22 = __int_as_float(__builtin_amdgcn_readlane(acc_bits, 5 * sl));
+        const float bb[3] = {__int_as_float(__builtin_amdgcn_readlane(acc_bits, 6 * sl)), __int_as_float(__builtin_amdgcn_readlane(acc_bits, 7 * sl)),
+                             __int_as_float(__builtin_amdgcn_readlane(acc_bits, 8 * sl))};
         float v[3];
         ldlt3_solve<true>(h00, h01, h02, h11, h12, h22, bb, v, b.lane);
         if (isnan(v[0]) || isnan(v[1]) || isnan(v[2])) {
@@ -2029,6 +2061,7 @@ __global__ void FTK_EU_ATTR __launch_bounds__(kWave *kMaxWaves) klt_track_kernel
         if (p.iters) {
             p.iters[id] = iters;
         }
+        tail_report(p, iters, id);  // the longest feature of the call, for the next call's wave policy
         sched_grid_record(p, full_ref_u, full_ref_v, out_u, out_v, iters);  // ... and by position
         if (p.sched_iters) {
             p.sched_iters[id] = iters;  // the next call's launch order (ftk_api.cpp: longest first)

@@ -1042,9 +1042,8 @@ hipError_t launch_nw(const MatchParams &p, hipStream_t stream) {
 
 }  // namespace
 
-bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits) {
-    const char *env = getenv("FTK_MATCH_SMALL");  // experiment switch, read per call (scripts/match_small_ab.py flips it)
-    const bool allowed = !(env && atoi(env) == 0);
+bool match_small_form(int n_ref, int n_cur, int n_words, int n_bits, bool small_off) {
+    const bool allowed = !small_off;  // FTK_MATCH_SMALL=0 (experiment switch of the context; scripts/match_small_ab.py flips it)
     const bool width = n_words == 1 || n_words == 2 || n_words == 4 || n_words == 8 || n_words == 16;
     return allowed && width && n_bits > 0 && n_cur < kSmallNoIndex && (long long)n_cur * n_words <= kSmallMatchRowWork &&
            (long long)n_ref * n_cur * n_words <= kSmallMatchWork;
@@ -1055,7 +1054,7 @@ hipError_t match_launch(const MatchParams &p, hipStream_t stream) {
         return hipSuccess;
     }
     hipError_t e = hipSuccess;
-    if (match_small_form(p.n_ref, p.n_cur, p.n_words, p.n_bits)) {
+    if (match_small_form(p.n_ref, p.n_cur, p.n_words, p.n_bits, p.small_off != 0)) {
         switch (p.n_words) {
             case 1: return launch_small<1>(p, stream);
             case 2: return launch_small<2>(p, stream);

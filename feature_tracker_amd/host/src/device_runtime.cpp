@@ -101,18 +101,31 @@ struct IdFile {
     unsigned char id[FTK_UNIQUE_ID_BYTES];
 };
 
+// The nonce as the id file stores it: as is while it fits, otherwise its head + '#' + a 64-bit FNV-1a hash of the WHOLE string — so
+// that what follows the 63rd character (";parent=...;restart=..." behind a UUID run id) still tells two launches apart.
 void PadNonce(const std::string &nonce, char out[kNonceBytes]) {
     std::memset(out, 0, kNonceBytes);
-    std::memcpy(out, nonce.data(), nonce.size() < kNonceBytes - 1 ? nonce.size() : kNonceBytes - 1);
+    if (nonce.size() < kNonceBytes) {
+        std::memcpy(out, nonce.data(), nonce.size());
+        return;
+    }
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char ch : nonce) {
+        h = (h ^ ch) * 1099511628211ull;
+    }
+    char tail[20];
+    std::snprintf(tail, sizeof(tail), "#%016llx", h);
+    std::memcpy(out, nonce.data(), kNonceBytes - 1 - 17);
+    std::memcpy(out + kNonceBytes - 1 - 17, tail, 17);
 }
+
+std::string ShownNonce(const char stored[kNonceBytes]) { return std::string(stored, strnlen(stored, kNonceBytes)); }
 }  // namespace
 
 namespace {
-// "<pid>@<start time in clock ticks since boot>" of this process's parent (Linux: /proc/<pid>/stat, field 22), or "" when it
-// cannot be read.  The start time makes the pair unique for the life of the machine even when pids are reused.
-std::string ParentIdentity() {
-    const long ppid = static_cast<long>(getppid());
-    const std::string stat_path = "/proc/" + std::to_string(ppid) + "/stat";
+// /proc/<pid>/stat: the parent's pid (field 4) and the start time in clock ticks since boot (field 22); false when unreadable.
+bool ProcStat(long pid, long *ppid, std::string *start) {
+    const std::string stat_path = "/proc/" + std::to_string(pid) + "/stat";
     std::string line;
     if (FILE *f = std::fopen(stat_path.c_str(), "rb")) {
         char buf[1024];
@@ -123,7 +136,7 @@ std::string ParentIdentity() {
     // the command name (field 2) is in parentheses and may contain spaces: count fields after the LAST ')'
     const size_t close = line.rfind(')');
     if (close == std::string::npos) {
-        return std::string();
+        return false;
     }
     size_t pos = close + 1;
     std::string field;
@@ -133,22 +146,75 @@ std::string ParentIdentity() {
         }
         const size_t end = line.find(' ', pos);
         field = line.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+        if (index == 4) {
+            *ppid = std::atol(field.c_str());
+        }
         if (end == std::string::npos && index < 22) {
-            return std::string();
+            return false;
         }
         pos = end == std::string::npos ? line.size() : end;
     }
     if (field.empty()) {
-        return std::string();
+        return false;
     }
-    return std::to_string(ppid) + "@" + field;
+    *start = field;
+    return true;
+}
+
+// Whether the environment a process was STARTED with holds `name` (/proc/<pid>/environ; unreadable: false).
+bool StartedWith(long pid, const char *name) {
+    const std::string path = "/proc/" + std::to_string(pid) + "/environ";
+    std::string env;
+    if (FILE *f = std::fopen(path.c_str(), "rb")) {
+        char buf[4096];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0 && env.size() < (1u << 20)) {
+            env.append(buf, got);
+        }
+        std::fclose(f);
+    }
+    const std::string key = std::string(name) + "=";
+    for (size_t pos = 0; pos < env.size();) {
+        if (env.compare(pos, key.size(), key) == 0) {
+            return true;
+        }
+        const size_t end = env.find('\0', pos);
+        if (end == std::string::npos) {
+            break;
+        }
+        pos = end + 1;
+    }
+    return false;
+}
+
+// "<pid>@<start time>" of the process that launched the ranks: the nearest ancestor that was NOT itself started as a rank (no
+// LOCAL_RANK in the environment it was started with).  Under plain torchrun that is the parent (the elastic agent); with a per-rank
+// wrapper in between (`torchrun --no-python wrapper.sh`, a per-rank `rocprofv3 -- python3 ...`: the wrapper inherits LOCAL_RANK from
+// the agent) it is still the agent, the same for every rank — round 4 took the parent and gave every wrapped rank its own nonce
+// (ADVICE r4).  The start time makes the pair unique for the life of the machine even when pids are reused.  "" when unreadable.
+std::string LauncherIdentity() {
+    long pid = static_cast<long>(getppid());
+    for (int depth = 0; depth < 8 && pid > 1; ++depth) {
+        long ppid = 0;
+        std::string start;
+        if (!ProcStat(pid, &ppid, &start)) {
+            return std::string();
+        }
+        if (!StartedWith(pid, "LOCAL_RANK")) {
+            return std::to_string(pid) + "@" + start;
+        }
+        pid = ppid;
+    }
+    return std::string();
 }
 
 const std::chrono::system_clock::time_point g_process_start = std::chrono::system_clock::now();
 }  // namespace
 
 // What tells THIS launch's id file from one an earlier (or crashed) run left under the same path.  FTK_COMM_NONCE, when the caller
-// sets it, is taken as is (ranks started from unrelated parents — two terminals, an MPI launcher with a shell per rank — need it).
+// sets it, is taken as is — REQUIRED when the ranks do not descend from one launcher process that exports LOCAL_RANK to them (two
+// terminals, an MPI launcher whose per-rank shell sets LOCAL_RANK itself): their automatic nonces would differ, and the reader's
+// time-out message then names both nonces.
 // Otherwise: the launcher's variables are NOT unique per launch under default torchrun (TORCHELASTIC_RUN_ID is "none",
 // MASTER_PORT 29500, every time), so under a launcher that forks all ranks of a node from one agent process (it exports
 // LOCAL_RANK / TORCHELASTIC_RUN_ID; this library shards over the GPUs of ONE node) the agent's identity — pid and start time —
@@ -170,7 +236,7 @@ std::string CommLaunchNonce() {
     const char *local_rank = std::getenv("LOCAL_RANK");
     const bool common_parent = (local_rank != nullptr && local_rank[0] != '\0') || std::getenv("TORCHELASTIC_RUN_ID") != nullptr;
     if (common_parent) {
-        const std::string parent = ParentIdentity();
+        const std::string parent = LauncherIdentity();
         if (!parent.empty()) {
             nonce += (nonce.empty() ? "" : ";") + std::string("parent=") + parent;
         }
@@ -178,7 +244,7 @@ std::string CommLaunchNonce() {
             nonce += std::string(";restart=") + restarts;
         }
     }
-    return nonce;  // at most kNonceBytes - 1 characters take part (PadNonce)
+    return nonce;  // (longer than the id file's field: stored as head + hash of the whole string, PadNonce)
 }
 
 bool PublishCommId(const std::string &path, const std::string &nonce, const unsigned char id[FTK_UNIQUE_ID_BYTES], std::string *error) {
@@ -207,6 +273,7 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
     char want[kNonceBytes];
     PadNonce(nonce, want);
     bool stale_seen = false;
+    std::string found;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
     for (;;) {
         if (FILE *f = std::fopen(path.c_str(), "rb")) {
@@ -223,6 +290,7 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
                 return true;
             }
             stale_seen = true;  // another launch's file, an old format or a foreign file: rank 0 of THIS launch replaces it
+            found = whole ? ShownNonce(file.nonce) + (fresh ? "" : " (written before this launch)") : std::string("<not an id file>");
         }
         if (std::chrono::steady_clock::now() >= deadline) {
             break;
@@ -231,7 +299,9 @@ bool AwaitCommId(const std::string &path, const std::string &nonce, int timeout_
     }
     if (error != nullptr) {
         *error = "timed out waiting for the RCCL unique id in " + path +
-                 (stale_seen ? " (the file there belongs to another launch: its nonce differs from this rank's)" : "");
+                 (stale_seen ? " (the file there belongs to another launch: this rank expects the nonce \"" + ShownNonce(want) + "\", the file holds \"" + found +
+                                   "\"; ranks that do not share one launcher process must be given the same FTK_COMM_NONCE)"
+                             : "");
     }
     return false;
 }

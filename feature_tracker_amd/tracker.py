@@ -13,6 +13,7 @@ All compute goes through libftk_hip.so; nothing here falls back to numpy.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -26,6 +27,15 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_LIVE_CONTEXTS = weakref.WeakSet()
+
+
+def refresh_env_switches() -> None:
+    """Every live context re-reads the FTK_* experiment switches (they are read once per context, not per call)."""
+    for ctx in list(_LIVE_CONTEXTS):
+        ctx.refresh_env()
+
+
 class Context:
     """One HIP device + stream (ftk_context).  ``stream`` may be a raw hipStream_t handle, e.g.
     ``torch.cuda.Stream().cuda_stream``; by default the context owns a private stream."""
@@ -34,6 +44,12 @@ class Context:
         self._h = C.c_void_p()
         rc = N.lib().ftk_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
         N.check(rc, None)
+        _LIVE_CONTEXTS.add(self)
+
+    def refresh_env(self):
+        """ftk_context_refresh_env: the FTK_* experiment switches are read once per context; read them again (tests, sweeps)."""
+        if self._h:
+            N.check(N.lib().ftk_context_refresh_env(self._h), self._h)
 
     @property
     def handle(self):

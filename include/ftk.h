@@ -94,7 +94,9 @@ int ftk_device_count(void);
  * create and own one.  device < 0 keeps the calling thread's current device. */
 int ftk_context_create(int device, void *stream, ftk_context **out);
 void ftk_context_destroy(ftk_context *ctx);
-/* Text of the last failure on this context (or of the last failed ftk_context_create when ctx is NULL). */
+/* Text of the last failure on this context (or of the last failed ftk_context_create when ctx is NULL).  One successful call leaves
+ * text too: ftk_direct_track, when its spread launch could not become co-resident and the problem was re-run on one workgroup
+ * ("note: ..."; the result is correct, the call took two launches). */
 const char *ftk_last_error(const ftk_context *ctx);
 int ftk_synchronize(ftk_context *ctx);
 /* First-use cost out of the caller's timed region.  The reference constructs its tracker / matcher objects BEFORE it starts its
@@ -121,6 +123,11 @@ void ftk_default_klt_options(ftk_klt_options *opt);
  */
 enum { FTK_REDUCTION_EXACT = 0, FTK_REDUCTION_TREE = 1 };
 int ftk_set_reduction_mode(ftk_context *ctx, int mode);
+
+/* Diagnostics.  The library's FTK_* environment switches (launch shapes, kernel choices; none changes a result) are read ONCE, when
+ * the context is created — no entry point calls getenv.  A test or a sweep that flips one for an existing context calls this
+ * to have them read again.  Nothing in the reference corresponds to it. */
+int ftk_context_refresh_env(ftk_context *ctx);
 
 /* ---- image pyramids resident in HBM ------------------------------------------------------ */
 

@@ -21,6 +21,7 @@ def main():
     m.options().kMaxValidDescriptorDistance = 60
     dump = os.path.join(tempfile.gettempdir(), "match_stamps.bin")
     os.environ["FTK_MATCH_STAMPS_DUMP"] = dump
+    F.refresh_env_switches()  # the switches are read once per context
     for _ in range(3):
         m.ForceMatch(ref, cur)
     st = np.fromfile(dump, dtype=np.uint64).reshape(-1, 8)

@@ -2,7 +2,8 @@
 """Back-to-back launch time of tracker variants on device-resident inputs (bench.py's timed-region method: K launches, one
 synchronisation on each side, wall clock), checked against the oracle:
     python scripts/time_variant.py basic:fast:2000:6 lssd:fast:10000:6:lum affine:fast:2000:6 [--steps 50] [--size 640x480] [--levels 4]
-Each spec is model:method:n:half[:lum]."""
+Each spec is model:method:n:half[:lum].  --real: the reference's example pair (tests/data/optical_flow, 752x480) with Harris corners topped up
+to n (bench.py real_image_features) instead of the synthetic scene."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,6 +18,7 @@ def main():
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--fixed-iterations", action="store_true", help="never converge, never stop on large steps: kMaxIteration iterations on every level (what ONE iteration costs)")
     ap.add_argument("--max-iteration", type=int, default=15)
+    ap.add_argument("--real", action="store_true", help="the reference's example image pair + Harris corners instead of the synthetic scene")
     args = ap.parse_args()
     import torch
     import feature_tracker_amd as F
@@ -33,13 +35,23 @@ def main():
             f = spec.split(":")
             model, method, n, half = f[0], f[1], int(f[2]), int(f[3])
             lum = len(f) > 4 and f[4] == "lum"
-            key = model == "basic"
+            key = "real" if args.real else model == "basic"
             if key not in scenes:
-                ref, cur = synth.make_image_pair(w, h, (3.3, -2.1)) if key else synth.make_image_pair(w, h, (3.3, -2.1), rotation_deg=1.5, scale=1.02)
+                if args.real:
+                    from PIL import Image
+                    import bench
+                    ref = np.ascontiguousarray(np.array(Image.open(bench.REAL_PAIR[0]).convert("L"), dtype=np.uint8))
+                    cur = np.ascontiguousarray(np.array(Image.open(bench.REAL_PAIR[1]).convert("L"), dtype=np.uint8))
+                else:
+                    ref, cur = synth.make_image_pair(w, h, (3.3, -2.1)) if key else synth.make_image_pair(w, h, (3.3, -2.1), rotation_deg=1.5, scale=1.02)
                 rl, cl = synth.build_pyramid(ref, args.levels), synth.build_pyramid(cur, args.levels)
                 scenes[key] = (rl, cl, D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev))
             rl, cl, rp, cp = scenes[key]
-            uv = synth.make_features(n, w, h, half=half)
+            if args.real:
+                import bench
+                uv, _ = bench.real_image_features(rl[0], n, half, ctx)
+            else:
+                uv = synth.make_features(n, w, h, half=half)
             opt = F.OpticalFlowOptions()
             opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, half, half, n
             opt.kMaxIteration = args.max_iteration
@@ -63,7 +75,7 @@ def main():
                     launches[k & 1]()
                 stream.synchronize()
                 best.append((time.perf_counter() - t0) / args.steps * 1e6)
-            out = {"spec": spec, "us_per_step": round(min(best), 2), "us_runs": [round(x, 2) for x in best], "mean_iters": float(d_it.float().mean().item())}
+            out = {"spec": spec, "us_per_step": round(min(best), 2), "us_runs": [round(x, 2) for x in best], "mean_iters": float(d_it.float().mean().item()), "max_iters": int(d_it.max().item())}
             if not args.no_oracle and not args.fixed_iterations:
                 t0 = time.perf_counter()
                 ok, cuv, cst, cit = oracle_lib.klt_track_pyramid(model, rl, cl, uv, method=method, half=half, max_points=n, consider_luminance=lum)

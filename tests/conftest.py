@@ -31,3 +31,26 @@ def ftk():
 @pytest.fixture(scope="session")
 def gpu_ctx(ftk):
     return ftk.default_context()
+
+
+@pytest.fixture
+def switch():
+    """Sets one of the library's FTK_* experiment switches for the duration of a test.  The library reads them ONCE per context
+    (ftk_context_create), so every live context is told to read them again (ftk_context_refresh_env) after each change and once
+    more when the test's environment has been restored."""
+    import feature_tracker_amd as F
+    saved = {}
+
+    def set_switch(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = str(value)
+        F.refresh_env_switches()
+
+    yield set_switch
+    for name, old in saved.items():
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+    if saved:
+        F.refresh_env_switches()

@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["default", "one-workgroup", "spread-3-tiny"], autouse=True)
-def direct_form(request, monkeypatch):
+def direct_form(request, switch):
     """Every test runs three times: with the default dispatch (ONE problem with enough terms is spread over the chip:
     direct_track_spread_kernel), with the one-workgroup kernel only (FTK_DIRECT_SPREAD=0), and spread over three producer workgroups
     whatever the size (problems of one feature included: most producer waves then own no chunk of the stream)."""
     if request.param == "one-workgroup":
-        monkeypatch.setenv("FTK_DIRECT_SPREAD", "0")
+        switch("FTK_DIRECT_SPREAD", "0")
     elif request.param == "spread-3-tiny":
-        monkeypatch.setenv("FTK_DIRECT_SPREAD", "3")
-        monkeypatch.setenv("FTK_DIRECT_SPREAD_MIN_TERMS", "1")
+        switch("FTK_DIRECT_SPREAD", "3")
+        switch("FTK_DIRECT_SPREAD_MIN_TERMS", "1")
 
 FX, FY, CX, CY = 400.0, 410.0, 321.5, 238.25
 
@@ -198,3 +198,25 @@ def test_small_batches_of_problems_match_the_oracle_problem_by_problem(ftk, orac
         assert np.array_equal(pr["cur_uv"].cpu().numpy().view(np.uint32), c.view(np.uint32))
         assert np.array_equal(pr["status"].cpu().numpy(), st)
         assert int(pr["iterations"].cpu().numpy()[0]) == it
+
+
+def test_spread_launch_that_cannot_be_resident_never_returns_a_poisoned_pose(ftk, oracle, switch):
+    """the spread kernel needs its 1 + NP workgroups co-resident.  (1) The producers are sized from what the
+    device holds (occupancy x compute units; FTK_DIRECT_SPREAD_RESIDENT pretends a 32-CU partition or less) and the one-workgroup
+    kernel runs when fewer than 1 + 8 fit; (2) a spread launch whose bounded waits ran out (FTK_DIRECT_SPREAD_POISON=1 makes the
+    consumer behave so) leaves header word 1 set and a NaN pose on the device — the synchronous entry point must re-run the problem on
+    one workgroup and return the oracle's pose, with a note in ftk_last_error()."""
+    from feature_tracker_amd import _native as N
+    rl, cl, uv, pts = scene(n=300)
+    switch("FTK_DIRECT_SPREAD", "32")
+    switch("FTK_DIRECT_SPREAD_MIN_TERMS", "1")
+    for resident in ("33", "9", "4"):
+        switch("FTK_DIRECT_SPREAD_RESIDENT", resident)
+        g, c = run_both(ftk, oracle, rl, cl, uv, pts, max_points=300)
+        assert_identical(g, c)
+    switch("FTK_DIRECT_SPREAD_RESIDENT", "256")
+    switch("FTK_DIRECT_SPREAD_POISON", "1")
+    g, c = run_both(ftk, oracle, rl, cl, uv, pts, max_points=300)
+    assert_identical(g, c)
+    note = N.lib().ftk_last_error(ftk.default_context().handle).decode()
+    assert "re-run on one workgroup" in note, note

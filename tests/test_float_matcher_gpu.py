@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["default", "launches"], autouse=True)
-def matcher_form(request, monkeypatch):
+def matcher_form(request, switch):
     """Every test runs twice: with the default dispatch — the one-launch exact form (cosine_match_small_kernel: calls of few candidates) and the clear + prep + contraction + recheck pipeline by size — and with the one-launch form
     switched off (FTK_COSINE_SMALL=0, read per call), so that small inputs also reach the kernels that serve the large ones."""
     if request.param == "launches":
-        monkeypatch.setenv("FTK_COSINE_SMALL", "0")
+        switch("FTK_COSINE_SMALL", "0")
 
 
 def matcher(ftk, max_dist, col=40, row=40):
@@ -163,12 +163,12 @@ def test_full_size_properties(ftk):
 
 
 @pytest.mark.parametrize("env", [{}, {"FTK_COSINE_TWO_PASS": "1"}, {"FTK_COSINE_CHUNKED": "1"}, {"FTK_COSINE_SPLITS": "1"}, {"FTK_COSINE_SPLITS": "5"}])
-def test_contraction_variants_agree_with_oracle(ftk, oracle, monkeypatch, env):
+def test_contraction_variants_agree_with_oracle(ftk, oracle, switch, env):
     """The shortlist has three implementations behind one decision rule (single walk with a running row maximum,
     maximum-then-collect, chunked for long descriptors) and a split count chosen from the grid size: each of them,
     at forced split counts, must give the oracle's indices — force and nearby, ragged sizes."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        switch(k, v)
     rs = np.random.RandomState(21)
     for n_ref, n_cur, dim in ((700, 2100, 256), (260, 1500, 128), (130, 513, 200)):
         ref, cur, _ = synth.make_float_descriptors(n_ref, n_cur, dim=dim, noise=0.25)
@@ -184,14 +184,14 @@ def test_contraction_variants_agree_with_oracle(ftk, oracle, monkeypatch, env):
 
 
 @pytest.mark.parametrize("splits", [None, "1", "2"])
-def test_candidates_in_ascending_order_of_similarity(ftk, oracle, monkeypatch, splits):
+def test_candidates_in_ascending_order_of_similarity(ftk, oracle, switch, splits):
     """Worst case for the running row maximum: every later cur row beats all earlier ones for one ref row, so the single
     walk collects an entry per tile until the list overflows and the row takes the exact scan.  Other rows see the
     same cur rows in an unrelated order.  Results must not depend on any of it."""
     if splits is not None:
         # one or two workgroups walk ALL tiles: the rows below then stage an entry per tile, more than a wave's staging
         # region holds, and must fall back to the exact scan
-        monkeypatch.setenv("FTK_COSINE_SPLITS", splits)
+        switch("FTK_COSINE_SPLITS", splits)
     rs = np.random.RandomState(3)
     dim, n_cur = 256, 4096
     base = rs.standard_normal(dim).astype(np.float32)
@@ -293,12 +293,12 @@ def test_nearby_match_in_spatial_order(ftk, oracle, n, dim, window):
 
 
 @pytest.mark.parametrize("splits", [None, "1"])
-def test_long_walk_over_many_candidates(ftk, oracle, monkeypatch, splits):
+def test_long_walk_over_many_candidates(ftk, oracle, switch, splits):
     """Few reference rows against 40 000 candidates: one or two workgroups per row group walk hundreds of tiles, so a
     wave's staging region fills several times over and is emptied inside the walk.  Random descriptors (no planted
     partner) make every row set new maxima again and again."""
     if splits is not None:
-        monkeypatch.setenv("FTK_COSINE_SPLITS", splits)
+        switch("FTK_COSINE_SPLITS", splits)
     rs = np.random.RandomState(31)
     ref = rs.standard_normal((600, 64)).astype(np.float32)
     cur = rs.standard_normal((40000, 64)).astype(np.float32)

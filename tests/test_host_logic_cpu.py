@@ -266,10 +266,24 @@ def test_stale_id_file_is_not_mistaken_for_this_launch(tmp_path):
     assert _comm_cli(["nonce"], MASTER_PORT="29500", LOCAL_RANK="0").stdout.strip().startswith("MASTER_PORT=29500;parent=%d@" % os.getpid())
     restarted = _comm_cli(["nonce"], MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1", TORCHELASTIC_RESTART_COUNT="1").stdout.strip()
     assert restarted == mine + ";restart=1"
-    # the same launcher variables under ANOTHER launching process (a shell in between) give another nonce
-    other = subprocess.run(["sh", "-c", COMM_CLI + " nonce; true"], capture_output=True, text=True, timeout=30,
-                           env=dict(base, MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1")).stdout.strip()
+    # a per-rank WRAPPER in between (it was started with the rank's LOCAL_RANK: `torchrun --no-python wrapper.sh`, a per-rank
+    # `rocprofv3 -- python3 ...`) is looked through — the launcher is the nearest ancestor that was not itself started as a rank, the
+    # same for every rank (taking the parent gave every wrapped rank its own nonce and a 120 s time-out)
+    wrapped = subprocess.run(["sh", "-c", COMM_CLI + " nonce; true"], capture_output=True, text=True, timeout=30,
+                             env=dict(base, MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", LOCAL_RANK="1")).stdout.strip()
+    assert wrapped == mine
+    # the same launcher variables under ANOTHER launching process (a shell that was not started as a rank) give another nonce
+    other = subprocess.run(["sh", "-c", "LOCAL_RANK=1 " + COMM_CLI + " nonce; true"], capture_output=True, text=True, timeout=30,
+                           env=dict(base, MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none")).stdout.strip()
     assert other.startswith("TORCHELASTIC_RUN_ID=none;parent=") and other != mine
+    # a nonce longer than the id file's 64-byte field (a UUID run id + parent + restart) is stored as head + hash of the WHOLE string:
+    # two launches that differ only behind the 63rd character are still told apart, and the time-out names both nonces
+    long_a, long_b = "u" * 70 + ";restart=0", "u" * 70 + ";restart=1"
+    assert _comm_cli(["publish", path, "17"], FTK_COMM_NONCE=long_a).returncode == 0
+    miss = _comm_cli(["await", path, "300"], FTK_COMM_NONCE=long_b)
+    assert miss.returncode == 2 and "expects the nonce" in miss.stderr and "FTK_COMM_NONCE" in miss.stderr
+    hit = _comm_cli(["await", path, "300"], FTK_COMM_NONCE=long_a)
+    assert hit.returncode == 0 and hit.stdout.strip() == "17"
     # and whatever its nonce, a file written long before this process started is a leftover (ranks start within two minutes)
     assert _comm_cli(["publish", path, "99"], FTK_COMM_NONCE="B").returncode == 0
     old = time.time() - 600

@@ -377,12 +377,12 @@ def test_patches_beyond_a_workgroups_lds_run_the_large_patch_form(ftk, oracle, m
 
 @pytest.mark.parametrize("windows", [1, 2])
 @pytest.mark.parametrize("model", MODELS)
-def test_large_patch_form_forced_on_ordinary_patches(ftk, oracle, model, windows, monkeypatch):
+def test_large_patch_form_forced_on_ordinary_patches(ftk, oracle, model, windows, switch):
     """FTK_KLT_SPILL=1 sends every variant through the large-patch form at an ordinary size (13 x 13, rectangular 5 x 9), =2 also
     without the LDS image windows (every tap from global memory — what patches from about 280 x 280 get); the feature list is
     tracked in three batches (a 1 MB budget of device memory), with a kMaxTrackPointsNumber that cuts the second batch."""
-    monkeypatch.setenv("FTK_KLT_SPILL", str(windows))
-    monkeypatch.setenv("FTK_KLT_SPILL_BUDGET_MB", "1")
+    switch("FTK_KLT_SPILL", str(windows))
+    switch("FTK_KLT_SPILL_BUDGET_MB", "1")
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "hard", "similarity")
     uv = scenes.features(150, 320, 240, half=6, seed=5, border_fraction=0.05)
     for method in METHODS:
@@ -462,12 +462,12 @@ def test_sharded_tracker_on_device_world_size_1(ftk, oracle):
 
 
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
-def test_one_wave_features_packed_into_workgroups(ftk, oracle, monkeypatch, group):
+def test_one_wave_features_packed_into_workgroups(ftk, oracle, switch, group):
     """One wave per feature (what large batches use) with 1..4 features per workgroup — the compile-time SOLO instantiations of
     both kernels, incl. the chunked LSSD-fast level: no barrier, own LDS carve per wave, ragged last group.  Every variant must
     still equal the oracle bit for bit."""
-    monkeypatch.setenv("FTK_KLT_WAVES", "1")
-    monkeypatch.setenv("FTK_KLT_GROUP", str(group))
+    switch("FTK_KLT_WAVES", "1")
+    switch("FTK_KLT_GROUP", str(group))
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
     uv = scenes.features(301, 320, 240, half=6)  # not a multiple of any group size
     for model in MODELS:
@@ -479,7 +479,7 @@ def test_one_wave_features_packed_into_workgroups(ftk, oracle, monkeypatch, grou
 
 
 @pytest.mark.parametrize("group", [None, 1, 3])
-def test_affine_fast_one_wave_kernel_on_the_edge_cases(ftk, oracle, monkeypatch, group):
+def test_affine_fast_one_wave_kernel_on_the_edge_cases(ftk, oracle, switch, group):
     """The affine tracker's `fast` method runs klt_fast_kernel<affine> only from 513 features on (a smaller call is its slowest
     feature, and that one is faster on the generic kernel's three waves: ftk_api.cpp fk_model), so the edge-case tests above — all
     of 64 - 400 features — reach it on the generic kernel.  The same cases at 520 - 700 features: border and outside features (clamped
@@ -487,7 +487,7 @@ def test_affine_fast_one_wave_kernel_on_the_edge_cases(ftk, oracle, monkeypatch,
     a workgroup's group of features, a rectangular patch with tight options, pyramid levels smaller than the patch, the single-level
     overload with its affine prior.  Default packing, one feature per workgroup, and three (ragged last group)."""
     if group is not None:
-        monkeypatch.setenv("FTK_KLT_GROUP", str(group))
+        switch("FTK_KLT_GROUP", str(group))
     # border / outside
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "similarity")
     rs = np.random.RandomState(11)
@@ -532,10 +532,10 @@ def test_affine_fast_one_wave_kernel_on_the_edge_cases(ftk, oracle, monkeypatch,
     assert_parity((ok, c, s, klt.last_iterations), cpu, "affine/fast one-wave: single level with prior")
 
 
-def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
+def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, switch):
     """The chunked one-wave LSSD-fast level (64-pixel ring, sums in registers) against the oracle on border / hard-motion /
     rectangular-patch inputs, and against the plain level (FTK_LSSD_CHUNKED=0)."""
-    monkeypatch.setenv("FTK_KLT_WAVES", "1")
+    switch("FTK_KLT_WAVES", "1")
     ref_levels, cur_levels = scenes.scene(320, 240, 4, "hard", "similarity")
     rs = np.random.RandomState(8)
     uv = np.stack([rs.uniform(-10, 330, 500), rs.uniform(-10, 250, 500)], axis=1).astype(np.float32)
@@ -544,7 +544,7 @@ def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
     for half, half_cols in ((6, None), (3, 9), (10, None), (1, 1)):
         results = []
         for chunked in ("1", "0"):
-            monkeypatch.setenv("FTK_LSSD_CHUNKED", chunked)
+            switch("FTK_LSSD_CHUNKED", chunked)
             gpu, cpu = run_pyramid(ftk, oracle, "lssd", "fast", ref_levels, cur_levels, uv, half=half, half_cols=half_cols, prior=prior)
             assert_parity(gpu, cpu, f"chunked={chunked} half={half}x{half_cols}")
             results.append(gpu)
@@ -552,7 +552,7 @@ def test_lssd_fast_chunked_equals_the_unchunked_level(ftk, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("model,method", [("affine", "inverse"), ("lssd", "fast"), ("basic", "inverse")])
-def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model, method, monkeypatch):
+def test_launch_order_from_the_previous_call_changes_nothing(ftk, oracle, model, method, switch):
     """From the third call with the same feature count on, the device entry launches the features longest-first by an earlier
     call's iteration counts (ftk_api.cpp; the sort runs in an extra workgroup of the launch in between, klt_common.h
     klt_order_block; calls of >= 4096 features).  Every call must return what the first one did — the oracle's answer — also
@@ -638,7 +638,7 @@ def test_position_keyed_launch_order_when_the_feature_count_changes(ftk, oracle,
 
 
 @pytest.mark.parametrize("n", [4603, 8192])
-def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle, n, monkeypatch, tmp_path):
+def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle, n, switch, tmp_path):
     """Without a tail in the iteration counts the launch order is by image region, dealt XCD-major (klt_common.h klt_order_block,
     xcd_major_slot): it must be a permutation for feature counts that do and do not fill the last workgroup, the slots of one XCD
     (workgroup index mod 8) must come in runs that each cover a compact part of the image, and the results stay the oracle's."""
@@ -647,7 +647,7 @@ def test_flat_iteration_counts_give_a_spatial_xcd_major_launch_order(ftk, oracle
     ref_levels, cur_levels = scenes.scene(320, 240, 3, "easy", "translation")
     uv = synth.make_features(n, 320, 240, margin=24.0, border_fraction=0.0, half=5)
     dump = tmp_path / "order.bin"
-    monkeypatch.setenv("FTK_KLT_SCHED_DUMP", str(dump))
+    switch("FTK_KLT_SCHED_DUMP", str(dump))
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     ctx = D.context_on_stream(stream, 0)
@@ -740,7 +740,7 @@ def test_host_images_reach_the_pyramid_launch_through_the_pinned_slots(ftk, orac
         assert np.array_equal(pyramids[-1].download_level(i), level), i
 
 
-def test_position_keyed_trades_of_launch_slots_process_every_feature_once(ftk, oracle, monkeypatch, tmp_path):
+def test_position_keyed_trades_of_launch_slots_process_every_feature_once(ftk, oracle, switch, tmp_path):
     """A list that is reshuffled between calls: the launch order (by list index) is stale, and early launch slots trade places with
     late ones whose POSITION predicts many iterations (klt_common.h sched_resolve_slot; multi-wave trackers, >= 4096 features).
     Trades must happen here, and every feature must come out exactly as the oracle has it — whichever slot ran it."""
@@ -750,7 +750,7 @@ def test_position_keyed_trades_of_launch_slots_process_every_feature_once(ftk, o
     n = 4700
     uv = synth.make_features(n, 320, 240, margin=20.0, border_fraction=0.02, half=6)
     dump = tmp_path / "trades.txt"
-    monkeypatch.setenv("FTK_KLT_SWAP_DUMP", str(dump))
+    switch("FTK_KLT_SWAP_DUMP", str(dump))
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     ctx = D.context_on_stream(stream, 0)

@@ -8,11 +8,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["default", "launches"], autouse=True)
-def matcher_form(request, monkeypatch):
+def matcher_form(request, switch):
     """Every test runs twice: with the default dispatch — the one-launch form (hamming_match_small_kernel: small calls) and the boxes + scan + epilogue launches by size — and with the one-launch form
     switched off (FTK_MATCH_SMALL=0, read per call), so that small inputs also reach the kernels that serve the large ones."""
     if request.param == "launches":
-        monkeypatch.setenv("FTK_MATCH_SMALL", "0")
+        switch("FTK_MATCH_SMALL", "0")
 
 
 def matcher(ftk, max_dist, col=40, row=40):
@@ -170,13 +170,13 @@ def test_nearby_match_in_spatial_order(ftk, oracle, n, n_bits, window):
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "scalar", "lds"])
-def test_every_scan_kernel_gives_the_oracle_indices(ftk, oracle, kernel, monkeypatch):
+def test_every_scan_kernel_gives_the_oracle_indices(ftk, oracle, kernel, switch):
     """The three Hamming scans behind ftk_hamming_match (matrix cores for 256 / 512 bits, popcount with the candidates on the
     scalar path, popcount with LDS tiles; FTK_MATCH_KERNEL picks one, read per call) on the same inputs: thresholds below,
     at and far above the distances that occur (the early exits key on the threshold), duplicates (lowest j wins), a
     candidate count that is not a multiple of any tile, reference counts around the 64-row and 512-row blocks, NearbyMatch
     windows with NaN coordinates, and stale indices that must survive."""
-    monkeypatch.setenv("FTK_MATCH_KERNEL", kernel)
+    switch("FTK_MATCH_KERNEL", kernel)
     rs = np.random.RandomState(17)
     for n_ref, n_cur, n_bits in ((65, 33, 256), (513, 1001, 256), (1500, 2100, 512), (200, 777, 256), (130, 95, 512)):
         ref, cur, _ = synth.make_descriptors(n_ref, n_cur, n_bits=n_bits, flips=n_bits // 12)
