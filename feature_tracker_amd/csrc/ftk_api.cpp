@@ -120,7 +120,8 @@ int ensure_match_keys(ftk_context *ctx, size_t count) {
     return FTK_OK;
 }
 
-constexpr uint32_t kSchedMinFeatures = 4096;  // below this every feature is resident from the start: nothing to order
+constexpr uint32_t kSchedMinFeatures = 4096;  // below this (nearly) every feature is resident from the start: nothing to order ...
+constexpr uint32_t kSchedMinLongTail = 1024;  // ... unless the calls have a long tail (see ftk_klt_track_device)
 constexpr size_t kSchedTableWords = (2u << 16) + 2;  // two position tables of 2^16 entries (klt_common.h kSchedTableSize) + the two "no tail" flags behind them
 constexpr size_t kSchedOrderWords = 512;             // behind them: histogram + cursors of the position-keyed launch order (klt_position_order_launch)
 constexpr int32_t kSchedMaxFeatures = 1 << 18;  // the sort block walks the list alone; beyond this it could outlast the launch
@@ -1266,7 +1267,15 @@ int ftk_klt_track_device(ftk_context *ctx, int model, const ftk_klt_options *opt
         // calls old.  Which slot runs a feature changes nothing in its arithmetic.  Only for calls with more features than
         // fit the chip at once; FTK_KLT_SCHED=0 keeps list order.
         const bool sched_allowed = !(FTK_ENV(ctx, klt_sched) && atoi(FTK_ENV(ctx, klt_sched)) == 0);
-        if (sched_allowed && p.n_track >= kSchedMinFeatures && n <= kSchedMaxFeatures) {
+        // From kSchedMinFeatures on — or, when this variant's recent calls had a long feature (p.long_tail: the kernels report it,
+        // fill_klt_params), already from kSchedMinLongTail: multi-wave features of a few thousand do NOT all fit the chip at once, and
+        // a 50-iteration feature that starts in the second round ends the launch that much later (the reference's example pair, same
+        // box, order from 4 096 / from 1 024: affine inverse 2 000 features 165.9 / 138.8 us, affine direct 3 000: 174.7 / 136.0, LSSD
+        // fast 3 000: 143.2 / 113.2, Basic fast 3 000: 60.9 / 52.3; the synthetic scene's LSSD / affine variants -4 ... -15 %).  Calls
+        // without a tail keep list order there: the order costs every feature one more dependent load (Basic variants +3 ... 4 %).
+        const uint32_t sched_min = FTK_ENV(ctx, klt_sched_min) ? (uint32_t)atoi(FTK_ENV(ctx, klt_sched_min))  // (experiment override)
+                                                               : (p.long_tail ? kSchedMinLongTail : kSchedMinFeatures);
+        if (sched_allowed && p.n_track >= sched_min && n <= kSchedMaxFeatures) {
             if ((size_t)n > ctx->sched_capacity) {
                 FTK_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 for (int k = 0; k < 2; ++k) {
