@@ -176,6 +176,39 @@ int ftk_ensure_device_buffer(ftk_context *ctx, void **buf, size_t *have, size_t 
     return FTK_OK;
 }
 
+namespace ftk {
+namespace {
+#include "klt_wave_policy.inc"
+
+// nearest bucket centre on a log scale (the centres ascend)
+int policy_bucket(const int *centres, int count, int x) {
+    int best = 0;
+    for (int i = 1; i < count; ++i) {
+        // x is nearer to centres[i] than to centres[i - 1] when x * x > centres[i - 1] * centres[i]
+        if ((long long)x * x > (long long)centres[i - 1] * centres[i]) {
+            best = i;
+        }
+    }
+    return best;
+}
+}  // namespace
+
+// Waves per feature for one call (klt_wave_policy.inc: measured, generated): method_class 0 inverse, 1 direct, 2 fast-like.
+// Patches beyond the table's largest bucket by more than a factor of two (from about 30 x 30) are outside what was swept: the
+// lanes-per-pixel rule serves them (they run four waves: the pixel loops dominate).
+int klt_policy_waves(int model, int method_class, int consider_luminance, int long_tail, int pixels, int n) {
+    if (pixels > 2 * kPolicyPixels[kPolicyPixelBuckets - 1]) {
+        return std::min(4, std::max(1, (pixels + 63) / 64));
+    }
+    int variant = model * 3 + method_class;
+    if (model == FTK_MODEL_LSSD && method_class == 2 && consider_luminance) {
+        variant = 9;
+    }
+    const int w = kWavePolicy[variant][long_tail ? 1 : 0][policy_bucket(kPolicyPixels, kPolicyPixelBuckets, pixels)][policy_bucket(kPolicyFeatures, kPolicyFeatureBuckets, n)];
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+}  // namespace ftk
+
 namespace {
 
 constexpr uint32_t kTailLongFrom = 24;  // iterations of a call's longest feature from which the call counts as tail-bound
@@ -237,108 +270,19 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     }
     p.consider_luminance = consider_luminance ? 1 : 0;
     ftk::klt_fill_geometry(p);  // patch / window / lattice geometry: everything that follows from the half sizes alone (ftk_device.h)
-    // Wavefronts per feature (measured on MI355X; 4096 wave slots at 4 waves per SIMD):
-    //  * small batches are latency-bound: up to 4 waves share the pixel loops (21x21 patch, <= 1024
-    //    features: 56 / 41 / 32 us per call at 1 / 2 / 4 waves);
-    //  * beyond ~1024 features 4-wave workgroups no longer fit the chip at once: 2 waves;
-    //  * beyond ~2048 features the call is throughput-bound; patches of <= 256 pixels then run best
-    //    with ONE wave per feature (no barriers, no redundant uniform work: 25 000 features at 13x13
-    //    take 252 us instead of 346 us), larger patches keep 2 waves (the chain / sampling overlap
-    //    still pays), and so do the non-fast affine variants (24 chains per feature).
-    // These three rules were made at 13 x 13 and 21 x 21 for Basic KLT; the blocks below refine them per variant and patch size from the
-    // sweeps of round 4 (scripts/wave_policy_sweep*.sh, profiles/r4_wave_policy_sweep.txt: every variant x 9 x 9 ... 21 x 21 x 200 ... 6 000
-    // features x 1 - 4 waves).  Whatever is chosen here changes the launch shape only, never a result.
-    int waves = (p.P + 63) / 64;
-    if (waves > 4) {
-        waves = 4;
-    }
-    if (n > 1024 && waves > 2) {
-        // Four-wave features fill the chip's 4 096 wave slots at 1 024.  THREE-wave features (13 x 13) stay up to 1 536 — six per CU — for
-        // the variants whose sweep shows it (scripts/wave_policy_sweep4.sh, three against two waves at 1 100 / 1 250 / 1 350 / 1 450 / 1 550
-        // features: LSSD fast -7 / -9 / -8 / -9 / +31 %, LSSD direct -15 / -14 / -14 / -14 / +9 %, affine direct -13 / -12 / -20 / -11 / +14 %,
-        // Basic direct -7 / -6 / -7 / -6 / -5 %; affine inverse +0 ... +5 % and the pipelined Basic inverse kernel keep two).
-        const bool nonfast = opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT;
-        const bool three_pays = (model == FTK_MODEL_LSSD && !nonfast && !p.consider_luminance) || (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) ||
-                                (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_DIRECT) || (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT);
-        // (15 x 15, four waves: the same at 1 200 features, LSSD -8 ... -10 %, affine direct -20 %: kept up to 1 280)
-        if (!(three_pays && !p.tree && ((waves == 3 && n <= 1536) || (waves == 4 && n <= 1280 && p.P <= 256)))) {
-            waves = 2;
-        }
-    }
-    if (n > 2048 && p.P <= 256 && !(model == FTK_MODEL_AFFINE && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT))) {
-        waves = 1;
-    }
-    // The non-fast LSSD variants sweep the patch twice per iteration (twelve taps a pixel) and Basic direct five current taps: they
-    // keep several waves per feature for longer (13 x 13, one / two / three waves: LSSD inverse 2 000 features 226 / 200 / 180 us,
-    // 3 000: 210 / 183 / 202, 5 000: 225 / 200 / 173, 10 000: 235 / 240 / 285; Basic direct 3 000: 41.6 / 34.9 / 47.8, 10 000: 89 / 111 / 133).
-    if (p.P > 64 && p.P <= 256 && (opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT)) {
-        if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_INVERSE) {
-            waves = n <= 2048 ? (p.P > 128 ? 3 : 2) : (n <= 6144 ? 2 : 1);
-        } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_DIRECT) {
-            waves = n <= 1536 ? waves : (n <= 4096 ? 2 : 1);  // (waves: three up to 1 536 features, above)
-        } else if (model == FTK_MODEL_LSSD && opt->method == FTK_METHOD_DIRECT) {
-            // (scripts/wave_policy_sweep2.sh, one / two waves: 2 400 features 190 / 155 us, 3 000: 258 / 243, 4 000: 200 / 178, 5 000: 188 / 159,
-            // 6 000: 177 / 189, 8 000: 225 / 261)
-            // (9 x 9 and 11 x 11, scripts/wave_policy_sweep7.sh: at 6 000 features two waves are still 14 - 23 % ahead)
-            waves = n <= 2048 ? waves : (n <= (p.P <= 128 ? 7168 : 5632) ? 2 : 1);
-        }
-    }
-    // LSSD fast with consider_patch_luminance: the chunked one-wave level that keeps a lane's sampled values in registers between the mean
-    // pass and the product pass beats the generic kernel's TWO waves wherever those would be chosen (13 x 13, one / two / three waves:
-    // 1 200 features 123 / 147 / 130 us, 1 600: 138 / 159 / 182, 2 000: 142 / 154 / 202; up to 1 024 features three waves and one wave are
-    // within 2 % of each other and the default stays)
-    if (model == FTK_MODEL_LSSD && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && p.consider_luminance && !p.tree && p.P <= 256 &&
-        n > 1024 && waves == 2) {
-        waves = 1;
-    }
-    // Small patches (9 x 9, 11 x 11: two waves by pixel count): LSSD fast is 5 - 15 % faster on its chunked one-wave level from 600
-    // features on (scripts/wave_policy_sweep7.sh: 1 500 features 67 -> 59 and 70 -> 61 us); every other variant sits on its best column there.
-    if (model == FTK_MODEL_LSSD && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && p.P <= 128 && n > 512 && waves == 2 && !p.tree) {
-        waves = 1;
-    }
-    // Large patches (from about 20 x 20; swept at 21 x 21, scripts/wave_policy_sweep5.sh): a feature's per-pixel arrays then take so much
-    // LDS that few features fit a CU whatever their wave count, and the "two waves beyond 1 024 features" rule — made for 13 x 13 — only
-    // halves the lanes that share a feature's pixel loops.  Four against two waves at 1 200 / 2 000 / 3 000 / 5 000 features: affine direct
-    // 128 / 250 / 341 / 382 against 243 / 475 / 579 / 558 us, affine inverse 175 / 172 / 309 / 385 against 251 / 220 / 410 / 489, LSSD direct
-    // -14 ... -18 %, LSSD inverse -11 ... -15 %, affine fast (generic kernel, up to 2 048 features) -22 %.  LSSD fast: four waves up to
-    // 1 536 features (88 against 100 us at 1 200), beyond that the chunked ONE-wave level (2 000 features 114 against 169 us, 5 000: 229
-    // against 285; with luminance 237 against 345 and 381 against 519) where the patch allows it.  Basic KLT keeps its rules (mixed).
-    if (p.P > 384 && n > 1024 && !p.tree) {
-        const bool nonfast = opt->method == FTK_METHOD_INVERSE || opt->method == FTK_METHOD_DIRECT;
-        if ((model == FTK_MODEL_AFFINE || model == FTK_MODEL_LSSD) && nonfast) {
-            waves = 4;
-        } else if (model == FTK_MODEL_LSSD) {
-            waves = (n > 1536 && (!p.consider_luminance || p.P <= 512)) ? 1 : 4;
-        } else if (model == FTK_MODEL_AFFINE && n <= 2048) {
-            waves = 4;
-        }
-    }
-    // Between the two (15 x 15 and 17 x 17 swept, scripts/wave_policy_sweep6.sh; 1 200 / 2 000 / 3 000 features): affine direct wants four
-    // waves at every count (15 x 15: 75 / 142 / 179 against 94 / 206 / 229 us on two; 17 x 17: 116 / 159 / 121 against 175 / 228 / 146), affine
-    // inverse three (17 x 17: -19 / -17 / -11 %, 15 x 15: -5 / -6 / -7 %), affine fast on the generic kernel three (17 x 17: -10 %); LSSD fast
-    // beyond 2 048 features its chunked one-wave level also above 256 pixels (17 x 17, 3 000 features: 138 -> 103 us, with luminance
-    // 310 -> 225), and the pipelined Basic inverse kernel one wave from 17 x 17 x 3 000 on (63 -> 46 us).
-    if (p.P > 192 && p.P <= 384 && n > 1024 && !p.tree) {
-        const bool fast_like_m = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
-        if (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_DIRECT) {
-            waves = 4;
-        } else if (model == FTK_MODEL_AFFINE && opt->method == FTK_METHOD_INVERSE) {
-            waves = 3;
-        } else if (model == FTK_MODEL_AFFINE && fast_like_m && p.P > 256 && n <= 2048) {
-            waves = 3;
-        } else if (model == FTK_MODEL_LSSD && fast_like_m && p.P > 256 && n > 2048) {
-            waves = 1;
-        } else if (model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.P > 256 && p.P <= 324 && n > 2560) {
-            waves = 1;
-        }
-    }
-    // Tail-aware (round 5).  The ladder above was swept on a scene whose features all take the same five iterations; a real frame
-    // holds a few that never converge and run kMaxIteration iterations on every level, and a call of a few thousand features then lasts
-    // as long as its slowest one (the reference's example pair, Basic inverse: 44 iterations at 2 000 features).  For such a feature
-    // the pipelined Basic-inverse kernel is fastest with ONE wave — produce a chunk, chain it, no barrier, no hand-off (same box,
-    // default / one wave: 300 features 63.5 / 60.0 us, 1 200: 81.0 / 73.0, 2 000: 84.2 / 76.8) — while level entries, which more waves
-    // share, dominate the short calls.  The kernels report each call's longest feature (klt_common.h tail_report); when this
-    // variant's recent calls had one of kTailLongFrom iterations or more, the call runs one wave per feature.
+    // Wavefronts per feature: DATA, not rules (round 5).  csrc/klt_wave_policy.inc is generated by
+    // scripts/make_wave_policy.py from one committed sweep (scripts/wave_policy_sweep.py -> profiles/r5_wave_policy_sweep.jsonl:
+    // every variant x 9 x 9 ... 21 x 21 x 300 ... 16 000 features x one to four waves, on the synthetic scene and on the reference's
+    // example pair) and holds, per (variant, tail class, pixel bucket, feature bucket), the wave count that measured fastest.  The
+    // kernel forms follow from the count (below): one wave = the one-wave kernels (klt_fast_kernels.hip, the chunked LSSD levels, the
+    // pipelined Basic kernel's solo form), more = the multi-wave forms.  tests/test_wave_policy_gpu.py times cells of every variant
+    // and fails when the table's column is more than 10 % off the best.  Whatever is chosen changes the launch shape only, never a
+    // result.
+    //
+    // Tail class: the table was swept on two kinds of scene — every feature done after a handful of iterations, and real frames in
+    // which a few features never converge and run kMaxIteration iterations on every level, so that a call of a few thousand features
+    // lasts as long as its slowest one.  The kernels report each call's longest feature (klt_common.h tail_report); a variant whose
+    // recent calls had one of kTailLongFrom iterations or more is looked up in the long-tail half of the table.
     p.long_tail = 0;
     if (ctx && ctx->tail_host && !ftk_env::off(FTK_ENV(ctx, klt_tail)) && model >= 0 && model < 3) {
         const int mi = opt->method == FTK_METHOD_INVERSE ? 0 : (opt->method == FTK_METHOD_DIRECT ? 1 : 2);
@@ -357,9 +301,14 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             fprintf(stderr, "[ftk tail] model %d method %d launch %u (context launch %u): host word call %u iterations %u, long_until %u -> long_tail %d\n", model, mi,
                     ts.launches, ctx->tail_call, seen >> 8, seen & 0xFFu, ts.long_until, p.long_tail);
         }
-        if (p.long_tail && model == FTK_MODEL_BASIC && opt->method == FTK_METHOD_INVERSE && p.P <= 256 && p.patch_rows <= 64 && p.patch_cols <= 64 && !p.tree) {
-            waves = 1;
-        }
+    }
+    if (const char *env = FTK_ENV(ctx, klt_tail_class)) {
+        p.long_tail = atoi(env) != 0 ? 1 : 0;  // experiment override (the sweep and the policy test pin the class)
+    }
+    const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
+    int waves = ftk::klt_policy_waves(model, fast_like ? 2 : (opt->method == FTK_METHOD_DIRECT ? 1 : 0), p.consider_luminance, p.long_tail, p.P, n);
+    if (p.tree && waves == 1 && fast_like && model != FTK_MODEL_LSSD) {
+        waves = std::min(4, std::max(2, (p.P + 63) / 64));  // the throughput mode has no one-wave fast kernel: the generic kernel's waves
     }
     if (const char *env = FTK_ENV(ctx, klt_waves)) {
         waves = atoi(env);  // experiment override
@@ -407,8 +356,8 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
     // through a ring, the later ones six whole rows) from 512 features on: 13 x 13, same box, one wave / generic kernel: 1 000
     // features 34.7 / 36.9 us, 2 000: 77.0 / 83.6, 3 000: 66.0 / 108.3, 5 000: 80.5 / 128.9 — and 100: 83.8 / 75.0, 300: 56.9 / 53.4:
     // a small call IS its slowest feature (31 iterations here), and that one runs 10 % faster on the generic kernel's three waves.
-    const bool fk_model = model == FTK_MODEL_BASIC || (model == FTK_MODEL_AFFINE && n > 512);
-    if (fk_model && opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT && !p.tree && (p.P <= 256 || (n > 2048 && p.P <= 1024))) {
+    const bool fk_model = model == FTK_MODEL_BASIC || model == FTK_MODEL_AFFINE;
+    if (fk_model && fast_like && !p.tree && p.waves_per_feature == 1 && p.P <= 1024) {  // (the policy table chose ONE wave: the one-wave kernel)
         bool small = true;
         for (int i = 0; i < p.n_levels; ++i) {
             small = small && p.ref[i].rows < (1 << 23) && p.ref[i].cols < (1 << 23) && p.cur[i].rows < (1 << 23) && p.cur[i].cols < (1 << 23);
@@ -438,7 +387,6 @@ int fill_klt_params(ftk_context *ctx, int model, const ftk_klt_options *opt, con
             p.a0_floats = 0;
         }
     }
-    const bool fast_like = opt->method != FTK_METHOD_INVERSE && opt->method != FTK_METHOD_DIRECT;
     const char *chunk_env = FTK_ENV(ctx, lssd_chunked);
     // (with consider_patch_luminance: the variant that keeps the sampled values in registers — patches up to 512 pixels, klt_kernels.hip kLumChunks)
     if (model == FTK_MODEL_LSSD && fast_like && p.waves_per_feature == 1 && (!p.consider_luminance || (p.P <= 512 && !p.tree)) && !(chunk_env && atoi(chunk_env) == 0)) {

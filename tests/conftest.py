@@ -43,7 +43,10 @@ def switch():
 
     def set_switch(name, value):
         saved.setdefault(name, os.environ.get(name))
-        os.environ[name] = str(value)
+        if value is None:
+            os.environ.pop(name, None)  # unset
+        else:
+            os.environ[name] = str(value)
         F.refresh_env_switches()
 
     yield set_switch
