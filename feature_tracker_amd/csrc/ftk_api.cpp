@@ -211,6 +211,13 @@ int klt_policy_waves(int model, int method_class, int consider_luminance, int lo
 
 namespace {
 
+// Direct method: batches up to this size are spread over the chip (1 + NP workgroups per problem), while at least so many producer
+// workgroups per problem fit beside the others.  Larger batches were measured spread as well (round 5, scripts/direct_batch_time.py,
+// 300 points x 13 x 13 x 4 levels, spread / one workgroup each: 6 problems 1.67 / 1.84 ms, 8: 2.08 / 1.84, 12: 2.28 / 1.86, 16: 2.69 /
+// 1.86, 30: 4.14 / 1.87): with fewer than about 30 producers per consumer the hand-offs through L2 cost more than the idle compute
+// units were worth — from seven problems on one workgroup per problem IS the fast form, and its time is one problem's.
+constexpr int kDirectSpreadMaxProblems = 6;
+constexpr int kDirectSpreadMinProducers = 8;
 constexpr uint32_t kTailLongFrom = 24;  // iterations of a call's longest feature from which the call counts as tail-bound
 constexpr uint32_t kTailHold = 8;       // launches of the variant for which one such report holds
 constexpr uint32_t kTailFresh = 256;    // launches of the context a report may lag behind (the host enqueues far ahead of the device)
@@ -2185,7 +2192,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         if (const char *min_env = FTK_ENV(ctx, direct_spread_min_terms)) {
             min_terms = atoll(min_env);  // tests: spread even tiny problems (producers whose waves own no chunk)
         }
-        bool spread = producers > 0 && !ctx->direct_spread_off && n_problems <= 6 && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global &&
+        bool spread = producers > 0 && !ctx->direct_spread_off && n_problems <= kDirectSpreadMaxProblems && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global &&
                       max_features > 0 && terms >= min_terms && terms < (1ll << 31);
         if (spread) {
             // Every workgroup of the launch must be resident at once (consumer and producers wait for each other): size the producers from
@@ -2202,7 +2209,7 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
             const int usable = resident - resident / 8;
             const int fit = usable / n_problems - 1;
             producers = std::min(producers, fit);
-            spread = producers >= 8 || (env && producers >= 1 && producers == std::min(atoi(env), fit));  // (an explicit FTK_DIRECT_SPREAD=n < 8 that fits is honoured: tests)
+            spread = producers >= kDirectSpreadMinProducers || (env && producers >= 1 && producers == std::min(atoi(env), fit));  // (an explicit FTK_DIRECT_SPREAD=n that fits is honoured: tests)
         }
         size_t ws = 0;
         if (spread) {

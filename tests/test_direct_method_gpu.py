@@ -161,9 +161,9 @@ def test_world_frame_overload(ftk, oracle):
     assert np.array_equal(p_wc.view(np.uint32), (oracle.quat_rotate(ref_q, p_rc) + ref_p).astype(np.float32).view(np.uint32))
 
 
-@pytest.mark.parametrize("sizes", [(300, 300), (300, 1, 0, 120), (40, 260, 500)])
+@pytest.mark.parametrize("sizes", [(300, 300), (300, 1, 0, 120), (40, 260, 500), (300, 280, 260, 240, 220, 200, 180, 160, 140, 120, 100, 80), tuple([150] * 30)])
 def test_small_batches_of_problems_match_the_oracle_problem_by_problem(ftk, oracle, sizes):
-    """ftk_direct_track_batch_device with two to four problems of different sizes (one of a single feature, one empty): on the default
+    """ftk_direct_track_batch_device with two to thirty problems of different sizes (one of a single feature, one empty): on the default
     dispatch each problem is spread over its own group of workgroups with its own workspace; every problem's pose, positions, status
     and iteration count must be those of the oracle run on that problem alone."""
     import torch
