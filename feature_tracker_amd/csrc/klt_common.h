@@ -1041,27 +1041,27 @@ __device__ __forceinline__ float chain_quads_left(float acc, const float *quad_r
     return chain_quad_step16(acc, q0);
 }
 
-// A whole row of `n16` 16-term steps (n16 >= 1, wave-uniform): two register pairs, the reads two steps ahead of the adds.
-__device__ __forceinline__ float chain_quads_row(float acc, const float *quad_row, int n16) {
-    const float4 *t = reinterpret_cast<const float4 *>(quad_row);
-    float4 qa = t[0], qb = t[n16 > 1 ? 4 : 0], qc, qd;
+// `n16` 16-term steps (n16 >= 1, wave-uniform) from `t_lane` = this lane's first float4, consecutive steps `step4` float4 apart: two
+// register pairs, the reads two steps ahead of the adds.
+__device__ __forceinline__ float chain_quads_strided(float acc, const float4 *t, int n16, int step4) {
+    float4 qa = t[0], qb = t[n16 > 1 ? step4 : 0], qc, qd;
     int j = 0;
 #pragma nounroll
     for (; j + 4 <= n16; j += 4) {
-        qc = t[(j + 2) * 4];
-        qd = t[(j + 3) * 4];
+        qc = t[(j + 2) * step4];
+        qd = t[(j + 3) * step4];
         __builtin_amdgcn_sched_barrier(0);
         acc = chain_quad_step16(acc, qa);
         acc = chain_quad_step16(acc, qb);
-        qa = t[(j + 4 < n16 ? j + 4 : 0) * 4];  // (wave-uniform selects; a read past the row's end is never made)
-        qb = t[(j + 5 < n16 ? j + 5 : 0) * 4];
+        qa = t[(j + 4 < n16 ? j + 4 : 0) * step4];  // (wave-uniform selects; a read past the end is never made)
+        qb = t[(j + 5 < n16 ? j + 5 : 0) * step4];
         __builtin_amdgcn_sched_barrier(0);
         acc = chain_quad_step16(acc, qc);
         acc = chain_quad_step16(acc, qd);
     }
     const int rem = n16 - j;  // 0 .. 3 steps left; qa / qb hold the first two
     if (rem > 2) {
-        qc = t[(j + 2) * 4];
+        qc = t[(j + 2) * step4];
         __builtin_amdgcn_sched_barrier(0);
     }
     if (rem > 0) {
@@ -1074,6 +1074,11 @@ __device__ __forceinline__ float chain_quads_row(float acc, const float *quad_ro
         acc = chain_quad_step16(acc, qc);
     }
     return acc;
+}
+
+// A whole row [n16 * 16 terms] of one sum: `quad_row` = the row + 4 * (lane & 3) floats.
+__device__ __forceinline__ float chain_quads_row(float acc, const float *quad_row, int n16) {
+    return chain_quads_strided(acc, reinterpret_cast<const float4 *>(quad_row), n16, 4);
 }
 
 constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked sweep / chain loops = one wave round

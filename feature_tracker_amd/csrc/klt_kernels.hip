@@ -903,6 +903,8 @@ __device__ __forceinline__ void affine_level(const Blk &b, const KltParams &p, c
             publish_count(b, n_valid, c.wave_cnt, iter);
             blk_sync(b);  // the terms (and the published counts) are visible
             FTK_STAMP_END(b, 3);
+            // (The 24 sums as quad chains on TWO waves side by side — 16 + 8 quads, published through LDS, one more barrier — were built
+            // and measured in round 5: slower, config 3 139.8 -> 149.1 us, real pair 300 features 89.1 -> 91.1; docs/LAB_NOTES.md.)
             if (b.wave == 0 && b.lane < A_COUNT) {
                 acc = chain_groups<kAffineGroup / 4>(reinterpret_cast<const float4 *>(c.terms) + b.lane, affine_group_rounds(p.Ppad), 0.0f);
             }

@@ -44,6 +44,11 @@ def main():
             print(f"== {spec}: mean iterations {it.mean():.1f}, max {it.max()}")
             for i in np.argsort(-it)[:3]:
                 s = a[i]
+                generic = not (model == "basic" and method in ("inverse",))
+                if generic:
+                    print(f"  feature {i}: {it[i]} iterations, total {s[7]:.0f} ticks; slots (ref_stage setup cur_stage phaseA count chain solve): " + " ".join(f"{x:.0f}" for x in s[:7]) +
+                          f"; per iteration: phaseA {s[3] / it[i]:.0f} count {s[4] / it[i]:.0f} chain {s[5] / it[i]:.0f} solve {s[6] / it[i]:.0f} window {s[2] / it[i]:.0f} rest {(s[7] - s[:7].sum()) / it[i]:.0f} total {s[7] / it[i]:.0f}")
+                    continue
                 inside = s[0] + s[1] + s[2] + s[3] + s[5]
                 print(f"  feature {i}: {it[i]} iterations, total {s[7]:.0f} ticks; slots 0..5: {s[0]:.0f} {s[1]:.0f} {s[2]:.0f} {s[3]:.0f} [{s[4]:.0f}] {s[5]:.0f}; outside the slots {s[7] - inside:.0f}; "
                       f"per iteration: slot2 {s[2] / it[i]:.0f} slot3 {s[3] / it[i]:.0f} slot5 {s[5] / it[i]:.0f} rest {(s[7] - inside) / it[i]:.0f} total {s[7] / it[i]:.0f}")
