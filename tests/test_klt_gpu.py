@@ -775,3 +775,74 @@ def test_position_keyed_trades_of_launch_slots_process_every_feature_once(ftk, o
     assert int(it.max()) >= 20, "the scene has no long feature: nothing to trade"
     trades, own = (int(x) for x in dump.read_text().split())
     assert trades > 0, "no early slot traded places with a late one"
+
+
+def _real_pair():
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = np.ascontiguousarray(np.array(Image.open(os.path.join(root, "tests", "data", "optical_flow", "ref_image.png")).convert("L"), dtype=np.uint8))
+    cur = np.ascontiguousarray(np.array(Image.open(os.path.join(root, "tests", "data", "optical_flow", "cur_image.png")).convert("L"), dtype=np.uint8))
+    return synth.build_pyramid(ref, 4), synth.build_pyramid(cur, 4)
+
+
+@pytest.mark.parametrize("model,method", [(m, k) for m in MODELS for k in METHODS])
+def test_real_pair_both_tail_classes_and_the_early_launch_order_change_nothing(ftk, oracle, model, method, switch):
+    """Round 5's launch policies on the reference's example pair (features that never converge: the calls have a long tail): the
+    kernels report each call's longest feature, a variant with long calls is looked up in the long-tail half of the wave-policy
+    table (klt_wave_policy.inc) and gets the longest-first launch order from 1 024 features on.  Both halves of the table (pinned with
+    FTK_KLT_TAIL_CLASS), the class the library detects by itself over repeated calls, and the order switched on and off must all
+    return the oracle's bits — on a list whose features are passed through in places (incoming status, kMaxTrackPointsNumber)."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = _real_pair()
+    n, cap, half = 1500, 1450, 6
+    rows, cols = ref_levels[0].shape
+    rs = np.random.RandomState(5)
+    uv = np.stack([rs.uniform(30, cols - 30, n), rs.uniform(30, rows - 30, n)], axis=1).astype(np.float32)
+    status = (np.arange(n) % 13 == 0).astype(np.uint8) * 2
+    ok, c, s, _ = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, uv, status, method=method, half=half, max_points=cap)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, half, half, cap
+    for tail_class, sched_min in ((None, None), ("0", None), ("1", None), (None, "100000"), ("1", "1024")):
+        switch("FTK_KLT_TAIL_CLASS", tail_class)
+        switch("FTK_KLT_SCHED_MIN", sched_min)
+        with torch.cuda.stream(stream):
+            ctx = D.context_on_stream(stream, 0)
+            klt = D.DeviceKlt(model, opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+            d_ref, d_st = torch.from_numpy(uv).to(dev), torch.from_numpy(status).to(dev)
+            for call in range(5):  # the tail class and the launch order settle over the first calls: every one of them must be right
+                d_out, d_so = torch.full_like(d_ref, -7.0), torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                klt.track(d_ref, d_ref.clone(), d_st, d_out, d_so)
+                stream.synchronize()
+                what = f"{model}/{method} tail class {tail_class} order from {sched_min}, call {call}"
+                assert np.array_equal(d_so.cpu().numpy(), s), what
+                assert np.array_equal(d_out.cpu().numpy().view(np.uint32), c.view(np.uint32)), what
+
+
+def test_pair_arrays_at_an_odd_float_offset_are_refused(ftk):
+    """The kernels move a feature's (u, v) as one 8-byte access (include/ftk.h): a device pair array that is only 4-byte aligned is an
+    FTK_E_INVALID_ARGUMENT, not a misaligned 64-bit access on the device."""
+    import torch
+    from feature_tracker_amd import device as D
+    from feature_tracker_amd._native import FtkError
+    ref_levels, cur_levels = scenes.scene(320, 240, 3)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        opt = ftk.OpticalFlowOptions()
+        opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = "inverse", 5, 5, 64
+        klt = D.DeviceKlt("basic", opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        flat = torch.zeros(2 * 64 + 2, dtype=torch.float32, device=dev)
+        odd = flat[1:129].view(64, 2)  # starts one float into the allocation: 4-byte aligned only
+        good = torch.full((64, 2), 100.0, dtype=torch.float32, device=dev)
+        st, so = torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(64, dtype=torch.uint8, device=dev)
+        for args in ((odd, good, good.clone()), (good, odd, good.clone()), (good, good.clone(), odd)):
+            with pytest.raises(FtkError) as err:
+                klt.track(args[0], args[1], st, args[2], so)
+            assert err.value.code == -1 and "8-byte aligned" in str(err.value)
+        klt.track(good, good.clone(), st, good.clone(), so)  # the aligned call goes through
+        stream.synchronize()
