@@ -15,4 +15,5 @@ for name in ("config1", "config2"):
         ts = []
         for _ in range(200):
             t0 = time.perf_counter(); ok, c, s = klt.TrackFeatures(rp, cp, uv); ts.append(time.perf_counter() - t0)
-        print(name, "n", n, "host call median us", round(np.median(ts) * 1e6, 1), "tracked", float((s == 1).mean()))
+        print(name, "n", n, "host call median us", round(np.median(ts) * 1e6, 1), "p10", round(np.percentile(ts, 10) * 1e6, 1), "tracked", float((s == 1).mean()),
+              "checksum", int(np.ascontiguousarray(c).view(np.uint32).astype(np.uint64).sum()))
