@@ -1194,9 +1194,11 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
     float *icur = c.a0;
     for (uint32_t iter = 0; iter < p.max_iteration; ++iter) {
         ++iters;
+        FTK_STAMP_BEGIN(b);
         float centre_u, centre_v;
         se2_apply(s, ref_u, ref_v, centre_u, centre_v);
         ensure_cur_window(b, p, cur, centre_u, centre_v, c, cw, cw_staged);
+        FTK_STAMP_END(b, 2);
         // pass 1 (:140-184): validity mask and the two patch means (sequential sums)
         uint32_t n_valid = 0;
         bool miss_unused = false;
@@ -1223,8 +1225,10 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
             }
             n_valid += (uint32_t)__popcll(wave_ballot(ok));
         }
+        FTK_STAMP_END(b, 3);  // pass 1: sampling, the two mean terms
         n_valid = block_total(b, n_valid, c.wave_cnt);
         chain_sums(b, c.terms, 2, p.Ppad, c.sums);
+        FTK_STAMP_END(b, 4);  // count exchange + the two mean chains
         const float ref_average = c.sums[0] / (float)n_valid;
         const float cur_average = c.sums[1] / (float)n_valid;
         const float grad_average = (METHOD == FTK_METHOD_INVERSE) ? ref_average : cur_average;
@@ -1248,10 +1252,12 @@ __device__ __forceinline__ void lssd_level(const Blk &b, const KltParams &p, con
             lssd_terms(p, c.terms, pxi, ok, j0, j1, j2, residual);
         }
         blk_sync(b);
+        FTK_STAMP_END(b, 5);  // pass 2: divisions by the means, nine products
         if (n_valid == 0) {
             break;
         }
         chain_then(b, c.terms, 9, p.Ppad, c.sums, false, [&]() { lssd_solve(c.sums, b.lane); });
+        FTK_STAMP_END(b, 6);  // nine chains + the 3 x 3 solve
         float v[3];
         const bool solved = lssd_solve_and_update(c.sums, s, v, status, b.lane);
         blk_sync(b);  // sums[] is rewritten by the first chain of the next iteration
