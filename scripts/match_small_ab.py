@@ -34,7 +34,7 @@ def main():
                     out, want = {}, None
                     for small in ("0", "1"):
                         os.environ["FTK_MATCH_SMALL"] = small
-                        F.refresh_env_switches()  # the switches are read once per context
+                        ctx.refresh_env()  # the switches are read once per context
                         d_idx = torch.full((n_ref,), -1, dtype=torch.int32, device=dev)
                         args = dict(pred_uv=pred_uv if nearby else None, cur_uv=cur_uv if nearby else None, max_col=60, max_row=60)
                         for _ in range(3):

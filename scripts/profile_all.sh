@@ -24,7 +24,7 @@ for W in $WORKLOADS; do
     CMD="python3 $ROOT/scripts/bench_configs.py --only match --quick"
   else
     # (the legs that launch OTHER workloads or isolated calls are off: the trace average of the workload's kernel is then the back-to-back figure bench.py times)
-    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline --no-upload-leg --no-tree-leg --no-configs-leg --no-host-call-leg"
+    CMD="python3 $ROOT/bench.py --workload $W --steps 30 --warmup 3 --no-cpu-baseline --no-upload-leg --no-tree-leg --no-configs-leg --no-host-call-leg --no-real-images-leg"
   fi
   echo "== $W: trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $CMD > "$D/trace_stdout.log" 2>&1 || echo "trace failed: $W" >> "$OUT/errors.log"

@@ -24,7 +24,7 @@ elif [ "$PART" = B ]; then
   bash scripts/profile_all.sh r5 > $O/profile_all.log 2>&1; echo "profile rc=$?"
   bash scripts/trace_all_kernels.sh > $O/trace_all.log 2>&1; cp gpurun_out/all_kernels_stats.csv $O/ 2>/dev/null; echo "trace all rc=$?"
 elif [ "$PART" = C ]; then
-  python scripts/soak_parity.py 400 2028 > $O/soak_parity.txt 2>&1; echo "soak rc=$?"
+  python scripts/soak_parity.py 360 2029 > $O/soak_parity.txt 2>&1; echo "soak rc=$?"
   python scripts/soak_parity.py 100 41 matcher > $O/soak_matcher.txt 2>&1; echo "soak matcher rc=$?"
   bash scripts/run_dropin_programs.sh > $O/dropin_programs.txt 2>&1; echo "dropin rc=$?"
   PYTHONPATH=. python scripts/host_call_latency.py > $O/host_call_latency.txt 2>&1; echo "host latency rc=$?"
