@@ -846,3 +846,33 @@ def test_pair_arrays_at_an_odd_float_offset_are_refused(ftk):
             assert err.value.code == -1 and "8-byte aligned" in str(err.value)
         klt.track(good, good.clone(), st, good.clone(), so)  # the aligned call goes through
         stream.synchronize()
+
+
+@pytest.mark.parametrize("model,method", [("lssd", "fast"), ("affine", "inverse"), ("lssd", "inverse")])
+def test_position_keyed_order_below_4096_features_on_a_changing_list(ftk, oracle, model, method, switch):
+    """With a long tail the launch order applies from 1 024 features on (round 5) — also the position-keyed one a call gets when the
+    feature COUNT has just changed (a front end that drops and re-detects features): lists of 1 500, 1 400, 1 600, 1 450 features of
+    the reference's pair, frame after frame on one tracker, every result the oracle's."""
+    import torch
+    from feature_tracker_amd import device as D
+    ref_levels, cur_levels = _real_pair()
+    rows, cols = ref_levels[0].shape
+    rs = np.random.RandomState(11)
+    switch("FTK_KLT_TAIL_CLASS", "1")
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    opt = ftk.OpticalFlowOptions()
+    opt.kMethod, opt.kPatchRowHalfSize, opt.kPatchColHalfSize, opt.kMaxTrackPointsNumber = method, 6, 6, 100000
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        klt = D.DeviceKlt(model, opt, D.upload_pyramid(ref_levels, ctx, dev), D.upload_pyramid(cur_levels, ctx, dev), ctx)
+        pool = np.stack([rs.uniform(30, cols - 30, 1700), rs.uniform(30, rows - 30, 1700)], axis=1).astype(np.float32)
+        for n in (1500, 1400, 1600, 1450, 1450):
+            uv = np.ascontiguousarray(pool[rs.permutation(1700)[:n]])
+            d_ref = torch.from_numpy(uv).to(dev)
+            d_out, d_so = torch.full_like(d_ref, -3.0), torch.full((n,), 7, dtype=torch.uint8, device=dev)
+            klt.track(d_ref, d_ref.clone(), torch.zeros(n, dtype=torch.uint8, device=dev), d_out, d_so)
+            stream.synchronize()
+            ok, c, s, _ = oracle.klt_track_pyramid(model, ref_levels, cur_levels, uv, method=method, half=6, max_points=100000)
+            assert np.array_equal(d_so.cpu().numpy(), s), (model, method, n)
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint32), c.view(np.uint32)), (model, method, n)
