@@ -143,6 +143,57 @@ __device__ __forceinline__ float dm_chain_chunk(float acc, const float *row) {
     return acc;
 }
 
+// The spread kernel's chain: a QUAD of lanes per sum (klt_common.h, chain_quad_step16 — the same left-to-right sum, 16 terms per
+// ds_read_b128 and 4.84 cycles per term instead of one lane's ~7).  `t`: this lane's first float4 of the round's first chunk (row of
+// its sum, floats 4 (lane & 3) ..); a chunk's 64 terms are four steps of 16, the chunks of a round lie kDmTerms rows apart.  The
+// reads of chunk w + 1 are issued before chunk w's 64 adds; with kChunks a constant the loop unrolls and every address is an
+// immediate offset of one base register (6 chunks x 7 344 B < 64 KB).
+constexpr int kDmChunkStep4 = kDmTerms * kDmRow / 4;  // float4 from one chunk of the ring to the next
+__device__ __forceinline__ void dm_quad_reads(float4 (&a)[4], const float4 *t) {
+    a[0] = t[0];
+    a[1] = t[4];
+    a[2] = t[8];
+    a[3] = t[12];
+}
+__device__ __forceinline__ float dm_quad_adds(float acc, const float4 (&a)[4]) {
+    acc = chain_quad_step16(acc, a[0]);
+    acc = chain_quad_step16(acc, a[1]);
+    acc = chain_quad_step16(acc, a[2]);
+    return chain_quad_step16(acc, a[3]);
+}
+template <int kChunks>
+__device__ __forceinline__ float dm_chain_quads_round(float acc, const float4 *t) {
+    float4 a[4], b[4];
+    dm_quad_reads(a, t);
+#pragma unroll
+    for (int w = 0; w < kChunks; w += 2) {
+        if (w + 1 < kChunks) {
+            dm_quad_reads(b, t + (w + 1) * kDmChunkStep4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = dm_quad_adds(acc, a);
+        if (w + 2 < kChunks) {
+            dm_quad_reads(a, t + (w + 2) * kDmChunkStep4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (w + 1 < kChunks) {
+            acc = dm_quad_adds(acc, b);
+        }
+    }
+    return acc;
+}
+// (the stream's last round: any number of chunks)
+__device__ __forceinline__ float dm_chain_quads_tail(float acc, const float4 *t, int chunks) {
+    float4 a[4];
+#pragma nounroll
+    for (int w = 0; w < chunks; ++w) {
+        dm_quad_reads(a, t + w * kDmChunkStep4);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = dm_quad_adds(acc, a);
+    }
+    return acc;
+}
+
 // ---- pieces shared by the one-workgroup kernel and the spread kernel (same arithmetic by construction) ----
 
 // Per level: the part of feature i's terms that does not change with the pose -> feat[4 i].w, feat[4 i + 1 .. 3]
@@ -237,8 +288,10 @@ __device__ __forceinline__ void dm_term(const float4 *feat, const DirectParams &
 }
 
 // wave 0: the 27 sums (lane k < 27 holds sum k) -> full symmetric H in LDS -> lane-parallel LDLT (klt_common.h) -> dx at sums[68..74)
+// (kPublish = false: the sums already lie in sums[0 .. 27), written behind a barrier by the waves that chained them)
+template <bool kPublish = true>
 __device__ __forceinline__ void dm_solve(float *sums, float acc, int lane) {
-    if (lane < kDmTerms) {
+    if (kPublish && lane < kDmTerms) {
         sums[lane] = acc;
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic is ordered
@@ -474,16 +527,21 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
 // ---------------------------------------------------------------------------------------------------------------------------
 // ONE pose problem spread over the chip (exact sums).  The one-workgroup kernel above is bound by what a single compute unit can
 // issue per iteration — 793 chunks x ~390 producer instructions beside the 50 700-term chains (profiles/r4_pmc_direct.txt) — while
-// 255 compute units idle.  Here workgroup 0 is the CONSUMER and keeps only the sequential part: seven loader waves copy finished
-// chunks of products from device memory into the LDS ring, wave 0 adds them in stream order, solves and moves the pose.  Workgroups
-// 1 .. NP are PRODUCERS: per iteration each takes the pose the consumer published, projects the features, and its waves form the
-// 27 products of chunks w, w + 8 NP, ... (w = the wave's number over all producers: the first chunks of the stream come first).
+// 255 compute units idle.  Here workgroup 0 is the CONSUMER and keeps only the sequential part: six loader waves bring finished
+// chunks from device memory into the LDS ring, waves 0 and 1 add them in stream order (a quad of lanes per sum: sums 0 .. 15 and
+// 16 .. 26), wave 0 solves, everybody moves the pose.  Workgroups 1 .. NP are PRODUCERS: per iteration each takes the pose the
+// consumer published, projects the features, and its waves form the terms of chunks w, w + 8 NP, ... (w = the wave's number over all
+// producers: the first chunks of the stream come first).
+// What crosses the chip per term is the 1 x 6 Jacobian row and the residual — 7 floats, not the 27 products: the loader wave that
+// fetched them forms jac[r] * jac[c] and residual * jac[r] on its way into the ring, the same single-rounded fp32 products the
+// one-workgroup kernel forms, so the sums see the same 27 x 64 rows (1 792 B per chunk through the consumer's memory queue
+// instead of 6 912, a workspace of 1.4 MB instead of 5.5 MB at 300 points x 13 x 13, and a quarter of the producers' stores).
 //
 // Hand-offs (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): every handed-off byte is stored
 // AND loaded with agent-scope relaxed atomics (sc1: L2, never a stale L1 line); a storing wave waits for its stores (vmcnt(0))
 // before one lane stores the flag; the wave that polled a flag is the wave that loads what it guards.
 //   * consumer -> producers: pose[7] + level, then iter_tag = g + 1 (g counts iterations over all levels; 0xFFFFFFFF = leave);
-//   * producer wave -> consumer loader wave: the chunk's 27 x 64 products, then chunk_flag[c] = g + 1.
+//   * producer wave -> consumer loader wave: the chunk's 7 x 64 values (jac[0 .. 5], residual), then chunk_flag[c] = g + 1.
 // A chunk slot is rewritten only after the consumer has published the NEXT pose, i.e. after it has consumed the whole stream.
 // Every wait is BOUNDED (kSpreadMaxPolls): a wait that runs out poisons the pose with NaN and releases everybody — a bug or a
 // launch that cannot become co-resident ends in a wrong answer the caller sees, never in a hung device.
@@ -492,27 +550,40 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_kernel(const Di
 constexpr uint32_t kSpreadStop = 0xFFFFFFFFu;
 constexpr uint32_t kSpreadMaxPolls = 1u << 22;   // x (one L2 round trip + s_sleep) ~ seconds
 constexpr int kSpreadHeaderWords = 64;           // iter_tag, error, level, -, pose[7] ...
+constexpr int kSpreadValues = 7;                 // floats per term in the workspace: jac[0 .. 5], residual
+constexpr int kSpreadChainWaves = 2;             // 27 sums x 4 lanes
+constexpr int kSpreadLoaders = kDmWaves - kSpreadChainWaves;
+static_assert(kSpreadLoaders <= kDmProducers, "the LDS ring is sized for the one-workgroup kernel's rounds");
 
 __device__ __forceinline__ uint32_t spread_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void spread_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void spread_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The flag itself: a RELEASE store at agent scope after the storing wave has waited for its data stores, and an ACQUIRE fence in the
-// wave whose poll saw it (with relaxed flags the order of the guarded loads behind the poll rested on how gfx950 happens to
-// issue sc1 accesses, not on the memory model).  The data accesses stay relaxed agent-scope atomics.  -DFTK_SPREAD_FENCES=0: the
-// round-4 form, for A / B timing only.
+// The flag itself.  Default: a relaxed sc1 store behind the storing wave's own `s_waitcnt vmcnt(0)` (every data store has been
+// acknowledged by the memory side before the flag store is issued), and in the polling wave the guarded sc1 loads behind the branch
+// on the polled value — MI355X_MICROARCH.md's second valid form for handed-off bytes that are ONLY ever touched by sc1 accesses: no
+// cache holds a copy that could be stale, a wave issues its memory instructions in order and nothing is issued past an unresolved
+// branch, and a compiler barrier on either side keeps the compiler from moving the accesses.  -DFTK_SPREAD_FENCES=1 makes
+// the flag store an agent-scope RELEASE and puts an agent-scope ACQUIRE fence behind the poll.  Same results, but on gfx950 these are
+// `buffer_wbl2 sc1` (a write-back of the XCD's L2) per produced chunk and `buffer_inv sc1` (an invalidate of it) per fetched chunk —
+// 800 of each per iteration: the loader's seven loads then take 800 - 900 ns instead of 320, the consumer waits for its loaders,
+// 1.32 -> 1.48 ms for one 300-point problem and 1.33 -> 1.72 ms for six side by side (profiles/r5_direct_spread_consumer.txt).  That
+// form stays a build switch; tests/test_direct_method_gpu.py and the soak compare the default build with the one-workgroup kernel.
 #ifndef FTK_SPREAD_FENCES
-#define FTK_SPREAD_FENCES 1
+#define FTK_SPREAD_FENCES 0
 #endif
 __device__ __forceinline__ void spread_publish(uint32_t *p, uint32_t v) {
 #if FTK_SPREAD_FENCES
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     spread_store(p, v);
 #endif
 }
 __device__ __forceinline__ void spread_acquired() {
 #if FTK_SPREAD_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
 #endif
 }
 
@@ -543,18 +614,21 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
     const int n_chunks = (int)((total_terms + kDmChunk - 1) / kDmChunk);
     uint32_t *const header = pp.spread_ws + (size_t)problem * pp.spread_ws_words;
     uint32_t *const chunk_flag = header + kSpreadHeaderWords;
-    uint32_t *const products = chunk_flag + ((n_chunks + 63) & ~63);  // [n_chunks][kDmTerms][kDmChunk] floats (as bits)
+    uint32_t *const values = chunk_flag + ((n_chunks + 63) & ~63);  // [n_chunks][kSpreadValues][kDmChunk] floats (as bits)
     const float scale = (float)(1 << (pp.n_levels - 1));
 
     if (role == 0) {
         // ================= the consumer =================
-        const bool chain_wave = wave == 0;
+        const bool chain_wave = wave < kSpreadChainWaves;
         if (chain_wave) {
-            __builtin_amdgcn_s_setprio(3);  // the chain IS the launch: it goes ahead of the loader wave on its SIMD (2.67 -> 2.59 ms; with rounds of eight 2.53)
+            __builtin_amdgcn_s_setprio(3);  // the chain IS the launch: it goes ahead of the loader wave on its SIMD
         }
-        float *const ring = reinterpret_cast<float *>(dm_lds);            // [2][kDmProducers][kDmTerms][kDmRow]
+        float *const ring = reinterpret_cast<float *>(dm_lds);            // [2][kSpreadLoaders][kDmTerms][kDmRow] (of the [2][kDmProducers] allocated)
         float *const sums = ring + 2 * kDmProducers * kDmTerms * kDmRow;  // [96]
-        const int n_rounds = (n_chunks + kDmProducers - 1) / kDmProducers;
+        const int n_rounds = (n_chunks + kSpreadLoaders - 1) / kSpreadLoaders;
+        // chain waves: lanes 4 s .. 4 s + 3 of wave w hold sum 16 w + s (the lanes beyond sum 26 repeat it: DPP wants every lane on)
+        const int my_sum = min(wave * 16 + (lane >> 2), kDmTerms - 1);
+        const float4 *const my_terms = reinterpret_cast<const float4 *>(ring + my_sum * kDmRow) + (lane & 3);
         Quat q = {pr.pose[1], pr.pose[2], pr.pose[3], pr.pose[0]};
         float px = pr.pose[4], py = pr.pose[5], pz = pr.pose[6];
         uint32_t iterations = 0, g = 0;
@@ -580,12 +654,12 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                     spread_stores_done();
                     spread_publish(header, g + 1u);
                 }
-                // ---- the stream: loaders bring chunk round r + 1 into the ring while wave 0 adds round r ----
+                // ---- the stream: the loaders bring round r + 1 into the ring while waves 0 and 1 add round r ----
                 float acc = 0.0f;
                 bool wait_failed = false;
                 for (int round = 0; round < n_rounds; ++round) {
                     if (!chain_wave) {
-                        const int chunk = round * kDmProducers + (wave - 1);
+                        const int chunk = round * kSpreadLoaders + (wave - kSpreadChainWaves);
                         if (chunk < n_chunks) {
                             uint32_t seen;
                             // (a wave whose wait has run out once does not wait again: the iteration is lost anyway, and a second
@@ -593,30 +667,43 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
                             if (!wait_failed && !spread_wait(chunk_flag + chunk, g + 1u, g + 1u, seen)) {
                                 wait_failed = true;
                             }
-                            const uint32_t *src = products + (size_t)chunk * (kDmTerms * kDmChunk) + lane;
-                            float *slot = ring + (((round & 1) * kDmProducers + (wave - 1)) * kDmTerms) * kDmRow + lane;
-                            uint32_t v[kDmTerms];
+                            const uint32_t *src = values + (size_t)chunk * (kSpreadValues * kDmChunk) + lane;
+                            float *slot = ring + (((round & 1) * kSpreadLoaders + (wave - kSpreadChainWaves)) * kDmTerms) * kDmRow + lane;
+                            float jac[6];
 #pragma unroll
-                            for (int k = 0; k < kDmTerms; ++k) {
-                                v[k] = spread_load(src + k * kDmChunk);
+                            for (int r = 0; r < 6; ++r) {
+                                jac[r] = __uint_as_float(spread_load(src + r * kDmChunk));
+                            }
+                            const float residual = __uint_as_float(spread_load(src + 6 * kDmChunk));
+                            // the 27 products of the term, as the one-workgroup kernel forms them (H upper triangle row-major, then b)
+                            int k = 0;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                                for (int c = r; c < 6; ++c) {
+                                    slot[k * kDmRow] = jac[r] * jac[c];
+                                    ++k;
+                                }
                             }
 #pragma unroll
-                            for (int k = 0; k < kDmTerms; ++k) {
-                                slot[k * kDmRow] = __uint_as_float(v[k]);
+                            for (int r = 0; r < 6; ++r) {
+                                slot[(21 + r) * kDmRow] = residual * jac[r];
                             }
                         }
                     }
                     __syncthreads();
-                    if (chain_wave && lane < kDmTerms) {
-                        for (int w = 0; w < kDmProducers; ++w) {
-                            if (round * kDmProducers + w < n_chunks) {
-                                acc = dm_chain_chunk(acc, ring + ((((round & 1) * kDmProducers + w) * kDmTerms) + lane) * kDmRow);
-                            }
-                        }
+                    if (chain_wave) {
+                        const float4 *t = my_terms + ((round & 1) * kSpreadLoaders) * kDmChunkStep4;
+                        const int chunks = n_chunks - round * kSpreadLoaders;
+                        acc = chunks >= kSpreadLoaders ? dm_chain_quads_round<kSpreadLoaders>(acc, t) : dm_chain_quads_tail(acc, t, chunks);
                     }
                 }
-                if (chain_wave) {
-                    dm_solve(sums, acc, lane);
+                if (chain_wave && (lane & 3) == 0 && wave * 16 + (lane >> 2) < kDmTerms) {
+                    sums[wave * 16 + (lane >> 2)] = acc;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    dm_solve<false>(sums, 0.0f, lane);
                 }
                 // a loader whose wait ran out: every thread learns it (the barrier below is the one the solve needs anyway)
                 if (wait_failed && lane == 0) {
@@ -723,20 +810,12 @@ __global__ void __launch_bounds__(kDmWaves * kWave) direct_track_spread_kernel(c
         for (; chunk < n_chunks; chunk += stride_chunks) {
             float jac[6], residual;
             dm_term(feat, pp, ref, cur, ti < n_track, ti, tpix, inv_patch_cols, jac, residual);
-            uint32_t *dst = products + (size_t)chunk * (kDmTerms * kDmChunk) + lane;
-            int k = 0;
+            uint32_t *dst = values + (size_t)chunk * (kSpreadValues * kDmChunk) + lane;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int c = r; c < 6; ++c) {
-                    spread_store(dst + k * kDmChunk, __float_as_uint(jac[r] * jac[c]));
-                    ++k;
-                }
+                spread_store(dst + r * kDmChunk, __float_as_uint(jac[r]));
             }
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                spread_store(dst + (21 + r) * kDmChunk, __float_as_uint(residual * jac[r]));
-            }
+            spread_store(dst + 6 * kDmChunk, __float_as_uint(residual));
             spread_stores_done();
             if (lane == 0) {
                 spread_publish(chunk_flag + chunk, tag);
@@ -773,7 +852,7 @@ size_t direct_lds_bytes(uint32_t max_features) {
 size_t direct_spread_ws_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols) {
     const long long total_terms = (long long)n_track * patch_rows * patch_cols;
     const long long n_chunks = (total_terms + kDmChunk - 1) / kDmChunk;
-    return sizeof(uint32_t) * (size_t)(kSpreadHeaderWords + ((n_chunks + 63) & ~63ll) + n_chunks * (long long)(kDmTerms * kDmChunk));
+    return sizeof(uint32_t) * (size_t)(kSpreadHeaderWords + ((n_chunks + 63) & ~63ll) + n_chunks * (long long)(kSpreadValues * kDmChunk));
 }
 
 size_t direct_spread_clear_bytes(uint32_t n_track, int32_t patch_rows, int32_t patch_cols) {

@@ -217,13 +217,14 @@ int klt_policy_waves(int model, int method_class, int consider_luminance, int lo
 
 namespace {
 
-// Direct method: batches up to this size are spread over the chip (1 + NP workgroups per problem), while at least so many producer
-// workgroups per problem fit beside the others.  Larger batches were measured spread as well (round 5, scripts/direct_batch_time.py,
-// 300 points x 13 x 13 x 4 levels, spread / one workgroup each: 6 problems 1.67 / 1.84 ms, 8: 2.08 / 1.84, 12: 2.28 / 1.86, 16: 2.69 /
-// 1.86, 30: 4.14 / 1.87): with fewer than about 30 producers per consumer the hand-offs through L2 cost more than the idle compute
-// units were worth — from seven problems on one workgroup per problem IS the fast form, and its time is one problem's.
-constexpr int kDirectSpreadMaxProblems = 6;
-constexpr int kDirectSpreadMinProducers = 8;
+// Direct method: a batch is spread over the chip (1 + NP workgroups per problem) while at least two producer workgroups per problem
+// fit beside the others (NP = 32 for up to six problems, then what the 224 usable workgroups of a whole MI355X allow).  Round 5, same box,
+// scripts/direct_batch_time.py (300 points x 13 x 13 x 4 levels), spread / one workgroup per problem, ms: 1 problem 1.01 / 1.81,
+// 6: 1.05 / 1.85, 12: 1.11 / 1.85, 24 (NP 8): 1.16 / 1.86, 32 (6): 1.21 / 1.86, 44 (4): 1.30 / 1.87, 56 (3): 1.41 / 1.89, 64 (2): 1.39 /
+// 1.89, 74 (2): 1.54 / 1.88, 100 (1): 2.03 / 1.93 — one producer workgroup does not keep up with its consumer's chain, two do
+// (profiles/r5_direct_spread_consumer.txt).  Beyond that one workgroup per problem IS the fast form, and its time is one problem's.
+constexpr int kDirectSpreadMaxProblems = 112;  // (two producers each no longer fit from 75 problems on a whole device: the fit decides)
+constexpr int kDirectSpreadMinProducers = 2;
 constexpr uint32_t kTailLongFrom = 24;  // iterations of a call's longest feature from which the call counts as tail-bound
 constexpr uint32_t kTailHold = 8;       // launches of the variant for which one such report holds
 constexpr uint32_t kTailFresh = 256;    // launches of the context a report may lag behind (the host enqueues far ahead of the device)
@@ -2198,12 +2199,16 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         if (const char *min_env = FTK_ENV(ctx, direct_spread_min_terms)) {
             min_terms = atoll(min_env);  // tests: spread even tiny problems (producers whose waves own no chunk)
         }
-        bool spread = producers > 0 && !ctx->direct_spread_off && n_problems <= kDirectSpreadMaxProblems && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global &&
+        int max_problems = kDirectSpreadMaxProblems;
+        if (const char *max_env = FTK_ENV(ctx, direct_spread_max_problems)) {
+            max_problems = atoi(max_env);  // experiments: scripts/direct_batch_time.py
+        }
+        bool spread = producers > 0 && !ctx->direct_spread_off && n_problems <= max_problems && !p.tree && opt->method == FTK_METHOD_DIRECT && !feat_in_global &&
                       max_features > 0 && terms >= min_terms && terms < (1ll << 31);
         if (spread) {
             // Every workgroup of the launch must be resident at once (consumer and producers wait for each other): size the producers from
             // what THIS device holds — occupancy of the kernel as launched x its compute units (256 on a whole MI355X, 32 on a CPX partition),
-            // an eighth left free for whatever else runs — and keep the one-workgroup kernel when fewer than 1 + 8 fit per problem.
+            // an eighth left free for whatever else runs — and keep the one-workgroup kernel when fewer than 1 + 2 fit per problem.
             if (ctx->direct_spread_resident < 0 || ctx->direct_spread_resident_features != max_features) {
                 ctx->direct_spread_resident = ftk::direct_spread_resident_groups(max_features, ctx->device);
                 ctx->direct_spread_resident_features = max_features;
@@ -2219,8 +2224,9 @@ int ftk_direct_track_batch_device(ftk_context *ctx, const ftk_direct_options *op
         }
         size_t ws = 0;
         if (spread) {
-            // Workspace: [chunk][27][64] products per problem.  Not beyond 512 MB in total (127 x 127 patches x 768 features would be
-            // 1.3 GB per problem: such problems keep the one-workgroup kernel), word offsets must fit 32 bits, and a buffer that would have
+            // Workspace: [chunk][7][64] values per problem (the Jacobian row and the residual of every term).  Not beyond 512 MB in total
+            // (127 x 127 patches x 768 features would be 347 MB per problem: two such problems keep the one-workgroup kernel), word
+            // offsets must fit 32 bits, and a buffer that would have
             // to GROW while the stream is being captured is an error the caller can act on, not a hipMalloc inside the capture.
             ws = align_up(ftk::direct_spread_ws_bytes(max_features, p.patch_rows, p.patch_cols), 256);
             if (ws / sizeof(uint32_t) > 0xFFFFFFFFull || ws * (size_t)n_problems > (512ull << 20)) {

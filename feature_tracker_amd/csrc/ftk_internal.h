@@ -22,7 +22,7 @@ using ftk::DevImage;
     X(klt_sched_dump, "FTK_KLT_SCHED_DUMP") X(stamps_dump, "FTK_STAMPS_DUMP") X(klt_zerocopy, "FTK_KLT_ZEROCOPY") X(pyramid_zerocopy, "FTK_PYRAMID_ZEROCOPY") \
     X(match_wgs, "FTK_MATCH_WGS") X(match_splits, "FTK_MATCH_SPLITS") X(match_any_per, "FTK_MATCH_ANY_PER") X(match_kernel, "FTK_MATCH_KERNEL") \
     X(match_boxes, "FTK_MATCH_BOXES") X(match_stamps_dump, "FTK_MATCH_STAMPS_DUMP") X(match_small, "FTK_MATCH_SMALL") \
-    X(direct_spread, "FTK_DIRECT_SPREAD") X(direct_spread_min_terms, "FTK_DIRECT_SPREAD_MIN_TERMS") X(direct_spread_resident, "FTK_DIRECT_SPREAD_RESIDENT") X(direct_spread_poison, "FTK_DIRECT_SPREAD_POISON") \
+    X(direct_spread, "FTK_DIRECT_SPREAD") X(direct_spread_min_terms, "FTK_DIRECT_SPREAD_MIN_TERMS") X(direct_spread_resident, "FTK_DIRECT_SPREAD_RESIDENT") X(direct_spread_poison, "FTK_DIRECT_SPREAD_POISON") X(direct_spread_max_problems, "FTK_DIRECT_SPREAD_MAX_PROBLEMS") \
     X(cosine_kernel, "FTK_COSINE_KERNEL") X(cosine_chunked, "FTK_COSINE_CHUNKED") X(cosine_splits, "FTK_COSINE_SPLITS") X(cosine_two_pass, "FTK_COSINE_TWO_PASS") \
     X(cosine_small, "FTK_COSINE_SMALL") X(cosine_small_any, "FTK_COSINE_SMALL_ANY") X(reduction, "FTK_REDUCTION") X(klt_policy, "FTK_KLT_POLICY") X(klt_quad, "FTK_KLT_QUAD") X(klt_tail, "FTK_KLT_TAIL") X(klt_sched_min, "FTK_KLT_SCHED_MIN") X(klt_tail_class, "FTK_KLT_TAIL_CLASS") X(pinned_noncoherent, "FTK_PINNED_NONCOHERENT")
 

@@ -22,11 +22,14 @@ def main():
     with torch.cuda.stream(stream):
         ctx = D.context_on_stream(stream, 0)
         rp, cp = D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev)
+        spread_env = os.environ.get("FTK_DIRECT_SPREAD")  # (=n: that many producer workgroups per problem, if they fit)
         for count in (int(a) for a in sys.argv[1:]):
             row = {}
             for mode in ("spread", "one-workgroup"):
                 if mode == "spread":
                     os.environ.pop("FTK_DIRECT_SPREAD", None)
+                    if spread_env is not None:
+                        os.environ["FTK_DIRECT_SPREAD"] = spread_env
                 else:
                     os.environ["FTK_DIRECT_SPREAD"] = "0"
                 ctx.refresh_env()

@@ -161,10 +161,11 @@ def test_world_frame_overload(ftk, oracle):
     assert np.array_equal(p_wc.view(np.uint32), (oracle.quat_rotate(ref_q, p_rc) + ref_p).astype(np.float32).view(np.uint32))
 
 
-@pytest.mark.parametrize("sizes", [(300, 300), (300, 1, 0, 120), (40, 260, 500), (300, 280, 260, 240, 220, 200, 180, 160, 140, 120, 100, 80), tuple([150] * 30)])
+@pytest.mark.parametrize("sizes", [(300, 300), (300, 1, 0, 120), (40, 260, 500), (300, 280, 260, 240, 220, 200, 180, 160, 140, 120, 100, 80), tuple([150] * 30), tuple([110] * 70)])
 def test_small_batches_of_problems_match_the_oracle_problem_by_problem(ftk, oracle, sizes):
-    """ftk_direct_track_batch_device with two to thirty problems of different sizes (one of a single feature, one empty): on the default
-    dispatch each problem is spread over its own group of workgroups with its own workspace; every problem's pose, positions, status
+    """ftk_direct_track_batch_device with two to seventy problems of different sizes (one of a single feature, one empty): on the default
+    dispatch each problem is spread over its own group of workgroups (32 producers each for up to six problems, two each for seventy)
+    with its own workspace; every problem's pose, positions, status
     and iteration count must be those of the oracle run on that problem alone."""
     import torch
     from feature_tracker_amd import device as D
@@ -203,14 +204,14 @@ def test_small_batches_of_problems_match_the_oracle_problem_by_problem(ftk, orac
 def test_spread_launch_that_cannot_be_resident_never_returns_a_poisoned_pose(ftk, oracle, switch):
     """the spread kernel needs its 1 + NP workgroups co-resident.  (1) The producers are sized from what the
     device holds (occupancy x compute units; FTK_DIRECT_SPREAD_RESIDENT pretends a 32-CU partition or less) and the one-workgroup
-    kernel runs when fewer than 1 + 8 fit; (2) a spread launch whose bounded waits ran out (FTK_DIRECT_SPREAD_POISON=1 makes the
+    kernel runs when fewer than 1 + 2 fit; (2) a spread launch whose bounded waits ran out (FTK_DIRECT_SPREAD_POISON=1 makes the
     consumer behave so) leaves header word 1 set and a NaN pose on the device — the synchronous entry point must re-run the problem on
     one workgroup and return the oracle's pose, with a note in ftk_last_error()."""
     from feature_tracker_amd import _native as N
     rl, cl, uv, pts = scene(n=300)
     switch("FTK_DIRECT_SPREAD", "32")
     switch("FTK_DIRECT_SPREAD_MIN_TERMS", "1")
-    for resident in ("33", "9", "4"):
+    for resident in ("33", "9", "4", "3", "2"):
         switch("FTK_DIRECT_SPREAD_RESIDENT", resident)
         g, c = run_both(ftk, oracle, rl, cl, uv, pts, max_points=300)
         assert_identical(g, c)
