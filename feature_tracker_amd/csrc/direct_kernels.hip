@@ -155,12 +155,7 @@ __device__ __forceinline__ void dm_quad_reads(float4 (&a)[4], const float4 *t) {
     a[2] = t[8];
     a[3] = t[12];
 }
-__device__ __forceinline__ float dm_quad_adds(float acc, const float4 (&a)[4]) {
-    acc = chain_quad_step16(acc, a[0]);
-    acc = chain_quad_step16(acc, a[1]);
-    acc = chain_quad_step16(acc, a[2]);
-    return chain_quad_step16(acc, a[3]);
-}
+__device__ __forceinline__ float dm_quad_adds(float acc, const float4 (&a)[4]) { return chain_quad_step64(acc, a[0], a[1], a[2], a[3]); }
 template <int kChunks>
 __device__ __forceinline__ float dm_chain_quads_round(float acc, const float4 *t) {
     float4 a[4], b[4];

@@ -35,6 +35,9 @@
 #ifndef FTK_PB_QUAD_CHAIN
 #define FTK_PB_QUAD_CHAIN 1  // the exact-order chain through the DPP network (klt_common.h chain_quads_left); 0: one lane per sum (round 4)
 #endif
+#ifndef FTK_PB_CHAIN_AHEAD
+#define FTK_PB_CHAIN_AHEAD 1  // the consumer reads chunk q + 1 of a step under the adds of chunk q (klt_common.h chain_quads_chunks); 0: chunk by chunk
+#endif
 #include "klt_common.h"
 
 #include <stdlib.h>
@@ -425,6 +428,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
     const int n_chunks = (p.P + kChunk - 1) / kChunk;
     const int n_steps = (n_chunks + np - 1) / np;
     const int ring_mask = pb_ring_slots(b.nwaves) - 1;
+#if FTK_PB_QUAD_CHAIN && FTK_PB_CHAIN_AHEAD
+    const bool last_chunk_short = p.P - (n_chunks - 1) * kChunk <= 48;  // (a last chunk of 49 .. 64 terms is a full one: its row is zero beyond P)
+    const float *const quad_rows = c.ring + min(b.lane >> 2, kTerms - 1) * kRingRow + 4 * (b.lane & 3);  // this lane's quad's sum, its 4 of every 16 terms
+#endif
 
     // basic_klt.cpp:10,18-19 (pyramid) / :59-86 (single level)
     const float full_ref_u = full_ref.x, full_ref_v = full_ref.y;
@@ -660,12 +667,26 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                     if (consumer) {
                         // the whole wave: quad k = lanes 4 k .. 4 k + 3 carries sum k (klt_common.h, "quad chain"); the quads behind the
                         // fifth follow its rows and are ignored
+#if FTK_PB_CHAIN_AHEAD
+                        // the step's chunks are all in the ring: the full ones in one go (the next chunk's reads under this one's adds),
+                        // then the patch's last chunk if it has fewer than 49 terms
+                        const int first = s * np, count = min(np, n_chunks - first);
+                        const int full = count - ((first + count == n_chunks && last_chunk_short) ? 1 : 0);
+                        const float *const row = quad_rows + ((s & ring_mask) * np) * (kTerms * kRingRow);
+                        if (full > 0) {
+                            acc = chain_quads_chunks(acc, reinterpret_cast<const float4 *>(row), full, kTerms * kRingRow / 4);
+                        }
+                        if (full < count) {
+                            acc = chain_quads_left(acc, row + full * (kTerms * kRingRow), p.P - (n_chunks - 1) * kChunk);
+                        }
+#else
                         const int sum = min(b.lane >> 2, kTerms - 1);
                         for (int q = 0; q < np; ++q) {
                             if (s * np + q < n_chunks) {
                                 acc = chain_quads_left(acc, c.ring + (((s & ring_mask) * np + q) * kTerms + sum) * kRingRow + 4 * (b.lane & 3), p.P - (s * np + q) * kChunk);
                             }
                         }
+#endif
                     }
 #else
                     if (consumer && b.lane < kTerms) {

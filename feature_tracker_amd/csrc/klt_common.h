@@ -1007,6 +1007,28 @@ __device__ __forceinline__ float chain_chunk_left(float acc, const float *row, i
 // front of this block, the two wait states a DPP operand needs after a VALU write are there (it cannot see the DPP in the asm).
 __device__ __forceinline__ float chain_quad_step16(float acc, const float4 q) {
     asm volatile("s_nop 1\n" FTK_QADD4(0) FTK_QADD4(1) FTK_QADD4(2) FTK_QADD4(3) : "+v"(acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+#ifdef FTK_QUAD_EXTRA_ZERO_ADDS  // experiment: what do 16 more adds per 16 terms cost (acc + 0 == acc)?
+    {
+        const float z = 0.0f;
+        asm volatile("s_nop 1\n" FTK_QADD4(0) FTK_QADD4(1) FTK_QADD4(2) FTK_QADD4(3) : "+v"(acc) : "v"(z), "v"(z), "v"(z), "v"(z));
+    }
+#endif
+    return acc;
+}
+
+// 64 terms (four reads) in one block: one `s_nop` and one wait for the reads per 64 adds instead of per 16 — a lone wave issues an
+// instruction of any kind every 4 - 5 cycles, so each instruction that is not an add costs as much as a term.
+#ifndef FTK_QUAD_STEP64
+#define FTK_QUAD_STEP64 1  // 0: 16-add blocks everywhere (A / B, scripts/build_variant.sh)
+#endif
+#define FTK_QADD4R(i, a, b, c, d) FTK_QADD(i, a) FTK_QADD(i, b) FTK_QADD(i, c) FTK_QADD(i, d)
+#define FTK_QADD16R(a, b, c, d) FTK_QADD4R(0, a, b, c, d) FTK_QADD4R(1, a, b, c, d) FTK_QADD4R(2, a, b, c, d) FTK_QADD4R(3, a, b, c, d)
+__device__ __forceinline__ float chain_quad_step64(float acc, const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
+    asm volatile("s_nop 1\n" FTK_QADD16R("%1", "%2", "%3", "%4") FTK_QADD16R("%5", "%6", "%7", "%8") FTK_QADD16R("%9", "%10", "%11", "%12")
+                     FTK_QADD16R("%13", "%14", "%15", "%16")
+                 : "+v"(acc)
+                 : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w),
+                   "v"(q3.x), "v"(q3.y), "v"(q3.z), "v"(q3.w));
     return acc;
 }
 
@@ -1020,8 +1042,8 @@ __device__ __forceinline__ float chain_quads_left(float acc, const float *quad_r
     if (left > 48) {
         const float4 q1 = t[4], q2 = t[8], q3 = t[12];
         __builtin_amdgcn_sched_barrier(0);
-        acc = chain_quad_step16(acc, q0);
-        acc = chain_quad_step16(acc, q1);
+        acc = chain_quad_step16(acc, q0);  // (16-add blocks here: the reads were issued just now, and the first block can start on the
+        acc = chain_quad_step16(acc, q1);  // first read; one 64-add block measured 1.6 - 2.3 % slower in the pipelined Basic kernel)
         acc = chain_quad_step16(acc, q2);
         return chain_quad_step16(acc, q3);
     }
@@ -1041,44 +1063,123 @@ __device__ __forceinline__ float chain_quads_left(float acc, const float *quad_r
     return chain_quad_step16(acc, q0);
 }
 
-// `n16` 16-term steps (n16 >= 1, wave-uniform) from `t_lane` = this lane's first float4, consecutive steps `step4` float4 apart: two
-// register pairs, the reads two steps ahead of the adds.
-__device__ __forceinline__ float chain_quads_strided(float acc, const float4 *t, int n16, int step4) {
-    float4 qa = t[0], qb = t[n16 > 1 ? step4 : 0], qc, qd;
-    int j = 0;
+// `count` FULL chunks (count >= 1, wave-uniform), `step4` float4 from one chunk's row to the next.  Four term registers as in
+// chain_quads_left, but each is read again — for the NEXT chunk — as soon as its 16 adds are through, so a read has the other 48 adds
+// to arrive: no LDS latency between chunks, no registers beyond chain_quads_left's (a second set of four cost the pipelined Basic
+// kernel a wave per SIMD), one address per chunk.  (Behind the last chunk the reads repeat that chunk: valid memory, never used.)
+__device__ __forceinline__ float chain_quads_chunks(float acc, const float4 *t, int count, int step4) {
+    float4 q0 = t[0], q1 = t[4], q2 = t[8], q3 = t[12];
 #pragma nounroll
-    for (; j + 4 <= n16; j += 4) {
-        qc = t[(j + 2) * step4];
-        qd = t[(j + 3) * step4];
+    for (int w = 0; w < count; ++w) {
+        t += w + 1 < count ? step4 : 0;
         __builtin_amdgcn_sched_barrier(0);
-        acc = chain_quad_step16(acc, qa);
-        acc = chain_quad_step16(acc, qb);
-        qa = t[(j + 4 < n16 ? j + 4 : 0) * step4];  // (wave-uniform selects; a read past the end is never made)
-        qb = t[(j + 5 < n16 ? j + 5 : 0) * step4];
+        acc = chain_quad_step16(acc, q0);
+        q0 = t[0];
         __builtin_amdgcn_sched_barrier(0);
-        acc = chain_quad_step16(acc, qc);
-        acc = chain_quad_step16(acc, qd);
-    }
-    const int rem = n16 - j;  // 0 .. 3 steps left; qa / qb hold the first two
-    if (rem > 2) {
-        qc = t[(j + 2) * step4];
+        acc = chain_quad_step16(acc, q1);
+        q1 = t[4];
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if (rem > 0) {
-        acc = chain_quad_step16(acc, qa);
-    }
-    if (rem > 1) {
-        acc = chain_quad_step16(acc, qb);
-    }
-    if (rem > 2) {
-        acc = chain_quad_step16(acc, qc);
+        acc = chain_quad_step16(acc, q2);
+        q2 = t[8];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = chain_quad_step16(acc, q3);
+        q3 = t[12];
     }
     return acc;
 }
 
+// `n16` 16-term steps (n16 >= 1, wave-uniform) from `t_lane` = this lane's first float4, consecutive steps `step4` float4 apart: two
+// register pairs, the reads two steps ahead of the adds.
+// kBlocks64 (the one-wave-per-feature kernels, where the chain wave is alone on its SIMD and every issued instruction counts: Basic /
+// affine fast on the real pair -4 .. -5 %): 64-add blocks; otherwise (the multi-wave kernels: no consistent difference) 16-add blocks.
+template <bool kBlocks64 = false>
+__device__ __forceinline__ float chain_quads_strided(float acc, const float4 *t, int n16, int step4) {
+    if constexpr (kBlocks64 && FTK_QUAD_STEP64) {
+        // blocks of four steps (64 adds in one asm block), the reads of the next block issued before the adds of this one; the up to
+        // three steps behind the last block are read up front and kept in registers (no LDS latency at the end of the chain)
+        const int rem = n16 & 3, tail = n16 - rem;
+        const float4 r0 = t[(rem > 0 ? tail : 0) * step4], r1 = t[(rem > 1 ? tail + 1 : 0) * step4], r2 = t[(rem > 2 ? tail + 2 : 0) * step4];
+        if (tail > 0) {
+            float4 a0 = t[0], a1 = t[step4], a2 = t[2 * step4], a3 = t[3 * step4], b0, b1, b2, b3;
+            int j = 0;
+#pragma nounroll
+            for (;;) {
+                const bool more_b = j + 8 <= tail;
+                if (more_b) {
+                    b0 = t[(j + 4) * step4];
+                    b1 = t[(j + 5) * step4];
+                    b2 = t[(j + 6) * step4];
+                    b3 = t[(j + 7) * step4];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = chain_quad_step64(acc, a0, a1, a2, a3);
+                j += 4;
+                if (!more_b) {
+                    break;
+                }
+                const bool more_a = j + 8 <= tail;
+                if (more_a) {
+                    a0 = t[(j + 4) * step4];
+                    a1 = t[(j + 5) * step4];
+                    a2 = t[(j + 6) * step4];
+                    a3 = t[(j + 7) * step4];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = chain_quad_step64(acc, b0, b1, b2, b3);
+                j += 4;
+                if (!more_a) {
+                    break;
+                }
+            }
+        }
+        if (rem > 0) {
+            acc = chain_quad_step16(acc, r0);
+        }
+        if (rem > 1) {
+            acc = chain_quad_step16(acc, r1);
+        }
+        if (rem > 2) {
+            acc = chain_quad_step16(acc, r2);
+        }
+        return acc;
+    } else {
+        float4 qa = t[0], qb = t[n16 > 1 ? step4 : 0], qc, qd;
+        int j = 0;
+#pragma nounroll
+        for (; j + 4 <= n16; j += 4) {
+            qc = t[(j + 2) * step4];
+            qd = t[(j + 3) * step4];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = chain_quad_step16(acc, qa);
+            acc = chain_quad_step16(acc, qb);
+            qa = t[(j + 4 < n16 ? j + 4 : 0) * step4];  // (wave-uniform selects; a read past the end is never made)
+            qb = t[(j + 5 < n16 ? j + 5 : 0) * step4];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = chain_quad_step16(acc, qc);
+            acc = chain_quad_step16(acc, qd);
+        }
+        const int rem = n16 - j;  // 0 .. 3 steps left; qa / qb hold the first two
+        if (rem > 2) {
+            qc = t[(j + 2) * step4];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rem > 0) {
+            acc = chain_quad_step16(acc, qa);
+        }
+        if (rem > 1) {
+            acc = chain_quad_step16(acc, qb);
+        }
+        if (rem > 2) {
+            acc = chain_quad_step16(acc, qc);
+        }
+        return acc;
+    }
+}
+
 // A whole row [n16 * 16 terms] of one sum: `quad_row` = the row + 4 * (lane & 3) floats.
+template <bool kBlocks64 = false>
 __device__ __forceinline__ float chain_quads_row(float acc, const float *quad_row, int n16) {
-    return chain_quads_strided(acc, reinterpret_cast<const float4 *>(quad_row), n16, 4);
+    return chain_quads_strided<kBlocks64>(acc, reinterpret_cast<const float4 *>(quad_row), n16, 4);
 }
 
 constexpr int kChunkPixels = 64;              // pixels per chunk of the chunked sweep / chain loops = one wave round

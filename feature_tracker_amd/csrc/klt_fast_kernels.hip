@@ -540,7 +540,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
 #if FTK_FK_QUAD_CHAIN
                     // every lane: quad q carries sum q (klt_common.h "quad chain"); the quads behind the last sum follow its row, ignored
                     constexpr int kSumLanes = 4;
-                    acc = chain_quads_row(0.0f, c.terms + min(lane >> 2, chains - 1) * pitch + 4 * (lane & 3), p.Ppad >> 4);
+                    acc = chain_quads_row<true>(0.0f, c.terms + min(lane >> 2, chains - 1) * pitch + 4 * (lane & 3), p.Ppad >> 4);
 #else
                     constexpr int kSumLanes = 1;
                     if (lane < chains) {
@@ -729,7 +729,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FTK_WAVES_PER_EU))) __launch_
                         fk_fence();
                         FTK_STAMP_END(b, 3);
 #if FTK_FK_QUAD_CHAIN
-                        acc = chain_quads_row(0.0f, c.terms + imul(min(lane >> 2, 5), pitch) + 4 * (lane & 3), p.Ppad >> 4);  // quad q carries bias sum q
+                        acc = chain_quads_row<true>(0.0f, c.terms + imul(min(lane >> 2, 5), pitch) + 4 * (lane & 3), p.Ppad >> 4);  // quad q carries bias sum q
 #else
                         if (lane < 6) {
                             acc = chain_lane(c.terms + imul(lane, pitch), p.Ppad);

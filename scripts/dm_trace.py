@@ -58,6 +58,8 @@ def main():
         a, b, c, d = lt[8:, 0], lt[8:, 1], lt[8:, 2], lt[8:, 3]
         print("loader wave 7, medians over rounds 8.., ns: poll %.0f | loads %.0f | LDS stores %.0f | then waits at the barrier for %.0f (its round %.0f)" % (
             np.median(b - a), np.median(c - b), np.median(d - c), np.median(a[1:] - d[:-1]), np.median(a[1:] - a[:-1])))
+    if buf[8190]:
+        print("shader clock over the iteration's stream: %.2f GHz (s_memtime ticks per s_memrealtime tick x 100 MHz)" % ((int(buf[8189]) - int(buf[8190])) / (t[-1] / 10) * 0.1))
     print("first 12 rounds (wait, chain) ns:", [(int(a), int(b)) for a, b in zip(wait[:12], chain[:12])])
 
 

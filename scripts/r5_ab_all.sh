@@ -1,9 +1,9 @@
 #!/bin/bash
-# A / B of the quad (DPP) chains, every tracker variant, same box: round-4 chains (diag/libftk_hip_r4chains.so) against the default build.
+# A / B of the quad (DPP) chains, every tracker variant, same box: round-4 chains (diag/libftk_hip_${BASE:-r4chains}.so) against the default build.
 # Synthetic scene (2 000 features, 13 x 13) and the reference's example pair (300 / 2 000 features).
 D=feature_tracker_amd/csrc/diag
 V="basic:inverse basic:direct basic:fast affine:inverse affine:direct affine:fast lssd:inverse lssd:direct lssd:fast"
-for lib in $D/libftk_hip_r4chains.so feature_tracker_amd/csrc/libftk_hip.so; do
+for lib in $D/libftk_hip_${BASE:-r4chains}.so feature_tracker_amd/csrc/libftk_hip.so; do
   echo "=== $lib"
   S=""; R3=""; R2=""
   for v in $V; do S="$S $v:2000:6"; R3="$R3 $v:300:6"; R2="$R2 $v:2000:6"; done
