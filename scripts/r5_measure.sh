@@ -26,6 +26,7 @@ elif [ "$PART" = B ]; then
 elif [ "$PART" = C ]; then
   python scripts/soak_parity.py 360 2029 > $O/soak_parity.txt 2>&1; echo "soak rc=$?"
   python scripts/soak_parity.py 100 41 matcher > $O/soak_matcher.txt 2>&1; echo "soak matcher rc=$?"
+  python scripts/soak_parity.py 200 4242 direct > $O/soak_direct_batches.txt 2>&1; echo "soak direct batches rc=$?"
   bash scripts/run_dropin_programs.sh > $O/dropin_programs.txt 2>&1; echo "dropin rc=$?"
   PYTHONPATH=. python scripts/host_call_latency.py > $O/host_call_latency.txt 2>&1; echo "host latency rc=$?"
 fi

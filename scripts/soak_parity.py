@@ -4,6 +4,9 @@ time budget — every tracker variant, both descriptor matchers, the direct meth
 
     python scripts/soak_parity.py [seconds] [seed] [family]   prints one summary line per family, exits 1 on any mismatch
                                                               family: all (default) | matcher (both matchers only, larger sets)
+                                                              | direct (batches of 1 .. 80 pose problems through the device
+                                                                batch entry: the spread kernel with 32 .. 2 producer workgroups
+                                                                per problem, and one workgroup per problem beyond what fits)
                                                               | tree (REPORTING mode: the trackers in the throughput mode,
                                                                 ftk_set_reduction_mode(TREE) — per-variant px-error statistics
                                                                 against the oracle, nothing asserted, exit code 0)
@@ -193,12 +196,63 @@ def direct_round():
     note("direct", same, f"{w}x{h} L{levels} h{half} n{n} cap{cap}")
 
 
+def direct_batch_round():
+    """One launch of a random batch of pose problems (ftk_direct_track_batch_device); every problem against the oracle run on it alone."""
+    import torch
+    from feature_tracker_amd import device as D
+    w, h = int(rs.choice([320, 640])), int(rs.choice([240, 480]))
+    t = (float(rs.uniform(-6, 6)), float(rs.uniform(-5, 5)))
+    ref, cur = synth.make_image_pair(w, h, t)
+    levels = int(rs.randint(2, 5))
+    rl, cl = synth.build_pyramid(ref, levels), synth.build_pyramid(cur, levels)
+    count = int(rs.choice([1, 2, 5, 6, 7, 12, 24, 40, 70, 76, 80]))
+    half = int(rs.choice([5, 6, 7]))
+    fx, fy, cx, cy = float(rs.uniform(300, 600)), float(rs.uniform(300, 600)), w / 2 + float(rs.uniform(-5, 5)), h / 2 + float(rs.uniform(-5, 5))
+    K = [fx, fy, cx, cy]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = D.context_on_stream(stream, 0)
+        rp, cp = D.upload_pyramid(rl, ctx, dev), D.upload_pyramid(cl, ctx, dev)
+        problems, host = [], []
+        for k in range(count):
+            n = int(rs.choice([0, 1, 60, 110, 150, 220, 300])) if rs.rand() < 0.3 else int(rs.randint(100, 301))
+            uv = synth.make_features(max(n, 1), w, h, seed=int(rs.randint(1 << 30)), margin=min(40.0, w / 8.0), half=half)[:n]
+            z = rs.uniform(2, 30, n).astype(np.float32)
+            pts = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], axis=1).astype(np.float32).reshape(-1, 3)
+            q0 = np.float32([1, 0, 0, 0]) if rs.rand() < 0.5 else np.float32([1, *rs.uniform(-0.01, 0.01, 3)])
+            p0 = np.zeros(3, np.float32) if rs.rand() < 0.5 else rs.uniform(-0.05, 0.05, 3).astype(np.float32)
+            host.append((uv, pts, q0, p0))
+            problems.append(dict(ref=rp, cur=cp, K=K, p_c_in_ref=torch.from_numpy(pts).to(dev).reshape(-1, 3), ref_uv=torch.from_numpy(uv).to(dev).reshape(-1, 2),
+                                 cur_uv=torch.from_numpy(uv.copy()).to(dev).reshape(-1, 2), pose=torch.from_numpy(np.concatenate([q0, p0]).astype(np.float32)).to(dev),
+                                 status=torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)[:n], status_valid=False,
+                                 iterations=torch.zeros(1, dtype=torch.int32, device=dev)))
+        opt = F.DirectMethodOptions()
+        opt.kMaxTrackPointsNumber, opt.kPatchRowHalfSize, opt.kPatchColHalfSize = 300, half, half
+        D.DeviceDirectBatch(opt, problems, ctx).track()
+        stream.synchronize()
+    same = True
+    for (uv, pts, q0, p0), pr in zip(host, problems):
+        pose = pr["pose"].cpu().numpy()
+        if len(uv) == 0:
+            same = same and np.array_equal(pose.view(np.uint32), np.concatenate([q0, p0]).astype(np.float32).view(np.uint32))
+            continue
+        with np.errstate(all="ignore"):
+            ok, c, q, p, st, it = O.direct_track(rl, cl, K, pts, uv, None, q0, p0, half=half, max_points=300)
+        same = same and (np.array_equal(pose[:4].view(np.uint32), np.float32(q).view(np.uint32)) and np.array_equal(pose[4:].view(np.uint32), np.float32(p).view(np.uint32)) and
+                         np.array_equal(pr["cur_uv"].cpu().numpy().view(np.uint32), c.view(np.uint32)) and np.array_equal(pr["status"].cpu().numpy(), st) and
+                         int(pr["iterations"].cpu().numpy()[0]) == it)
+    note(f"direct batch of {count:2d}", same, f"{w}x{h} L{levels} h{half}")
+
+
 t_end = time.time() + budget
 rounds = 0
 t_report = time.time() + 60.0
 while time.time() < t_end:
     if ONLY == "matcher":
         matcher_round()
+    elif ONLY == "direct":
+        direct_batch_round()
     elif ONLY == "tree":
         klt_round()
         direct_round()
